@@ -1,0 +1,62 @@
+"""Seeded synthetic inputs for the matching-cost path.
+
+Guide images are smooth + noise (low-pass filtered uniform noise plus sigma~8 gaussian noise) so the
+3x3 colour covariance of the guided filter is not degenerate; volumes are iid U[0,1) float32
+[D][H][W].  Pure numpy; used by tests and bench.py on both the CPU and the GPU legs.
+"""
+import numpy as np
+
+
+def _box_blur(a, r):
+    """Separable mean filter with edge replication (only used to synthesise smooth guides)."""
+    for axis in (0, 1):
+        pad = [(0, 0)] * a.ndim
+        pad[axis] = (r + 1, r)
+        c = np.cumsum(np.pad(a, pad, mode="edge"), axis=axis, dtype=np.float64)
+        n = a.shape[axis]
+        hi = np.take(c, np.arange(2 * r + 1, 2 * r + 1 + n), axis=axis)
+        lo = np.take(c, np.arange(0, n), axis=axis)
+        a = (hi - lo) / (2 * r + 1)
+    return a
+
+
+def make_guide(H, W, seed=1234):
+    """H x W x 3 uint8 BGR guide image: smooth structure + sigma=8 noise."""
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0, 255, size=(H // 8 + 3, W // 8 + 3, 3))
+    base = _box_blur(base, 1)
+    up = np.repeat(np.repeat(base, 8, axis=0), 8, axis=1)[:H, :W]
+    up = _box_blur(up, 6)
+    # stretch contrast so that edges and flat zones both exist
+    up = (up - up.mean()) * 2.2 + 128.0
+    img = up + rng.normal(0, 8.0, size=(H, W, 3))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_volume(D, H, W, seed=42, chunk=16):
+    """float32 [D][H][W] iid U[0,1) (seed 42)."""
+    rng = np.random.default_rng(seed)
+    vol = np.empty((D, H, W), np.float32)
+    for d0 in range(0, D, chunk):
+        d1 = min(D, d0 + chunk)
+        vol[d0:d1] = rng.random((d1 - d0, H, W), dtype=np.float32)
+    return vol
+
+
+def fronto_planes(D):
+    """H1: D fronto-parallel planes a=b=0, c=k."""
+    p = np.zeros((D, 4), np.float32)
+    p[:, 2] = np.arange(D, dtype=np.float32)
+    return p
+
+
+def slanted_planes(n, H, W, max_disp, seed=7):
+    """H2: a,b ~ U(-.5,.5), c such that the disparity at the image centre ~ U(0, max_disp)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    zc = rng.uniform(0, max_disp, n).astype(np.float32)
+    c = (zc - a * np.float32(W / 2) - b * np.float32(H / 2)).astype(np.float32)
+    p = np.zeros((n, 4), np.float32)
+    p[:, 0], p[:, 1], p[:, 2] = a, b, c
+    return p

@@ -1,0 +1,730 @@
+/*
+ * les_oracle.cpp -- CPU restatement of the LocalExpStereo matching-cost hot path (see les_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (no reference golden vectors exist; see header).
+ *
+ * Build: g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ * -ffp-contract=off matters: the reference is built by MSVC x64 /O2 without FMA contraction
+ * ("FMA contraction"), so every a*b+c below is two roundings.
+ *
+ * Citations: LES/<file>:<line> == /root/reference/LocalExpansionStereo/<file>:<line>.
+ * "[recollection]" marks restated OpenCV 3.1 behaviour whose source is not under /root/reference.
+ */
+#include "les_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+// =====================================================================================================
+// cv::RNG  [recollection: OpenCV 3.1 modules/core/include/opencv2/core/operations.hpp]
+//   state = (uint32)state * 4164903690 + (state >> 32);  next() = (uint32)state
+// =====================================================================================================
+extern "C" void les_rng_seed(les_rng* r, uint64_t seed) { r->state = seed ? seed : 0xffffffffULL; }
+
+extern "C" uint32_t les_rng_next(les_rng* r)
+{
+    r->state = (uint64_t)(uint32_t)r->state * 4164903690ULL + (uint32_t)(r->state >> 32);
+    return (uint32_t)r->state;
+}
+extern "C" int les_rng_uniform_int(les_rng* r, int a, int b)
+{
+    return a == b ? a : (int)(les_rng_next(r) % (uint32_t)(b - a) + a);
+}
+extern "C" float les_rng_uniform_float(les_rng* r, float a, float b)
+{
+    float f = les_rng_next(r) * 2.3283064365386962890625e-10f;
+    return f * (b - a) + a;
+}
+extern "C" double les_rng_uniform_double(les_rng* r, double a, double b)
+{
+    uint32_t t = les_rng_next(r);
+    double d = (double)(((uint64_t)t << 32) | les_rng_next(r)) * 5.4210108624275221700372640043497e-20;
+    return d * (b - a) + a;
+}
+
+// =====================================================================================================
+// Plane  (LES/Plane.h)
+// =====================================================================================================
+extern "C" les_plane les_plane_create(float nx, float ny, float nz, float z, float x, float y, float v)
+{
+    les_plane p;                 // LES/Plane.h:23-31
+    p.a = -nx / nz;
+    p.b = -ny / nz;
+    p.c = z - p.a * x - p.b * y;
+    p.v = v;
+    return p;
+}
+extern "C" void les_plane_normal(const les_plane* p, float n[3])
+{
+    // LES/Plane.h:42-50: "Calc sqrt in double then cast to float."  1.0 + a*a + b*b: a*a and b*b are
+    // float products promoted to double for the additions.
+    float nz = float(1.0 / sqrt(1.0 + p->a * p->a + p->b * p->b));
+    n[0] = -p->a * nz;
+    n[1] = -p->b * nz;
+    n[2] = nz;
+}
+extern "C" float les_plane_z(const les_plane* p, float x, float y)
+{
+    return p->a * x + p->b * y + p->c;   // LES/Plane.h:51-54
+}
+
+// =====================================================================================================
+// LayerManager::addLayer  (LES/LayerManager.h:88-185, the #else branch that is compiled)
+// =====================================================================================================
+struct les_layer {
+    int heightBlocks, widthBlocks, unit;
+    std::vector<les_rect> unitRegions, sharedRegions, filterRegions;
+    std::vector<std::vector<int>> sets;
+};
+
+static les_rect rect_and(les_rect a, les_rect b)
+{   // cv::Rect operator& [recollection]: intersection, empty -> Rect()
+    int x1 = std::max(a.x, b.x), y1 = std::max(a.y, b.y);
+    int x2 = std::min(a.x + a.w, b.x + b.w), y2 = std::min(a.y + a.h, b.y + b.h);
+    les_rect r = {x1, y1, x2 - x1, y2 - y1};
+    if (r.w <= 0 || r.h <= 0) r = les_rect{0, 0, 0, 0};
+    return r;
+}
+
+extern "C" les_layer* les_layer_create(int width, int height, int windowR, int unitRegionSize)
+{
+    les_layer* L = new les_layer();
+    les_layer& layer = *L;
+    layer.unit = unitRegionSize;                                           // :92
+    int minsize = std::max(2, unitRegionSize / 2);                         // :93
+    int frac_h = height % unitRegionSize;                                  // :94
+    int frac_w = width % unitRegionSize;                                   // :95
+    int split_h = frac_h >= minsize ? 1 : 0;                               // :96
+    int split_w = frac_w >= minsize ? 1 : 0;                               // :97
+    layer.heightBlocks = (height / unitRegionSize) + split_h;              // :99
+    layer.widthBlocks = (width / unitRegionSize) + split_w;                // :100
+    int n = layer.heightBlocks * layer.widthBlocks;
+    layer.sharedRegions.resize(n);
+    layer.filterRegions.resize(n);
+    layer.unitRegions.resize(n);
+    les_rect imageDomain = {0, 0, width, height};                          // :107
+    for (int i = 0; i < layer.heightBlocks; i++)
+        for (int j = 0; j < layer.widthBlocks; j++) {
+            int r = i * layer.widthBlocks + j;
+            les_rect u = {j * unitRegionSize, i * unitRegionSize, unitRegionSize, unitRegionSize};   // :117-120
+            layer.unitRegions[r] = rect_and(u, imageDomain);                                         // :121
+            les_rect s = {(j - 1) * unitRegionSize, (i - 1) * unitRegionSize, unitRegionSize * 3, unitRegionSize * 3};
+            layer.sharedRegions[r] = rect_and(s, imageDomain);                                       // :123-127
+            les_rect f = {(j - 1) * unitRegionSize - windowR, (i - 1) * unitRegionSize - windowR,
+                          unitRegionSize * 3 + windowR * 2, unitRegionSize * 3 + windowR * 2};
+            layer.filterRegions[r] = rect_and(f, imageDomain);                                       // :129-133
+        }
+    if (split_w == 0) {                                                    // :138-151
+        for (int i = 0; i < layer.heightBlocks; i++) {
+            int x1 = i * layer.widthBlocks + layer.widthBlocks - 1;
+            layer.unitRegions[x1].w += frac_w;
+        }
+        for (int i = 0; i < layer.heightBlocks; i++) {
+            int x1 = i * layer.widthBlocks + layer.widthBlocks - 2;
+            if (layer.widthBlocks - 2 < 0) continue;  // (reference would index out of range; never hit for shipped sizes)
+            layer.sharedRegions[x1].w += frac_w;
+            layer.filterRegions[x1].w += frac_w;
+            layer.filterRegions[x1] = rect_and(layer.filterRegions[x1], imageDomain);
+        }
+    }
+    if (split_h == 0) {                                                    // :152-165
+        for (int j = 0; j < layer.widthBlocks; j++) {
+            int y1 = (layer.heightBlocks - 1) * layer.widthBlocks + j;
+            layer.unitRegions[y1].h += frac_h;
+        }
+        for (int j = 0; j < layer.widthBlocks; j++) {
+            if (layer.heightBlocks - 2 < 0) continue;
+            int y1 = (layer.heightBlocks - 2) * layer.widthBlocks + j;
+            layer.sharedRegions[y1].h += frac_h;
+            layer.filterRegions[y1].h += frac_h;
+            layer.filterRegions[y1] = rect_and(layer.filterRegions[y1], imageDomain);
+        }
+    }
+    std::vector<std::vector<int>> sets(16);                                // :106, :168-173
+    for (int i = 0; i < layer.heightBlocks; i++)
+        for (int j = 0; j < layer.widthBlocks; j++)
+            sets[(i % 4) * 4 + (j % 4)].push_back(i * layer.widthBlocks + j);
+    for (auto& s : sets)                                                   // :174-182 (erase empty sets)
+        if (!s.empty()) layer.sets.push_back(s);
+    return L;
+}
+extern "C" void les_layer_destroy(les_layer* L) { delete L; }
+extern "C" int les_layer_height_blocks(const les_layer* L) { return L->heightBlocks; }
+extern "C" int les_layer_width_blocks(const les_layer* L) { return L->widthBlocks; }
+extern "C" int les_layer_num_cells(const les_layer* L) { return (int)L->unitRegions.size(); }
+extern "C" void les_layer_rects(const les_layer* L, les_rect* unit, les_rect* shared, les_rect* filter)
+{
+    size_t n = L->unitRegions.size();
+    if (unit) memcpy(unit, L->unitRegions.data(), n * sizeof(les_rect));
+    if (shared) memcpy(shared, L->sharedRegions.data(), n * sizeof(les_rect));
+    if (filter) memcpy(filter, L->filterRegions.data(), n * sizeof(les_rect));
+}
+extern "C" int les_layer_num_sets(const les_layer* L) { return (int)L->sets.size(); }
+extern "C" int les_layer_set_size(const les_layer* L, int s) { return (int)L->sets[s].size(); }
+extern "C" void les_layer_set_cells(const les_layer* L, int s, int* cells)
+{
+    memcpy(cells, L->sets[s].data(), L->sets[s].size() * sizeof(int));
+}
+
+// =====================================================================================================
+// cv::boxFilter(src, dst, -1, Size(2R+1,2R+1), Point(-1,-1), normalize=false, BORDER_CONSTANT)
+// (call site LES/GuidedFilter.h:43).  [recollection] OpenCV 3.1 imgproc/smooth.cpp: separable
+// RowSum<T,double> followed by ColumnSum<double,T>; for CV_32F/CV_64F sources the sum type is
+// CV_64F; border value 0; anchor at the kernel centre.  Every Mat the reference passes here is a
+// standalone (non-ROI) matrix, so the zero border sits exactly at the matrix edge.
+// The running-sum order below follows RowSum ("s += S[i+ksz] - S[i]") and ColumnSum
+// ("s0 = SUM[i] + Sp[i]; D[i] = s0; SUM[i] = s0 - Sm[i]").
+// =====================================================================================================
+template <typename T>
+static void boxfilter(const T* src, T* dst, int rows, int cols, int R)
+{
+    const int ksz = 2 * R + 1;
+    std::vector<double> rowsum((size_t)rows * cols);
+    std::vector<double> ext(cols + 2 * R);
+    for (int y = 0; y < rows; y++) {
+        for (int i = 0; i < R; i++) ext[i] = 0.0, ext[cols + R + i] = 0.0;
+        for (int x = 0; x < cols; x++) ext[R + x] = (double)src[(size_t)y * cols + x];
+        double s = 0;
+        for (int i = 0; i < ksz; i++) s += ext[i];
+        double* D = &rowsum[(size_t)y * cols];
+        D[0] = s;
+        for (int i = 0; i < cols - 1; i++) {
+            s += ext[i + ksz] - ext[i];
+            D[i + 1] = s;
+        }
+    }
+    std::vector<double> SUM(cols, 0.0);
+    auto rowptr = [&](int y) -> const double* {   // rows outside [0,rows) are the zero border
+        return (y < 0 || y >= rows) ? nullptr : &rowsum[(size_t)y * cols];
+    };
+    for (int y = -R; y < R; y++) {                // first ksize-1 rows
+        const double* Sp = rowptr(y);
+        if (Sp) for (int i = 0; i < cols; i++) SUM[i] += Sp[i];
+    }
+    for (int y = 0; y < rows; y++) {
+        const double* Sp = rowptr(y + R);
+        const double* Sm = rowptr(y - R);
+        T* D = dst + (size_t)y * cols;
+        for (int i = 0; i < cols; i++) {
+            double s0 = SUM[i] + (Sp ? Sp[i] : 0.0);
+            D[i] = (T)s0;
+            SUM[i] = s0 - (Sm ? Sm[i] : 0.0);
+        }
+    }
+}
+
+// =====================================================================================================
+// GuidedImageFilter<T> / FastGuidedImageFilter<T>  (LES/GuidedFilter.h:28-327)
+// =====================================================================================================
+template <typename T>
+struct GuideStats {
+    int H = 0, W = 0, R = 0;
+    double eps = 0;
+    std::vector<T> I[3], mean_I[3], invrr, invrg, invrb, invgg, invgb, invbb, N;
+
+    // LES/GuidedFilter.h:58-102.  `img` is H x W x 3 uint8 interleaved (channel 0 first).
+    void build(const uint8_t* img, int H_, int W_, int R_, double eps_, double scaling)
+    {
+        H = H_; W = W_; R = R_; eps = eps_;
+        size_t P = (size_t)H * W;
+        for (int c = 0; c < 3; c++) {
+            I[c].resize(P);
+            // :65 I.convertTo(realI, DEPTH, scaling): [recollection] for a CV_64F destination the
+            // scale is applied in double, for CV_32F in float.
+            for (size_t i = 0; i < P; i++) {
+                if (sizeof(T) == 8) I[c][i] = (T)((double)img[i * 3 + c] * scaling);
+                else                I[c][i] = (T)((float)img[i * 3 + c] * (float)scaling);
+            }
+        }
+        std::vector<T> ones(P, (T)1), tmp(P), prod(P);
+        N.resize(P);
+        boxfilter(ones.data(), N.data(), H, W, R);                                   // :69
+        for (int c = 0; c < 3; c++) {                                                // :70-72
+            mean_I[c].resize(P);
+            boxfilter(I[c].data(), tmp.data(), H, W, R);
+            for (size_t i = 0; i < P; i++) mean_I[c][i] = tmp[i] / N[i];
+        }
+        auto var = [&](int a, int b, bool diag) {                                    // :79-84
+            std::vector<T> v(P);
+            for (size_t i = 0; i < P; i++) prod[i] = I[a][i] * I[b][i];
+            boxfilter(prod.data(), tmp.data(), H, W, R);
+            for (size_t i = 0; i < P; i++) {
+                // cv::MatExpr evaluation order: (box/N - mean.mul(mean)) + eps, all in T
+                T t = tmp[i] / N[i] - mean_I[a][i] * mean_I[b][i];
+                v[i] = diag ? (T)(t + (T)eps) : t;   // Mat + double scalar: [recollection] scalar cast to T's work type
+            }
+            return v;
+        };
+        std::vector<T> rr = var(0, 0, true), rg = var(0, 1, false), rb = var(0, 2, false);
+        std::vector<T> gg = var(1, 1, true), gb = var(1, 2, false), bb = var(2, 2, true);
+        invrr.resize(P); invrg.resize(P); invrb.resize(P); invgg.resize(P); invgb.resize(P); invbb.resize(P);
+        for (size_t i = 0; i < P; i++) {                                             // :87-101
+            T irr = gg[i] * bb[i] - gb[i] * gb[i];
+            T irg = gb[i] * rb[i] - rg[i] * bb[i];
+            T irb = rg[i] * gb[i] - gg[i] * rb[i];
+            T igg = rr[i] * bb[i] - rb[i] * rb[i];
+            T igb = rb[i] * rg[i] - rr[i] * gb[i];
+            T ibb = rr[i] * gg[i] - rg[i] * rg[i];
+            T covDet = irr * rr[i] + irg * rg[i] + irb * rb[i];
+            invrr[i] = irr / covDet; invrg[i] = irg / covDet; invrb[i] = irb / covDet;
+            invgg[i] = igg / covDet; invgb[i] = igb / covDet; invbb[i] = ibb / covDet;
+        }
+    }
+
+    // createSubregionFilter(rect) (:301-326) + filter(p) (:248-266) -> filter_raw (:142-247).
+    // p, q are dense rect.h x rect.w float images.
+    void filter_subregion(les_rect rect, const float* p_in, float* q_out) const
+    {
+        const int rows = rect.h, cols = rect.w;
+        const size_t P = (size_t)rows * cols;
+        std::vector<T> Nloc(P), ones(P, (T)1);
+        boxfilter(ones.data(), Nloc.data(), rows, cols, R);                          // :324
+        std::vector<T> p(P), mean_p(P), mIp[3], a[3], b(P), tmp(P);
+        for (size_t i = 0; i < P; i++) p[i] = (T)p_in[i];                            // :251
+        boxfilter(p.data(), mean_p.data(), rows, cols, R);                           // :145
+        auto g = [&](const std::vector<T>& plane, int i, int j) -> T {               // ROI slice plane(rect)
+            return plane[(size_t)(rect.y + i) * W + rect.x + j];
+        };
+        for (int c = 0; c < 3; c++) {                                                // :151-172
+            mIp[c].resize(P);
+            for (int i = 0; i < rows; i++)
+                for (int j = 0; j < cols; j++) tmp[(size_t)i * cols + j] = g(I[c], i, j) * p[(size_t)i * cols + j];
+            boxfilter(tmp.data(), mIp[c].data(), rows, cols, R);
+            a[c].resize(P);
+        }
+        for (int i = 0; i < rows; i++)                                               // :180-222
+            for (int j = 0; j < cols; j++) {
+                size_t k = (size_t)i * cols + j;
+                T n = Nloc[k];
+                T mp = mean_p[k] / n;
+                T mIr = g(mean_I[0], i, j), mIg = g(mean_I[1], i, j), mIb = g(mean_I[2], i, j);
+                T cov_r = mIp[0][k] / n - mIr * mp;
+                T cov_g = mIp[1][k] / n - mIg * mp;
+                T cov_b = mIp[2][k] / n - mIb * mp;
+                T ar = g(invrr, i, j) * cov_r + g(invrg, i, j) * cov_g + g(invrb, i, j) * cov_b;
+                T ag = g(invrg, i, j) * cov_r + g(invgg, i, j) * cov_g + g(invgb, i, j) * cov_b;
+                T ab = g(invrb, i, j) * cov_r + g(invgb, i, j) * cov_g + g(invbb, i, j) * cov_b;
+                a[0][k] = ar; a[1][k] = ag; a[2][k] = ab;
+                b[k] = mp - ar * mIr - ag * mIg - ab * mIb;
+            }
+        std::vector<T> Ba[3], Bb(P);
+        for (int c = 0; c < 3; c++) { Ba[c].resize(P); boxfilter(a[c].data(), Ba[c].data(), rows, cols, R); }   // :224-226
+        boxfilter(b.data(), Bb.data(), rows, cols, R);                                                           // :227
+        for (int i = 0; i < rows; i++)                                               // :229-245
+            for (int j = 0; j < cols; j++) {
+                size_t k = (size_t)i * cols + j;
+                T q = (Bb[k] + Ba[0][k] * g(I[0], i, j) + Ba[1][k] * g(I[1], i, j) + Ba[2][k] * g(I[2], i, j)) / Nloc[k];
+                q_out[k] = (float)q;                                                 // :260-261
+            }
+    }
+};
+
+// =====================================================================================================
+// CostVolumeEnergy  (LES/CostVolumeEnergy.h) + StereoEnergy::IsValiLabel (LES/StereoEnergy.h:560-610)
+// =====================================================================================================
+struct les_oracle {
+    int H, W, D, windR, use_float;
+    float th_col, MAXD, MIND;
+    const float* vol[2];
+    GuideStats<double> gd[2];
+    GuideStats<float> gf[2];
+};
+
+extern "C" les_oracle* les_oracle_create(const uint8_t* imL, const uint8_t* imR, int H, int W,
+                                         const float* volL, const float* volR, int D, int windR, double eps,
+                                         float th_col, float max_disparity, float min_disparity, int use_float)
+{
+    les_oracle* o = new les_oracle();
+    o->H = H; o->W = W; o->D = D; o->windR = windR; o->use_float = use_float;
+    o->th_col = th_col; o->MAXD = max_disparity; o->MIND = min_disparity;
+    o->vol[0] = volL; o->vol[1] = volR;
+    const uint8_t* im[2] = {imL, imR};
+    for (int m = 0; m < 2; m++) {
+        if (!im[m]) continue;
+        // LES/CostVolumeEnergy.h:30-31 / :35-36: radius windR/2, eps = filter_param1, scaling 1/255
+        if (use_float) o->gf[m].build(im[m], H, W, windR / 2, eps, 1.0 / 255);
+        else           o->gd[m].build(im[m], H, W, windR / 2, eps, 1.0 / 255);
+    }
+    return o;
+}
+extern "C" void les_oracle_destroy(les_oracle* o) { delete o; }
+
+extern "C" void les_oracle_get_stats(const les_oracle* o, int mode, double* out)
+{
+    size_t P = (size_t)o->H * o->W;
+    auto put = [&](int k, auto& v) { for (size_t i = 0; i < P; i++) out[k * P + i] = (double)v[i]; };
+    if (o->use_float) {
+        const auto& g = o->gf[mode];
+        for (int c = 0; c < 3; c++) { put(c, g.I[c]); put(3 + c, g.mean_I[c]); }
+        put(6, g.invrr); put(7, g.invrg); put(8, g.invrb); put(9, g.invgg); put(10, g.invgb); put(11, g.invbb); put(12, g.N);
+    } else {
+        const auto& g = o->gd[mode];
+        for (int c = 0; c < 3; c++) { put(c, g.I[c]); put(3 + c, g.mean_I[c]); }
+        put(6, g.invrr); put(7, g.invrg); put(8, g.invrb); put(9, g.invgg); put(10, g.invgb); put(11, g.invbb); put(12, g.N);
+    }
+}
+
+// LES/CostVolumeEnergy.h:64-98 (interpolate == 1, the only mode ever selected: ctor :18).
+extern "C" void les_oracle_gather(const les_oracle* o, int mode, les_rect fr, les_plane plane, float* raw)
+{
+    const float* vol = o->vol[mode];
+    const size_t HW = (size_t)o->H * o->W;
+    const int D = o->D;
+    const int D0 = int(-o->MIND);                                                    // :67
+    const float MIN_DISPARITY = o->MIND, MAX_DISPARITY = o->MAXD;
+    const int y0 = fr.y + fr.h, x0 = fr.x + fr.w;
+    for (int y = fr.y; y < y0; y++) {
+        float* pC = raw + (size_t)(y - fr.y) * fr.w;
+        float d_base = plane.b * y + plane.c;                                        // :73
+        for (int x = fr.x; x < x0; x++) {
+            float d = plane.a * x + d_base;                                          // :76
+            float C;
+            size_t px = (size_t)y * o->W + x;
+            if (d < MIN_DISPARITY) C = vol[px];                                      // :78
+            else if (d >= MAX_DISPARITY) C = vol[(size_t)(D - 1) * HW + px];         // :79
+            else if (std::isnan(d) || std::isinf(d)) C = LES_COST_FOR_INVALID;       // :80
+            else {
+                int d0 = int(d) + D0;                                                // :83
+                int d1 = d0 + 1;
+                float f1 = d - std::floor(d);                                        // :85
+                float f0 = 1.0f - f1;
+                if (d1 >= D || d0 < 0) C = LES_COST_FOR_INVALID;                     // :87-90 (diagnostic printf omitted)
+                else C = f0 * vol[(size_t)d0 * HW + px] + f1 * vol[(size_t)d1 * HW + px];   // :92
+            }
+            pC[x - fr.x] = (o->th_col < C) ? o->th_col : C;                          // :96 std::min(C, th_col)
+        }
+    }
+}
+
+extern "C" void les_oracle_filter_subregion(const les_oracle* o, int mode, les_rect fr, const float* p, float* q)
+{
+    if (o->use_float) o->gf[mode].filter_subregion(fr, p, q);
+    else              o->gd[mode].filter_subregion(fr, p, q);
+}
+
+static bool valid_at(const les_oracle* o, float ds, float a5, float b5)
+{   // LES/StereoEnergy.h:567-573 == :600-605
+    const float MIN_DISPARITY = o->MIND, MAX_DISPARITY = o->MAXD;
+    float d;
+    return (ds >= MIN_DISPARITY && ds <= MAX_DISPARITY
+            && ((d = ds + a5 + b5) >= MIN_DISPARITY) && d <= MAX_DISPARITY
+            && ((d = ds + a5 - b5) >= MIN_DISPARITY) && d <= MAX_DISPARITY
+            && ((d = ds - a5 + b5) >= MIN_DISPARITY) && d <= MAX_DISPARITY
+            && ((d = ds - a5 - b5) >= MIN_DISPARITY) && d <= MAX_DISPARITY);
+}
+
+extern "C" void les_oracle_valid_mask(const les_oracle* o, les_rect pos, les_plane label, uint8_t* mask)
+{
+    float a5 = label.a * 5;                                                          // :563 / :586
+    float b5 = label.b * 5;
+    for (int y = 0; y < pos.h; y++)
+        for (int x = 0; x < pos.w; x++) {
+            float fx = (float)(pos.x + x), fy = (float)(pos.y + y);
+            float ds;
+            if (pos.w == 1 && pos.h == 1) {
+                ds = label.a * fx + label.b * fy + label.c;                          // :562 via Plane::GetZ(cv::Point) LES/Plane.h:55-58
+            } else {
+                // :592 channelSum(coordinates(pos).mul(label.toScalar())): coordinates = (x, y, 1, 0)
+                // (:114); [recollection] Mat.mul(Scalar) multiplies in float, cv::reduce(SUM) over the
+                // 4 channels accumulates left to right in float.
+                ds = ((fx * label.a + fy * label.b) + 1.0f * label.c) + 0.0f * label.v;
+            }
+            mask[(size_t)y * pos.w + x] = valid_at(o, ds, a5, b5) ? 255 : 0;
+        }
+}
+
+extern "C" void les_oracle_unary_nocheck(const les_oracle* o, int mode, les_rect fr, les_rect tr,
+                                         float* costs, int stride, les_plane plane)
+{
+    // LES/CostVolumeEnergy.h:55-174.  The Reusable scratch (pIL + sub-region filter, :57-62) is
+    // recreated per call here; it only caches, it does not change results.
+    std::vector<float> pIL((size_t)fr.w * fr.h), q((size_t)fr.w * fr.h);
+    les_oracle_gather(o, mode, fr, plane, pIL.data());
+    les_oracle_filter_subregion(o, mode, fr, pIL.data(), q.data());                  // :171
+    int sx = tr.x - fr.x, sy = tr.y - fr.y;                                          // :169 subrect = targetRect - filterRect.tl()
+    for (int y = 0; y < tr.h; y++)
+        for (int x = 0; x < tr.w; x++)
+            costs[(size_t)(sy + y) * stride + sx + x] = q[(size_t)(sy + y) * fr.w + sx + x];
+}
+
+extern "C" void les_oracle_unary(const les_oracle* o, int mode, les_rect fr, les_rect tr,
+                                 float* costs, int stride, les_plane plane)
+{
+    les_oracle_unary_nocheck(o, mode, fr, tr, costs, stride, plane);                 // :178
+    std::vector<uint8_t> mask((size_t)tr.w * tr.h);
+    les_oracle_valid_mask(o, tr, plane, mask.data());                                // :181
+    int sx = tr.x - fr.x, sy = tr.y - fr.y;
+    for (int y = 0; y < tr.h; y++)                                                   // :182 setTo(COST_FOR_INVALID, ~validMask)
+        for (int x = 0; x < tr.w; x++)
+            if (!mask[(size_t)y * tr.w + x]) costs[(size_t)(sy + y) * stride + sx + x] = LES_COST_FOR_INVALID;
+}
+
+extern "C" void les_oracle_unary_batch(const les_oracle* o, int mode, int n, const les_rect* frs,
+                                       const les_rect* trs, const les_plane* planes, float* cost_map,
+                                       int check, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        float* origin = cost_map + (size_t)frs[i].y * o->W + frs[i].x;               // proposalCost(filterRect), LES/FastGCStereo.h:49
+        if (check) les_oracle_unary(o, mode, frs[i], trs[i], origin, o->W, planes[i]);
+        else       les_oracle_unary_nocheck(o, mode, frs[i], trs[i], origin, o->W, planes[i]);
+    }
+}
+
+extern "C" void les_oracle_wta_update(int W, les_rect r, float* cur, const float* prop, les_plane* labels, les_plane plane)
+{
+    for (int y = r.y; y < r.y + r.h; y++)                                            // LES/FastGCStereo.h:57-60
+        for (int x = r.x; x < r.x + r.w; x++) {
+            size_t k = (size_t)y * W + x;
+            if (cur[k] > prop[k]) { cur[k] = prop[k]; labels[k] = plane; }
+        }
+}
+
+// =====================================================================================================
+// Label generation
+// =====================================================================================================
+extern "C" void les_random_unit_vector(les_rng* r, double thetaRange, double n[3])
+{   // LES/Utilities.hpp:254-261
+    double theta = les_rng_uniform_double(r, 0.0, thetaRange);
+    double phi = les_rng_uniform_double(r, 0.0, M_PI * 2.0);
+    double cosT = cos(theta), sinT = sin(theta);
+    double cosP = cos(phi), sinP = sin(phi);
+    n[0] = sinT * cosP; n[1] = sinT * sinP; n[2] = cosT;
+}
+
+extern "C" les_plane les_create_random_label(les_rng* r, float min_disp, float max_disp, int sx, int sy)
+{   // LES/StereoEnergy.h:120-129 (MAX_VDISPARITY == 0 -> vs = 0, no draw)
+    float zs = les_rng_uniform_float(r, min_disp, max_disp);
+    double n[3];
+    les_random_unit_vector(r, M_PI / 3, n);
+    // Plane::CreatePlane(cv::Vec<float,3> n, ...): the Vec3d is converted to Vec3f (LES/Plane.h:32-35)
+    return les_plane_create((float)n[0], (float)n[1], (float)n[2], zs, (float)sx, (float)sy, 0.0f);
+}
+
+extern "C" void les_select_random_pixel(les_rng* r, les_rect rect, int* px, int* py)
+{   // LES/Proposer.h:37-44 == LES/FastGCStereo.h:231-238
+    int n = les_rng_uniform_int(r, 0, rect.h * rect.w);
+    *px = rect.x + n % rect.w;
+    *py = rect.y + n / rect.w;
+}
+
+extern "C" les_plane les_expansion_proposal(les_rng* r, const les_plane* labels, int W, les_rect unit)
+{   // LES/Proposer.h:69-75: labeling = labeling(unitRegion) (:64), pixel drawn in Rect(0,0,cols,rows)
+    int px, py;
+    les_select_random_pixel(r, les_rect{0, 0, unit.w, unit.h}, &px, &py);
+    return labels[(size_t)(unit.y + py) * W + unit.x + px];
+}
+
+extern "C" float les_random_perturbation_width(float min_disp, float max_disp, int m)
+{   // LES/Proposer.h:93-96: (MAX - MIN) * pow(0.5f, m + 1); pow(float,int) evaluates in double
+    return (float)((max_disp - min_disp) * pow((double)0.5f, (double)(m + 1)));
+}
+
+extern "C" int les_random_is_continued(int iter, int K, int outerIter, float min_disp, float max_disp)
+{   // LES/Proposer.h:149-152 (doEarlyStop = true)
+    return (iter < K) && !(les_random_perturbation_width(min_disp, max_disp, outerIter + iter) < 0.1);
+}
+
+extern "C" les_plane les_random_proposal(les_rng* r, const les_plane* labels, int W, les_rect unit, int m,
+                                         float MIN_DISPARITY, float MAX_DISPARITY)
+{   // LES/Proposer.h:120-148 (MAX_VDISPARITY == 0)
+    int px, py;
+    les_select_random_pixel(r, les_rect{0, 0, unit.w, unit.h}, &px, &py);            // :122
+    les_plane in = labels[(size_t)(unit.y + py) * W + unit.x + px];                  // :123
+    int sx = unit.x + px, sy = unit.y + py;                                          // :127
+    float zs = les_plane_z(&in, float(sx), float(sy));                               // :128
+    float dz = les_random_perturbation_width(MIN_DISPARITY, MAX_DISPARITY, m);       // :129
+    float minz = std::max(MIN_DISPARITY, zs - dz);                                   // :130
+    float maxz = std::min(MAX_DISPARITY, zs + dz);                                   // :131
+    zs = les_rng_uniform_float(r, minz, maxz);                                       // :132
+    float vs = in.v;                                                                 // :134
+    float nr = (float)(1.0f * pow((double)0.5f, (double)m));                         // :142 randomNmax = 1.0
+    float n0[3];
+    les_plane_normal(&in, n0);
+    double u[3];
+    les_random_unit_vector(r, M_PI, u);                                              // :143 default thetaRange = CV_PI
+    float nv[3];
+    for (int i = 0; i < 3; i++) nv[i] = n0[i] + (float)u[i] * nr;                    // (Vec3f)Vec3d * nr
+    double dd = (double)nv[0] * nv[0] + (double)nv[1] * nv[1] + (double)nv[2] * nv[2];   // ddot
+    double inv = 1. / sqrt(dd);                                                      // :145 Matx / double -> * (1./alpha) [recollection]
+    for (int i = 0; i < 3; i++) nv[i] = (float)(nv[i] * inv);
+    return les_plane_create(nv[0], nv[1], nv[2], zs, float(sx), float(sy), vs);      // :147
+}
+
+extern "C" int les_ransac_sample_count(int ni, int ptNum, int pf, double conf)
+{   // LES/Proposer.h:243-262
+    int SampleCnt;
+    double q = 1.0;
+    for (double a = (ni - pf + 1), b = (ptNum - pf + 1); a <= ni; a += 1.0, b += 1.0) q *= (a / b);
+    const double eps = 1e-4;
+    if ((1.0 - q) < eps) SampleCnt = 1;
+    else SampleCnt = int(log(1.0 - conf) / log(1.0 - q));
+    if (SampleCnt < 1) SampleCnt = 1;
+    return SampleCnt;
+}
+
+// cv::solve(A, b, x, DECOMP_SVD) for an m x 3 float system  [recollection]: least-squares / minimum-norm
+// solution through the SVD with singular values below (sum of w) * 2*FLT_EPSILON treated as zero.
+// Restated through the 3x3 eigen-decomposition of A^T A in double (same pseudo-inverse; OpenCV runs a
+// one-sided Jacobi SVD in float, so agreement is to float round-off, not bitwise).
+static void solve_svd_mx3(const float* A, const float* b, int m, float x[3])
+{
+    double M[3][3] = {{0}}, rhs[3] = {0};
+    for (int i = 0; i < m; i++)
+        for (int r = 0; r < 3; r++) {
+            rhs[r] += (double)A[i * 3 + r] * b[i];
+            for (int c = 0; c < 3; c++) M[r][c] += (double)A[i * 3 + r] * A[i * 3 + c];
+        }
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(M[0][1]) + fabs(M[0][2]) + fabs(M[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(M[p][q]) < 1e-300) continue;
+                double theta = (M[q][q] - M[p][p]) / (2 * M[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    double mkp = M[k][p], mkq = M[k][q];
+                    M[k][p] = c * mkp - s * mkq; M[k][q] = s * mkp + c * mkq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double mpk = M[p][k], mqk = M[q][k];
+                    M[p][k] = c * mpk - s * mqk; M[q][k] = s * mpk + c * mqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double w[3], wsum = 0;
+    for (int k = 0; k < 3; k++) { w[k] = sqrt(std::max(M[k][k], 0.0)); wsum += w[k]; }
+    double thr = wsum * 2 * 1.1920929e-07;
+    double out[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        if (w[k] <= thr) continue;
+        double proj = (V[0][k] * rhs[0] + V[1][k] * rhs[1] + V[2][k] * rhs[2]) / (w[k] * w[k]);
+        for (int r = 0; r < 3; r++) out[r] += V[r][k] * proj;
+    }
+    for (int r = 0; r < 3; r++) x[r] = (float)out[r];
+}
+
+extern "C" les_plane les_ransac_proposal(les_rng* r, const les_plane* labels, int W, les_rect unit,
+                                         int MAX_SAM, float conf, float threshold)
+{
+    // startIterations, LES/Proposer.h:283-301: snapshot coordinates and disparities of the unit region
+    const int len = unit.w * unit.h;
+    std::vector<float> pts((size_t)len * 3), disp(len);
+    for (int y = 0; y < unit.h; y++)
+        for (int x = 0; x < unit.w; x++) {
+            float c0 = (float)x + unit.x, c1 = (float)y + unit.y;
+            const les_plane& v = labels[(size_t)(y + unit.y) * W + x + unit.x];
+            int k = y * unit.w + x;
+            pts[k * 3 + 0] = c0; pts[k * 3 + 1] = c1; pts[k * 3 + 2] = 1.0f;
+            disp[k] = v.a * c0 + v.b * c1 + v.c;                                     // :297
+        }
+    // RANSACPlane, :177-240
+    int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;
+    float N[3] = {0, 0, 0}, result[3] = {0, 0, 0};
+    std::vector<uint8_t> v(len);
+    std::vector<float> A, b;
+    auto count_inliers = [&](const float* n) {
+        int cnt = 0;
+        for (int i = 0; i < len; i++) {
+            // cv::abs(pts * N - disp) < threshold : float GEMM (accumulated in double by cv::gemm
+            // [recollection]) then float subtract
+            float dot = (float)((double)pts[i * 3] * n[0] + (double)pts[i * 3 + 1] * n[1] + (double)pts[i * 3 + 2] * n[2]);
+            v[i] = std::fabs(dot - disp[i]) < threshold;
+            cnt += v[i];
+        }
+        return cnt;
+    };
+    while (no_sam < max_sam) {
+        no_sam = no_sam + 1;
+        // randperm(len) (:163-174) draws a full std::random_shuffle (rand()) and uses only its first three
+        // entries: three distinct uniformly random indices.  Restated with a partial Fisher-Yates on `r`.
+        int idx[3];
+        for (int i = 0; i < 3; i++) {
+            bool again;
+            do {
+                idx[i] = len > 0 ? les_rng_uniform_int(r, 0, len) : 0;
+                again = false;
+                for (int j = 0; j < i; j++) if (idx[j] == idx[i] && len > i) again = true;
+            } while (again);
+        }
+        float ranpts[9], div[3];
+        for (int i = 0; i < 3; i++) {
+            for (int c = 0; c < 3; c++) ranpts[i * 3 + c] = pts[idx[i] * 3 + c];     // :199
+            div[i] = disp[idx[i]];                                                   // :200
+        }
+        solve_svd_mx3(ranpts, div, 3, N);                                            // :203
+        int no_i = count_inliers(N);                                                 // :204-206
+        if (max_i < no_i) {
+            // :211-222 -- QUIRK kept: the copy loop runs i < no_i (not i < len), so only inliers among
+            // the first no_i points are used and the remaining rows of A, b stay zero.
+            A.assign((size_t)no_i * 3, 0.0f);
+            b.assign(no_i, 0.0f);
+            for (int i = 0, j = 0; i < no_i; i++)
+                if (v[i]) {
+                    for (int c = 0; c < 3; c++) A[j * 3 + c] = pts[i * 3 + c];
+                    b[j] = disp[i];
+                    j++;
+                }
+            solve_svd_mx3(A.data(), b.data(), no_i, N);                              // :224
+            int no = count_inliers(N);                                               // :225-227
+            if (no > no_i_c) {                                                       // :229-236
+                result[0] = N[0]; result[1] = N[1]; result[2] = N[2];
+                no_i_c = no;
+                max_i = no_i;
+                max_sam = std::min(max_sam, les_ransac_sample_count(no, len, 3, conf));
+            }
+        }
+    }
+    return les_plane{result[0], result[1], result[2], 0.0f};                         // :239
+}
+
+// =====================================================================================================
+// Volume preparation (LES/main.cpp:146-199, margin = 0 as shipped: interp_margin = 0, :359)
+// =====================================================================================================
+extern "C" void les_fill_out_of_view(float* vol, int D, int H, int W, int mode)
+{
+    for (int d = 0; d < D; d++)
+        for (int y = 0; y < H; y++) {
+            float* row = vol + ((size_t)d * H + y) * W;
+            if (mode == 0) {                                                         // :152-163
+                int q = std::min(d, W - 1);   // (reference assumes d < W)
+                float v = row[q];
+                for (int x = 0; x < q; x++) row[x] = v;
+            } else {                                                                 // :165-175
+                int p = W - d;                // q - d - margin
+                if (p < 1) p = 1;
+                float v = row[p - 1];
+                for (int x = p; x < W; x++) row[x] = v;
+            }
+        }
+}
+
+extern "C" void les_convert_volume_l2r(const float* src, float* dst, int D, int H, int W)
+{   // LES/main.cpp:178-199 with margin = 0
+    memcpy(dst, src, (size_t)D * H * W * sizeof(float));                             // :183 clone
+    for (int d = 0; d < D && d < W; d++)
+        for (int y = 0; y < H; y++) {
+            const float* s0 = src + ((size_t)d * H + y) * W;
+            float* s1 = dst + ((size_t)d * H + y) * W;
+            for (int x = 0; x < W - d; x++) s1[x] = s0[x + d];                       // :189
+            float edge1 = s0[W - 1];                                                 // :191
+            for (int x = W - 1 - d; x < W; x++) s1[x] = edge1;                       // :193-194
+        }
+}
