@@ -1,0 +1,119 @@
+/*
+ * localexp_hip.h -- C ABI of liblocalexp_hip.so: the MI355X (gfx950) implementation of the
+ * LocalExpStereo matching-cost hot path.
+ *
+ * Drop-in boundary: the reference's operator interface
+ *     virtual void StereoEnergy::ComputeUnaryPotential(const cv::Rect& filterRect,
+ *             const cv::Rect& targetRect, const cv::Mat& costs, const Plane& plane,
+ *             Reusable& reusable, int mode) const            (LES/StereoEnergy.h:625-626)
+ * as implemented by CostVolumeEnergy (LES/CostVolumeEnergy.h:16-183) with the default "GF" joint
+ * filter (FastGuidedImageFilter<double>, LES/GuidedFilter.h:283-327).  A maintainer binds these
+ * entry points from a StereoEnergy subclass installed through
+ * PMStereoBase::setStereoEnergyCPU (LES/PMStereoBase.h:58-61); see INTEGRATION.md and
+ * localexpstereo_amd/host/HipCostVolumeEnergy.h.
+ *
+ * Plain C: pointers and sizes only, int status returns (0 = OK), no exceptions cross the boundary.
+ * Every function fails (non-zero) when no HIP device is available -- there is no CPU fallback.
+ */
+#ifndef LOCALEXP_HIP_H
+#define LOCALEXP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct les_hip_ctx les_hip_ctx;       /* one energy object (both views), cf. CostVolumeEnergy   */
+typedef struct les_hip_batch les_hip_batch;   /* prepared geometry of one lock-step (a disjoint set)    */
+
+typedef struct { int x, y, w, h; } les_hip_rect;        /* cv::Rect                                       */
+typedef struct { float a, b, c, v; } les_hip_plane;     /* struct Plane, LES/Plane.h:4-9                  */
+
+enum {
+    LES_HIP_OK = 0,
+    LES_HIP_ERR_ARG = 1,          /* bad argument                                                      */
+    LES_HIP_ERR_DEVICE = 2,       /* no usable HIP device / HIP runtime error (see les_hip_last_error) */
+    LES_HIP_ERR_UNSUPPORTED = 3   /* e.g. a guided-filter radius no kernel was instantiated for        */
+};
+
+/* Constructor arguments of CostVolumeEnergy(imL, imR, volL, volR, Parameters, MAX_DISPARITY,
+ * MIN_DISPARITY) -- LES/CostVolumeEnergy.h:16; Parameters fields LES/StereoEnergy.h:13-40. */
+typedef struct {
+    int H, W, D;                  /* image rows, cols; volume slices (ndisp)                           */
+    int windR;                    /* Parameters::windR; guided-filter radius is windR/2 (:30)          */
+    double eps;                   /* Parameters::filter_param1                                         */
+    float th_col;                 /* Parameters::th_col (mc_threshold, LES/main.cpp:351)               */
+    float max_disparity;          /* MAX_DISPARITY (ndisp-1, LES/main.cpp:341)                         */
+    float min_disparity;          /* MIN_DISPARITY                                                     */
+    int device;                   /* HIP device ordinal                                                */
+    int volumes_on_device;        /* != 0: volL/volR are device pointers owned by the caller (shared, not
+                                     copied -- like the ref-counted cv::Mat headers, :20-21)           */
+} les_hip_params;
+
+/* replaces: CostVolumeEnergy::CostVolumeEnergy (LES/CostVolumeEnergy.h:16-43) including the two
+ * FastGuidedImageFilter<double> constructions (global guide statistics, LES/GuidedFilter.h:58-102).
+ * imL/imR: H x W x 3 uint8 BGR host images; volL/volR: float [D][H][W] (host, copied to HBM once;
+ * or device when volumes_on_device).  Either view may be NULL if its mode is never used. */
+int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
+                   const float* volL, const float* volR);
+void les_hip_destroy(les_hip_ctx* ctx);                 /* replaces: ~CostVolumeEnergy (:50-52)          */
+const char* les_hip_last_error(void);                   /* thread-local description of the last failure  */
+
+/* All launches go to this hipStream_t (NULL = the default stream).  Not in the reference. */
+int les_hip_set_stream(les_hip_ctx* ctx, void* hip_stream);
+int les_hip_synchronize(les_hip_ctx* ctx);
+
+/* replaces: CostVolumeEnergy::ComputeUnaryPotential (check != 0, LES/CostVolumeEnergy.h:176-183) and
+ * ::ComputeUnaryPotentialWithoutCheck (check == 0, :55-174) for ONE call.  `costs` is the HOST
+ * pointer of the element (filterRect.y, filterRect.x) of a row-major float map with `row_stride`
+ * floats per row, i.e. the view proposalCost(filterRect) of LES/FastGCStereo.h:49; only
+ * costs(targetRect - filterRect.tl()) is written.  Synchronous. */
+int les_hip_unary_one(les_hip_ctx* ctx, int mode, const les_hip_rect* filterRect, const les_hip_rect* targetRect,
+                      const les_hip_plane* plane, float* costs, int row_stride, int check);
+
+/* The same for n independent calls (one proposal index of one disjoint set of cells:
+ * LES/FastGCStereo.h:30-49 run in lock-step) writing into one H x W map.  cost_map: HOST H*W floats;
+ * only the target rects are written.  Synchronous. */
+int les_hip_unary_batch(les_hip_ctx* ctx, int mode, int n, const les_hip_rect* filterRects,
+                        const les_hip_rect* targetRects, const les_hip_plane* planes, float* cost_map, int check);
+
+/* Prepared form for the hot loop: geometry is uploaded once, then reused for every proposal.
+ * out_slabs == 0: outputs go into one H x W map (element (y,x) of call i at y*W+x);
+ * out_slabs != 0: call i writes its target rect into slab i of a [n][H][W] array (used for whole-image
+ * aggregation of many hypothesis planes). */
+int les_hip_batch_create(les_hip_ctx* ctx, int n, const les_hip_rect* filterRects, const les_hip_rect* targetRects,
+                         int out_slabs, les_hip_batch** out);
+void les_hip_batch_destroy(les_hip_batch* b);
+int les_hip_batch_num_jobs(const les_hip_batch* b);     /* workgroups one run launches                   */
+/* planes: n labels, HOST (planes_on_device == 0) or DEVICE memory; out: DEVICE memory.  Asynchronous
+ * on the context's stream. */
+int les_hip_batch_run(les_hip_ctx* ctx, const les_hip_batch* b, int mode, const les_hip_plane* planes,
+                      int planes_on_device, float* out_dev, int check);
+
+/* replaces: the winner-take-all update of the PatchMatch iterations, LES/FastGCStereo.h:56-60
+ * (mask = cur > prop; cur <- prop, label <- plane under mask) for n shared regions, on DEVICE maps:
+ * cur_cost/prop_cost H*W floats, labels H*W planes (row stride W).  Asynchronous. */
+int les_hip_wta_update(les_hip_ctx* ctx, int n, const les_hip_rect* rects, const les_hip_plane* planes,
+                       int planes_on_device, float* cur_cost_dev, const float* prop_cost_dev,
+                       les_hip_plane* labels_dev);
+
+/* Device memory helpers for callers without a HIP toolchain (host C++ adapter, ctypes). */
+int les_hip_malloc(les_hip_ctx* ctx, void** dev_ptr, size_t bytes);
+int les_hip_free(les_hip_ctx* ctx, void* dev_ptr);
+int les_hip_memcpy_h2d(les_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int les_hip_memcpy_d2h(les_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int les_hip_memset(les_hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* Test/diagnostic: guide statistics of view `mode` as the kernels consume them:
+ * out[(y*W+x)*12 + k*4 + {0,1,2,3}] = {mean_I_k - 1/2, inv[k][0], inv[k][1], inv[k][2]} (float32). */
+int les_hip_get_stats(les_hip_ctx* ctx, int mode, float* out_host);
+/* Strip geometry the build was compiled with for radius R (0 if unsupported): output columns per
+ * workgroup. */
+int les_hip_strip_width(int R);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,249 @@
+"""ctypes binding of the C ABI in include/localexp_hip.h (liblocalexp_hip.so).
+
+This is plumbing for tests and bench.py: the product is the shared library and the C++ host adapter
+(localexpstereo_amd/host/).  The library is loaded from csrc/ in-tree; if it is missing, or no HIP
+device is present, everything here raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "liblocalexp_hip.so")
+
+RECT_DT = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4")])
+PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
+
+# every symbol include/localexp_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "les_hip_create", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
+    "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
+    "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
+    "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
+]
+
+
+class LesHipError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("D", C.c_int), ("windR", C.c_int), ("eps", C.c_double),
+                ("th_col", C.c_float), ("max_disparity", C.c_float), ("min_disparity", C.c_float),
+                ("device", C.c_int), ("volumes_on_device", C.c_int)]
+
+
+_libs = {}
+
+
+def load(path=None):
+    """Load the C-ABI library (default: the in-tree HIP build).  Raises if it does not exist."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise LesHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, ci = C.c_void_p, C.c_int
+    sig = {
+        "les_hip_create": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, vp, vp]),
+        "les_hip_destroy": (None, [vp]),
+        "les_hip_last_error": (C.c_char_p, []),
+        "les_hip_set_stream": (ci, [vp, vp]),
+        "les_hip_synchronize": (ci, [vp]),
+        "les_hip_unary_one": (ci, [vp, ci, vp, vp, vp, vp, ci, ci]),
+        "les_hip_unary_batch": (ci, [vp, ci, ci, vp, vp, vp, vp, ci]),
+        "les_hip_batch_create": (ci, [vp, ci, vp, vp, ci, C.POINTER(vp)]),
+        "les_hip_batch_destroy": (None, [vp]),
+        "les_hip_batch_num_jobs": (ci, [vp]),
+        "les_hip_batch_run": (ci, [vp, vp, ci, vp, ci, vp, ci]),
+        "les_hip_wta_update": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
+        "les_hip_malloc": (ci, [vp, C.POINTER(vp), C.c_size_t]),
+        "les_hip_free": (ci, [vp, vp]),
+        "les_hip_memcpy_h2d": (ci, [vp, vp, vp, C.c_size_t]),
+        "les_hip_memcpy_d2h": (ci, [vp, vp, vp, C.c_size_t]),
+        "les_hip_memset": (ci, [vp, vp, ci, C.c_size_t]),
+        "les_hip_get_stats": (ci, [vp, ci, vp]),
+        "les_hip_strip_width": (ci, [ci]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _libs[path] = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _rects(r):
+    r = np.asarray(r)
+    if r.dtype != RECT_DT:
+        r = np.ascontiguousarray(r, np.int32).reshape(-1, 4).view(RECT_DT).reshape(-1)
+    return np.ascontiguousarray(r)
+
+
+def _planes(p):
+    p = np.asarray(p)
+    if p.dtype != PLANE_DT:
+        p = np.ascontiguousarray(p, np.float32).reshape(-1, 4).view(PLANE_DT).reshape(-1)
+    return np.ascontiguousarray(p)
+
+
+class DeviceBuffer:
+    """A raw device allocation made through the C ABI (used when torch is not wanted)."""
+
+    def __init__(self, energy, nbytes):
+        self.e = energy
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        energy._chk(energy.L.les_hip_malloc(energy.h, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.e._chk(self.e.L.les_hip_memcpy_h2d(self.e.h, C.c_void_p(self.ptr), _ptr(arr), arr.nbytes))
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.e._chk(self.e.L.les_hip_memcpy_d2h(self.e.h, _ptr(out), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def fill(self, byte):
+        self.e._chk(self.e.L.les_hip_memset(self.e.h, C.c_void_p(self.ptr), byte, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.e.L.les_hip_free(self.e.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class Batch:
+    def __init__(self, energy, filter_rects, target_rects, out_slabs=False):
+        self.e = energy
+        self.frs = _rects(filter_rects)
+        self.trs = _rects(target_rects)
+        self.n = len(self.frs)
+        self.out_slabs = bool(out_slabs)
+        h = C.c_void_p()
+        energy._chk(energy.L.les_hip_batch_create(energy.h, self.n, _ptr(self.frs), _ptr(self.trs), int(out_slabs), C.byref(h)))
+        self.h = h
+
+    @property
+    def num_jobs(self):
+        return self.e.L.les_hip_batch_num_jobs(self.h)
+
+    def run(self, planes, out_dev_ptr, mode=0, check=True, planes_on_device=False):
+        """planes: host array (n,4) or a device pointer (int) when planes_on_device; out_dev_ptr: int."""
+        if planes_on_device:
+            pp = C.c_void_p(int(planes))
+        else:
+            self._planes = _planes(planes)
+            assert len(self._planes) == self.n
+            pp = _ptr(self._planes)
+        self.e._chk(self.e.L.les_hip_batch_run(self.e.h, self.h, mode, pp, int(planes_on_device), C.c_void_p(int(out_dev_ptr)), int(check)))
+
+    def destroy(self):
+        if self.h:
+            self.e.L.les_hip_batch_destroy(self.h)
+            self.h = None
+
+
+class HipCostVolumeEnergy:
+    """Python mirror of CostVolumeEnergy (LES/CostVolumeEnergy.h:6-184) over the C ABI."""
+
+    def __init__(self, imL, imR, volL, volR, windR=20, eps=1e-4, th_col=0.5, max_disp=None, min_disp=0.0,
+                 device=0, volumes_on_device=False, shape=None, lib=None):
+        self.L = load(lib)
+        self.imL = np.ascontiguousarray(imL, np.uint8) if imL is not None else None
+        self.imR = np.ascontiguousarray(imR, np.uint8) if imR is not None else None
+        im = self.imL if self.imL is not None else self.imR
+        self.H, self.W = im.shape[:2]
+        if volumes_on_device:
+            self.D = int(shape[0])
+            vl, vr = (C.c_void_p(int(volL)) if volL else None), (C.c_void_p(int(volR)) if volR else None)
+            self._keep = None
+        else:
+            self._keep = [np.ascontiguousarray(v, np.float32) if v is not None else None for v in (volL, volR)]
+            v = self._keep[0] if self._keep[0] is not None else self._keep[1]
+            self.D = v.shape[0]
+            vl, vr = _ptr(self._keep[0]), _ptr(self._keep[1])
+        self.max_disp = float(self.D - 1 if max_disp is None else max_disp)
+        self.params = Params(self.H, self.W, self.D, windR, eps, th_col, self.max_disp, float(min_disp), device,
+                             int(bool(volumes_on_device)))
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.L.les_hip_create(C.byref(h), C.byref(self.params), _ptr(self.imL), _ptr(self.imR), vl, vr))
+        self.h = h
+        self._keep = None     # host volumes were copied to HBM
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LesHipError(f"liblocalexp_hip error {rc}: {self.L.les_hip_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.les_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.les_hip_set_stream(self.h, C.c_void_p(int(stream_ptr))))
+
+    def synchronize(self):
+        self._chk(self.L.les_hip_synchronize(self.h))
+
+    def strip_width(self):
+        return self.L.les_hip_strip_width(self.params.windR // 2)
+
+    def stats(self, mode=0):
+        out = np.empty((self.H, self.W, 3, 4), np.float32)
+        self._chk(self.L.les_hip_get_stats(self.h, mode, _ptr(out)))
+        return out
+
+    # -- the operator (names follow the reference) ------------------------------------------------
+    def ComputeUnaryPotential(self, filterRect, targetRect, costs_map, plane, mode=0, check=True):
+        """costs_map is the caller's H x W float32 map; like the reference call site
+        (LES/FastGCStereo.h:49) the view costs_map(filterRect) is handed to the operator."""
+        assert costs_map.dtype == np.float32 and costs_map.flags.c_contiguous and costs_map.shape == (self.H, self.W)
+        fr, tr = _rects([filterRect]), _rects([targetRect])
+        pl = _planes([plane])
+        origin = costs_map.ctypes.data + 4 * (int(fr["y"][0]) * self.W + int(fr["x"][0]))
+        self._chk(self.L.les_hip_unary_one(self.h, mode, _ptr(fr), _ptr(tr), _ptr(pl), C.c_void_p(origin), self.W, int(check)))
+        return costs_map
+
+    def ComputeUnaryPotentialWithoutCheck(self, filterRect, targetRect, costs_map, plane, mode=0):
+        return self.ComputeUnaryPotential(filterRect, targetRect, costs_map, plane, mode, check=False)
+
+    def unary_batch(self, filter_rects, target_rects, planes, costs_map=None, mode=0, check=True):
+        if costs_map is None:
+            costs_map = np.full((self.H, self.W), np.nan, np.float32)
+        frs, trs, pls = _rects(filter_rects), _rects(target_rects), _planes(planes)
+        assert len(frs) == len(trs) == len(pls)
+        self._chk(self.L.les_hip_unary_batch(self.h, mode, len(frs), _ptr(frs), _ptr(trs), _ptr(pls), _ptr(costs_map), int(check)))
+        return costs_map
+
+    def wta_update(self, rects, planes, cur_cost_dev, prop_cost_dev, labels_dev, planes_on_device=False):
+        rects = _rects(rects)
+        if planes_on_device:
+            pp = C.c_void_p(int(planes))
+        else:
+            self._wplanes = _planes(planes)
+            pp = _ptr(self._wplanes)
+        self._chk(self.L.les_hip_wta_update(self.h, len(rects), _ptr(rects), pp, int(planes_on_device),
+                                            C.c_void_p(int(cur_cost_dev)), C.c_void_p(int(prop_cost_dev)), C.c_void_p(int(labels_dev))))

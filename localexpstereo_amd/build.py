@@ -1,0 +1,73 @@
+"""In-tree build of the native pieces (explicit compiler invocations, no JIT cache).
+
+  build_hip()     hipcc --offload-arch=gfx950 -> localexpstereo_amd/csrc/liblocalexp_hip.so   (the product)
+  build_host()    g++ -> localexpstereo_amd/host/les_host_demo (C++ host adapter self-test, links the .so)
+  build_oracle()  g++ -> oracle/libles_oracle.so        (CPU restatement: test infrastructure only)
+  build_sim()     g++ -> tools/hipsim/liblocalexp_sim.so (CPU SIMT simulator build of the same sources:
+                  test infrastructure only, never loaded by the package)
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+HOST = os.path.join(_HERE, "host")
+HIP_SO = os.path.join(CSRC, "liblocalexp_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources if os.path.exists(s))
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (needed to build liblocalexp_hip.so for gfx950)")
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in ("les_hip.hip", "les_kernels.h", "les_simt.h")]
+    srcs.append(os.path.join(ROOT, "include", "localexp_hip.h"))
+    if not force and _newer(HIP_SO, srcs):
+        return HIP_SO
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", HIP_SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return HIP_SO
+
+
+def build_host(force=False):
+    exe = os.path.join(HOST, "les_host_demo")
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".h", ".cpp"))] if os.path.isdir(HOST) else []
+    main = os.path.join(HOST, "les_host_demo.cpp")
+    if not os.path.exists(main):
+        return None
+    if not force and _newer(exe, srcs + [HIP_SO]):
+        return exe
+    cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), main, "-o", exe,
+           "-L", CSRC, "-llocalexp_hip", "-Wl,-rpath," + CSRC]
+    subprocess.check_call(cmd, cwd=HOST)
+    return exe
+
+
+def build_oracle(force=False):
+    d = os.path.join(ROOT, "oracle")
+    args = ["make", "-C", d] + (["-B"] if force else []) + ["libles_oracle.so"]
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return os.path.join(d, "libles_oracle.so")
+
+
+def build_sim(force=False):
+    d = os.path.join(ROOT, "tools", "hipsim")
+    args = ["make", "-C", d] + (["-B"] if force else []) + ["liblocalexp_sim.so"]
+    subprocess.check_call(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(d, "liblocalexp_sim.so")

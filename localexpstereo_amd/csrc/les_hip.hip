@@ -1,0 +1,434 @@
+// les_hip.hip -- C ABI (include/localexp_hip.h) + host-side launch logic of the MI355X matching-cost path.
+//
+// Build (see __graft_entry__.build / localexpstereo_amd/build.py):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared les_hip.hip -o liblocalexp_hip.so
+// There is no CPU fallback in this library: every entry point needs a HIP device.
+// (tools/hipsim compiles this same file against a CPU fiber simulator for logic tests only.)
+#include "../../include/localexp_hip.h"
+#include "les_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                               \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(LES_HIP_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- kernel configurations compiled into this build: guided-filter radius -> strip geometry
+constexpr int kWA = 64;     // stage-1 columns per workgroup (NT = 256 threads)
+constexpr int kBY = 16;     // rows per block
+typedef void (*StripKernel)(les::Geom, les::View, const les::Job*, const float4*, float*, int, int);
+struct StripEntry { int R; int TW; int NT; StripKernel fn; };
+
+#define LES_STRIP_ENTRY(R_) { R_, les::StripCfg<R_, kWA, kBY>::TW, les::StripCfg<R_, kWA, kBY>::NT, les::les_strip_kernel<R_, kWA, kBY> }
+const StripEntry kStrips[] = {
+    LES_STRIP_ENTRY(1), LES_STRIP_ENTRY(2), LES_STRIP_ENTRY(3), LES_STRIP_ENTRY(5), LES_STRIP_ENTRY(8), LES_STRIP_ENTRY(10),
+};
+const StripEntry* find_strip(int R)
+{
+    for (const auto& e : kStrips)
+        if (e.R == R) return &e;
+    return nullptr;
+}
+
+struct ViewData {
+    float* vol = nullptr;
+    bool own_vol = false;
+    float4* stats = nullptr;
+    uint32_t* ipk = nullptr;
+};
+
+}  // namespace
+
+struct les_hip_ctx {
+    les_hip_params p;
+    int R;
+    const StripEntry* strip;
+    hipStream_t stream;
+    les::Geom geom;
+    ViewData v[2];
+    // scratch reused by the non-prepared entry points and by batch_run
+    float4* d_planes = nullptr; size_t planes_cap = 0;
+    float* d_map = nullptr;                         // H*W floats
+    les::WtaJob* d_wta = nullptr; size_t wta_cap = 0;
+    float4* d_wta_planes = nullptr; size_t wta_planes_cap = 0;
+};
+
+struct les_hip_batch {
+    int n = 0, njobs = 0, out_slabs = 0, R = 0;
+    les::Job* d_jobs = nullptr;
+    std::vector<les_hip_rect> targets;
+    int device = 0;
+};
+
+namespace {
+
+int check_rects(const les_hip_ctx* c, const les_hip_rect& f, const les_hip_rect& t)
+{
+    if (f.w < 0 || f.h < 0 || t.w < 0 || t.h < 0) return fail(LES_HIP_ERR_ARG, "negative rect size");
+    if (f.x < 0 || f.y < 0 || f.x + f.w > c->p.W || f.y + f.h > c->p.H) return fail(LES_HIP_ERR_ARG, "filterRect outside the image");
+    if (t.w > 0 && t.h > 0 && (t.x < f.x || t.y < f.y || t.x + t.w > f.x + f.w || t.y + t.h > f.y + f.h))
+        return fail(LES_HIP_ERR_ARG, "targetRect not inside filterRect");
+    return LES_HIP_OK;
+}
+
+// Split every call's target rect into strips of TW columns (and row chunks when there are few calls),
+// ordered by position so that neighbouring workgroups share volume halos / guide statistics in L2.
+int build_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs,
+               std::vector<les::Job>& jobs)
+{
+    const int TW = c->strip->TW, R = c->R;
+    const long long P = (long long)c->p.H * c->p.W;
+    long long strips = 0;
+    for (int i = 0; i < n; i++) {
+        int rc = check_rects(c, frs[i], trs[i]);
+        if (rc) return rc;
+        if (trs[i].w > 0 && trs[i].h > 0) strips += (trs[i].w + TW - 1) / TW;
+    }
+    // row chunking: aim for >= ~2048 workgroups, never below 8*R rows per chunk (4R rows are halo work)
+    int max_rows = 1 << 30;
+    if (strips > 0 && strips < 2048) {
+        long long want = (2048 + strips - 1) / strips;
+        int tallest = 0;
+        for (int i = 0; i < n; i++) tallest = std::max(tallest, trs[i].h);
+        max_rows = std::max<long long>(std::max(8 * R, 64), (tallest + want - 1) / want);
+    }
+    jobs.clear();
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect &f = frs[i], &t = trs[i];
+        if (t.w <= 0 || t.h <= 0) continue;
+        for (int sy = 0; sy < t.h; sy += max_rows)
+            for (int sx = 0; sx < t.w; sx += TW) {
+                les::Job j;
+                j.tx0 = t.x + sx; j.ty0 = t.y + sy;
+                j.tw = std::min(TW, t.w - sx); j.th = std::min(max_rows, t.h - sy);
+                j.cx0 = f.x; j.cy0 = f.y; j.cx1 = f.x + f.w; j.cy1 = f.y + f.h;
+                j.out_off = (out_slabs ? (long long)i * P : 0) + (long long)j.ty0 * c->p.W + j.tx0;
+                j.out_stride = c->p.W;
+                j.plane_idx = i;
+                jobs.push_back(j);
+            }
+    }
+    std::stable_sort(jobs.begin(), jobs.end(), [](const les::Job& a, const les::Job& b) {
+        if (a.tx0 != b.tx0) return a.tx0 < b.tx0;
+        if (a.ty0 != b.ty0) return a.ty0 < b.ty0;
+        return a.plane_idx < b.plane_idx;
+    });
+    return LES_HIP_OK;
+}
+
+int ensure_planes(les_hip_ctx* c, size_t n)
+{
+    if (n <= c->planes_cap) return LES_HIP_OK;
+    if (c->d_planes) HIPCHECK(hipFree(c->d_planes));
+    c->d_planes = nullptr; c->planes_cap = 0;
+    size_t cap = std::max<size_t>(n, 1024);
+    HIPCHECK(hipMalloc((void**)&c->d_planes, cap * sizeof(float4)));
+    c->planes_cap = cap;
+    return LES_HIP_OK;
+}
+
+int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, const float4* d_planes, float* d_out, int check)
+{
+    if (njobs <= 0) return LES_HIP_OK;
+    if (mode < 0 || mode > 1 || !c->v[mode].vol || !c->v[mode].stats) return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
+    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk};
+    hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, c->stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
+{
+    const size_t P = (size_t)c->p.H * c->p.W;
+    ViewData& v = c->v[m];
+    if (vol) {
+        if (c->p.volumes_on_device) { v.vol = const_cast<float*>(vol); v.own_vol = false; }
+        else {
+            HIPCHECK(hipMalloc((void**)&v.vol, P * c->p.D * sizeof(float)));
+            v.own_vol = true;
+            HIPCHECK(hipMemcpy(v.vol, vol, P * c->p.D * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    if (!im) return LES_HIP_OK;
+    uint8_t* d_img = nullptr;
+    double* d_hs = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_img, P * 3));
+    HIPCHECK(hipMemcpy(d_img, im, P * 3, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc((void**)&v.ipk, P * sizeof(uint32_t)));
+    HIPCHECK(hipMalloc((void**)&v.stats, P * 3 * sizeof(float4)));
+    HIPCHECK(hipMalloc((void**)&d_hs, P * 9 * sizeof(double)));
+    const int W = c->p.W, H = c->p.H;
+    hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, c->stream, d_img, v.ipk, (int)P);
+    hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, v.ipk, d_hs, H, W, c->R);
+    hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.stats, H, W, c->R, c->p.eps);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipFree(d_img));
+    HIPCHECK(hipFree(d_hs));
+    return LES_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* les_hip_last_error(void) { return g_err.c_str(); }
+
+int les_hip_strip_width(int R)
+{
+    const StripEntry* e = find_strip(R);
+    return e ? e->TW : 0;
+}
+
+int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
+                   const float* volL, const float* volR)
+{
+    if (!out || !params) return fail(LES_HIP_ERR_ARG, "null argument");
+    *out = nullptr;
+    const les_hip_params& p = *params;
+    if (p.H <= 0 || p.W <= 0 || p.D <= 0 || p.windR < 2) return fail(LES_HIP_ERR_ARG, "bad dimensions");
+    const StripEntry* strip = find_strip(p.windR / 2);
+    if (!strip) return fail(LES_HIP_ERR_UNSUPPORTED, "no kernel instantiated for guided-filter radius %d (windR %d)", p.windR / 2, p.windR);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LES_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (p.device < 0 || p.device >= ndev) return fail(LES_HIP_ERR_ARG, "device %d out of range (%d devices)", p.device, ndev);
+    HIPCHECK(hipSetDevice(p.device));
+    les_hip_ctx* c = new les_hip_ctx();
+    c->p = p;
+    c->R = p.windR / 2;
+    c->strip = strip;
+    c->stream = nullptr;
+    c->geom.H = p.H; c->geom.W = p.W; c->geom.D = p.D;
+    c->geom.D0 = (int)(-p.min_disparity);                       // LES/CostVolumeEnergy.h:67
+    c->geom.th_col = p.th_col; c->geom.pad_ = 0.0f;
+    c->geom.maxd = p.max_disparity; c->geom.mind = p.min_disparity;
+    const uint8_t* ims[2] = {imL, imR};
+    const float* vols[2] = {volL, volR};
+    for (int m = 0; m < 2; m++) {
+        int rc = build_view(c, m, ims[m], vols[m]);
+        if (rc) { les_hip_destroy(c); return rc; }
+    }
+    if (hipMalloc((void**)&c->d_map, (size_t)p.H * p.W * sizeof(float)) != hipSuccess) {
+        les_hip_destroy(c);
+        return fail(LES_HIP_ERR_DEVICE, "hipMalloc of the scratch cost map failed");
+    }
+    *out = c;
+    return LES_HIP_OK;
+}
+
+void les_hip_destroy(les_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    for (int m = 0; m < 2; m++) {
+        if (c->v[m].own_vol && c->v[m].vol) (void)hipFree(c->v[m].vol);
+        if (c->v[m].stats) (void)hipFree(c->v[m].stats);
+        if (c->v[m].ipk) (void)hipFree(c->v[m].ipk);
+    }
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    if (c->d_map) (void)hipFree(c->d_map);
+    if (c->d_wta) (void)hipFree(c->d_wta);
+    if (c->d_wta_planes) (void)hipFree(c->d_wta_planes);
+    delete c;
+}
+
+int les_hip_set_stream(les_hip_ctx* c, void* s)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null context");
+    c->stream = (hipStream_t)s;
+    return LES_HIP_OK;
+}
+
+int les_hip_synchronize(les_hip_ctx* c)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null context");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return LES_HIP_OK;
+}
+
+int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs, les_hip_batch** out)
+{
+    if (!c || !out || n < 0 || (n > 0 && (!frs || !trs))) return fail(LES_HIP_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::vector<les::Job> jobs;
+    int rc = build_jobs(c, n, frs, trs, out_slabs, jobs);
+    if (rc) return rc;
+    les_hip_batch* b = new les_hip_batch();
+    b->n = n; b->njobs = (int)jobs.size(); b->out_slabs = out_slabs; b->R = c->R; b->device = c->p.device;
+    b->targets.assign(trs, trs + n);
+    if (!jobs.empty()) {
+        if (hipMalloc((void**)&b->d_jobs, jobs.size() * sizeof(les::Job)) != hipSuccess) { delete b; return fail(LES_HIP_ERR_DEVICE, "hipMalloc(jobs) failed"); }
+        if (hipMemcpy(b->d_jobs, jobs.data(), jobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(b->d_jobs); delete b; return fail(LES_HIP_ERR_DEVICE, "hipMemcpy(jobs) failed");
+        }
+    }
+    *out = b;
+    return LES_HIP_OK;
+}
+
+void les_hip_batch_destroy(les_hip_batch* b)
+{
+    if (!b) return;
+    if (b->d_jobs) (void)hipFree(b->d_jobs);
+    delete b;
+}
+
+int les_hip_batch_num_jobs(const les_hip_batch* b) { return b ? b->njobs : 0; }
+
+int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const les_hip_plane* planes, int planes_on_device,
+                      float* out_dev, int check)
+{
+    if (!c || !b || !out_dev || (b->n > 0 && !planes)) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (b->R != c->R) return fail(LES_HIP_ERR_ARG, "batch was prepared for a different context");
+    const float4* d_planes = reinterpret_cast<const float4*>(planes);
+    if (!planes_on_device) {
+        int rc = ensure_planes(c, (size_t)b->n);
+        if (rc) return rc;
+        HIPCHECK(hipMemcpyAsync(c->d_planes, planes, (size_t)b->n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        d_planes = c->d_planes;
+    }
+    return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check);
+}
+
+int les_hip_unary_batch(les_hip_ctx* c, int mode, int n, const les_hip_rect* frs, const les_hip_rect* trs,
+                        const les_hip_plane* planes, float* cost_map, int check)
+{
+    if (!c || !cost_map) return fail(LES_HIP_ERR_ARG, "null argument");
+    les_hip_batch* b = nullptr;
+    int rc = les_hip_batch_create(c, n, frs, trs, 0, &b);
+    if (rc) return rc;
+    rc = les_hip_batch_run(c, b, mode, planes, 0, c->d_map, check);
+    if (rc == LES_HIP_OK) {
+        // copy back only the target rects (the reference writes nothing else, LES/CostVolumeEnergy.h:169-171)
+        for (int i = 0; i < n && rc == LES_HIP_OK; i++) {
+            const les_hip_rect& t = trs[i];
+            if (t.w <= 0 || t.h <= 0) continue;
+            size_t off = (size_t)t.y * c->p.W + t.x;
+            hipError_t e = hipMemcpy2DAsync(cost_map + off, (size_t)c->p.W * sizeof(float), c->d_map + off, (size_t)c->p.W * sizeof(float),
+                                            (size_t)t.w * sizeof(float), (size_t)t.h, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
+        }
+        if (rc == LES_HIP_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "stream synchronize failed");
+    }
+    les_hip_batch_destroy(b);
+    return rc;
+}
+
+int les_hip_unary_one(les_hip_ctx* c, int mode, const les_hip_rect* fr, const les_hip_rect* tr, const les_hip_plane* plane,
+                      float* costs, int row_stride, int check)
+{
+    if (!c || !fr || !tr || !plane || !costs) return fail(LES_HIP_ERR_ARG, "null argument");
+    les_hip_batch* b = nullptr;
+    int rc = les_hip_batch_create(c, 1, fr, tr, 0, &b);
+    if (rc) return rc;
+    rc = les_hip_batch_run(c, b, mode, plane, 0, c->d_map, check);
+    if (rc == LES_HIP_OK && tr->w > 0 && tr->h > 0) {
+        // costs(targetRect - filterRect.tl()), LES/CostVolumeEnergy.h:169
+        float* dst = costs + (size_t)(tr->y - fr->y) * row_stride + (tr->x - fr->x);
+        const float* src = c->d_map + (size_t)tr->y * c->p.W + tr->x;
+        hipError_t e = hipMemcpy2DAsync(dst, (size_t)row_stride * sizeof(float), src, (size_t)c->p.W * sizeof(float),
+                                        (size_t)tr->w * sizeof(float), (size_t)tr->h, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
+        else if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "stream synchronize failed");
+    }
+    les_hip_batch_destroy(b);
+    return rc;
+}
+
+int les_hip_wta_update(les_hip_ctx* c, int n, const les_hip_rect* rects, const les_hip_plane* planes, int planes_on_device,
+                       float* cur, const float* prop, les_hip_plane* labels)
+{
+    if (!c || n < 0 || (n > 0 && (!rects || !planes || !cur || !prop || !labels))) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (n == 0) return LES_HIP_OK;
+    for (int i = 0; i < n; i++)
+        if (rects[i].x < 0 || rects[i].y < 0 || rects[i].w < 0 || rects[i].h < 0 || rects[i].x + rects[i].w > c->p.W || rects[i].y + rects[i].h > c->p.H)
+            return fail(LES_HIP_ERR_ARG, "rect outside the image");
+    if ((size_t)n > c->wta_cap) {
+        if (c->d_wta) HIPCHECK(hipFree(c->d_wta));
+        c->d_wta = nullptr; c->wta_cap = 0;
+        HIPCHECK(hipMalloc((void**)&c->d_wta, std::max<size_t>(n, 1024) * sizeof(les::WtaJob)));
+        c->wta_cap = std::max<size_t>(n, 1024);
+    }
+    static_assert(sizeof(les::WtaJob) == sizeof(les_hip_rect), "rect layout");
+    HIPCHECK(hipMemcpyAsync(c->d_wta, rects, (size_t)n * sizeof(les::WtaJob), hipMemcpyHostToDevice, c->stream));
+    const float4* d_planes = reinterpret_cast<const float4*>(planes);
+    if (!planes_on_device) {
+        if ((size_t)n > c->wta_planes_cap) {
+            if (c->d_wta_planes) HIPCHECK(hipFree(c->d_wta_planes));
+            c->d_wta_planes = nullptr; c->wta_planes_cap = 0;
+            HIPCHECK(hipMalloc((void**)&c->d_wta_planes, std::max<size_t>(n, 1024) * sizeof(float4)));
+            c->wta_planes_cap = std::max<size_t>(n, 1024);
+        }
+        HIPCHECK(hipMemcpyAsync(c->d_wta_planes, planes, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        d_planes = c->d_wta_planes;
+    }
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(n), dim3(256), 0, c->stream, c->d_wta, d_planes, cur, prop,
+                       reinterpret_cast<float4*>(labels), c->p.W);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_malloc(les_hip_ctx* c, void** p, size_t bytes)
+{
+    if (!c || !p) return fail(LES_HIP_ERR_ARG, "null argument");
+    HIPCHECK(hipMalloc(p, bytes));
+    return LES_HIP_OK;
+}
+int les_hip_free(les_hip_ctx* c, void* p)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (p) HIPCHECK(hipFree(p));
+    return LES_HIP_OK;
+}
+int les_hip_memcpy_h2d(les_hip_ctx* c, void* d, const void* s, size_t bytes)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
+    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return LES_HIP_OK;
+}
+int les_hip_memcpy_d2h(les_hip_ctx* c, void* d, const void* s, size_t bytes)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
+    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return LES_HIP_OK;
+}
+int les_hip_memset(les_hip_ctx* c, void* d, int value, size_t bytes)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
+    HIPCHECK(hipMemsetAsync(d, value, bytes, c->stream));
+    return LES_HIP_OK;
+}
+
+int les_hip_get_stats(les_hip_ctx* c, int mode, float* out)
+{
+    if (!c || !out || mode < 0 || mode > 1 || !c->v[mode].stats) return fail(LES_HIP_ERR_ARG, "bad argument");
+    HIPCHECK(hipMemcpy(out, c->v[mode].stats, (size_t)c->p.H * c->p.W * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    return LES_HIP_OK;
+}
+
+}  // extern "C"

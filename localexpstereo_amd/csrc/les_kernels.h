@@ -1,0 +1,443 @@
+// les_kernels.h -- HIP kernels of the matching-cost hot path (gfx950 / CDNA4, wave64).
+//
+// What is computed (reference: LES/CostVolumeEnergy.h:55-183, LES/GuidedFilter.h:142-266,301-326):
+//   for a plane (a,b,c), a target rect and a clip rect (== the reference's filterRect):
+//     p(s)   = min( lerp_d vol[a*x+b*y+c][y][x], th_col )              s in clip        (gather)
+//     Sp, SIp_c = 21x21 zero-padded window sums of p, I_c*p over the clip               (stage 1)
+//     a_c, b    = per-pixel 3x3 solve with the precomputed guide statistics
+//     q(y)   = ( box(b) + sum_c box(a_c) I_c(y) ) / N(y)                                 (stage 2)
+//   q is written for the target pixels only; pixels with an invalid label get 1e6.
+//
+// Kernel structure ("strip march"): one workgroup owns a strip of TW output columns of one job and
+// marches down the rows in blocks of BY rows.  Per block:
+//   G   gather p (2 volume taps, coalesced along x) for BY new rows x WP=TW+4R columns -> LDS
+//   H1  horizontal 2R+1 sums of (I'_0 p, I'_1 p, I'_2 p, p) : threads own (row, quantity, segment)
+//       and slide along x with an fp64 cumulative sum held in a register ring          -> LDS  T[row][x][k]
+//   V   threads own (column, quantity) = lane quads; vertical sums by fp64 cumulative register
+//       rings that persist across blocks; the 3x3 algebra is distributed over the quad with DPP
+//       quad_perm broadcasts; the vertical sums of (a_0,a_1,a_2,b) follow immediately   -> LDS  T (in place)
+//   H2  horizontal sums of the 4 stage-2 quantities, weighted by I'_c(y) and reduced over the quad
+//   F   coalesced store of q (+ validity overwrite)
+// All box sums are accumulated in fp64 (the reference's default "GF" filter is double); only
+// 21-term partial sums are rounded to fp32 when they pass through LDS.  The guide is centred
+// (I' = I - 1/2: cov and q are exactly invariant to a constant shift of I, for any clip rect), which
+// keeps those roundings far below the 1e-4 parity bound (measured: see DESIGN.md "Numerics").
+// The cost p itself is NOT centred: that would only be exact where the clipped window of the
+// sub-region equals the whole-image window, and the operator must reproduce the reference for any
+// (filterRect, targetRect), including targets closer than 2R to the filterRect border.
+//
+// This header is also compiled by tools/hipsim (CPU fiber simulator, test infrastructure only) with
+// LES_SIM defined; nothing in the product build depends on that.
+#pragma once
+
+#include "les_simt.h"
+
+namespace les {
+
+struct Geom {
+    int H, W, D, D0;          // D0 = int(-MIN_DISPARITY), LES/CostVolumeEnergy.h:67
+    float th_col, pad_;       // truncation threshold
+    float maxd, mind;         // MAX_DISPARITY, MIN_DISPARITY
+};
+
+struct View {
+    const float* vol;          // [D][H][W]
+    const float4* stats;       // [H*W][3] : {mean_I'_k, inv[k][0], inv[k][1], inv[k][2]}, k = 0..2
+    const uint32_t* ipk;       // [H*W] guide pixel packed B | G<<8 | R<<16
+};
+
+struct Job {
+    int tx0, ty0, tw, th;      // target strip (image coordinates), tw <= TW
+    int cx0, cy0, cx1, cy1;    // clip rect [cx0,cx1) x [cy0,cy1) == reference filterRect
+    long long out_off;         // float offset of output element (ty0, tx0)
+    int out_stride;            // floats per output row
+    int plane_idx;             // index into the planes array of this launch (LES/Plane.h labels)
+};
+
+#define LES_COST_INVALID 1000000.0f
+
+// ---------------------------------------------------------------------------------------------------
+// LES/CostVolumeEnergy.h:70-98 (interpolate == 1).  Compiled with -ffp-contract=off: d must be the
+// un-fused float expression a*x + (b*y + c) so that int(d) and the validity thresholds match the CPU.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gather_cost(const Geom& g, const float* __restrict__ vol, float a, float b,
+                                             float c, int gx, int gy)
+{
+    const size_t HW = (size_t)g.H * g.W;
+    const size_t px = (size_t)gy * g.W + gx;
+    float d_base = b * (float)gy + c;
+    float d = a * (float)gx + d_base;
+    float C;
+    if (d < g.mind) C = vol[px];
+    else if (d >= g.maxd) C = vol[(size_t)(g.D - 1) * HW + px];
+    else if (d != d || fabsf(d) == INFINITY) C = LES_COST_INVALID;
+    else {
+        int d0 = (int)d + g.D0;
+        int d1 = d0 + 1;
+        float f1 = d - floorf(d);
+        float f0 = 1.0f - f1;
+        if (d1 >= g.D || d0 < 0) C = LES_COST_INVALID;
+        else {
+            float v0 = vol[(size_t)d0 * HW + px];
+            float v1 = vol[(size_t)d1 * HW + px];
+            C = f0 * v0 + f1 * v1;
+        }
+    }
+    return (g.th_col < C) ? g.th_col : C;       // std::min(C, th_col), NaN-propagating like the reference
+}
+
+// LES/StereoEnergy.h:560-610
+__device__ __forceinline__ bool label_valid(const Geom& g, float a, float b, float c, float v, int gx, int gy)
+{
+    float fx = (float)gx, fy = (float)gy;
+    float ds = ((fx * a + fy * b) + 1.0f * c) + 0.0f * v;
+    float a5 = a * 5, b5 = b * 5;
+    float d;
+    return (ds >= g.mind && ds <= g.maxd
+            && ((d = ds + a5 + b5) >= g.mind) && d <= g.maxd
+            && ((d = ds + a5 - b5) >= g.mind) && d <= g.maxd
+            && ((d = ds - a5 + b5) >= g.mind) && d <= g.maxd
+            && ((d = ds - a5 - b5) >= g.mind) && d <= g.maxd);
+}
+
+// I'_k = I_k - 1/2 with I_k = u8/255 (LES/GuidedFilter.h:62-65 scaling), k = 0..2; k = 3 -> 1
+__device__ __forceinline__ float guide_centred_f32(uint32_t ipk, int k)
+{
+    int u = (int)((ipk >> (8 * k)) & 0xffu);
+    float w = (float)(2 * u - 255) * (1.0f / 510.0f);
+    return k == 3 ? 1.0f : w;
+}
+__device__ __forceinline__ double guide_centred_f64(uint32_t ipk, int k)
+{
+    int u = (int)((ipk >> (8 * k)) & 0xffu);
+    double w = (double)u * (1.0 / 255) - 0.5;
+    return k == 3 ? 1.0 : w;
+}
+
+__device__ __forceinline__ int window_count(int c, int R, int lo, int hi)
+{   // number of integers in [c-R, c+R] intersected with [lo, hi)
+    int a = c - R < lo ? lo : c - R;
+    int b = c + R + 1 > hi ? hi : c + R + 1;
+    return b > a ? b - a : 0;
+}
+
+// compile-time slot dispatch (binary search over [LO,HI]); `slot` is wave-uniform
+template <int LO, int HI>
+struct SlotDispatch {
+    template <typename F>
+    __device__ __forceinline__ static void run(int slot, F& f)
+    {
+        if constexpr (LO == HI) {
+            f.template step<LO>();
+        } else {
+            constexpr int MID = (LO + HI) / 2;
+            if (slot <= MID) SlotDispatch<LO, MID>::run(slot, f);
+            else SlotDispatch<MID + 1, HI>::run(slot, f);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Vertical phase state of one (column, quantity) lane.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+struct VLane {
+    static constexpr int RING = 2 * R + 2;
+    double ring1[RING] = {};
+    double ring2[RING] = {};
+    // per-row inputs / outputs
+    float in;            // H1 sum of this lane's quantity for the incoming p-row
+    float out;           // vertical stage-2 sum (centred R rows above the stage-1 row)
+    bool do_algebra;     // wave-uniform: t >= 2R
+    bool in_clip;        // stage-1 pixel inside the clip rect
+    int k;               // quantity: 0..2 -> I'_k p' / a_k, 3 -> p' / b
+    double rn1;          // 1 / N of the stage-1 pixel
+    const float4* st;    // statistics of the stage-1 pixel, valid when in_clip && k < 3
+
+    template <int S>
+    __device__ __forceinline__ void step()
+    {
+        constexpr int PREV = (S + RING - 1) % RING, OLD = (S + 1) % RING;
+        double C1 = ring1[PREV] + (double)in;
+        ring1[S] = C1;
+        double S1 = C1 - ring1[OLD];                       // sum over the last 2R+1 p-rows
+        float val = 0.0f;
+        if (do_algebra) {
+            // LES/GuidedFilter.h:204-221 on centred quantities
+            double m = S1 * rn1;                           // lane k<3: mean(I'_k p'), lane 3: mean(p')
+            double mq[4];
+            quad_allgather(m, mq);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in_clip && k < 3) s = *st;
+            double cov = m - (double)s.x * mq[3];          // cov_k = mean(I'_k p') - mean_I'_k * mean_p'
+            float cv[4];
+            quad_allgather((float)cov, cv);
+            float ak = s.y * cv[0] + s.z * cv[1] + s.w * cv[2];
+            float tk = ak * s.x;
+            float tt[4];
+            quad_allgather(tk, tt);
+            float bb = (float)mq[3] - tt[0] - tt[1] - tt[2];
+            val = (k < 3) ? ak : bb;
+            if (!in_clip) val = 0.0f;                      // a, b are zero-padded outside the sub-region
+        }
+        double C2 = ring2[PREV] + (double)val;
+        ring2[S] = C2;
+        out = (float)(C2 - ring2[OLD]);                    // sum over the last 2R+1 stage-1 rows
+#if !defined(LES_SIM)
+        // Keeps the RING instantiations distinct up to their last instruction: otherwise the optimiser
+        // sinks the common tail of the dispatch leaves into one block with a run-time ring index,
+        // which forces both rings out of registers into scratch memory.
+        asm volatile("" ::"n"(S));
+#endif
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// The fused strip kernel.   NT = 4*WA threads; TW = WA-2R output columns per strip.
+// ---------------------------------------------------------------------------------------------------
+template <int R, int WA, int BY>
+struct StripCfg {
+    static constexpr int TW = WA - 2 * R;
+    static constexpr int WP = WA + 2 * R;
+    static constexpr int NT = 4 * WA;
+    static constexpr int SEG = NT / (4 * BY);              // segments per (row, quantity)
+    static constexpr int L1 = WA / SEG;                    // H1 outputs per segment
+    static constexpr int L2 = (TW + SEG - 1) / SEG;        // H2 outputs per segment
+    static constexpr int TPITCH = WA * 4 + 4;              // floats per T row (+4: bank spread across rows)
+    static constexpr int RING = 2 * R + 2;
+    static_assert(NT % (4 * BY) == 0 && WA % SEG == 0, "bad strip configuration");
+    static_assert(TW > 0, "strip too narrow for this radius");
+};
+
+template <int R, int WA, int BY>
+__global__ void __launch_bounds__(4 * WA)
+les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
+                 float* __restrict__ out, int njobs, int check)
+{
+    using Cfg = StripCfg<R, WA, BY>;
+    constexpr int TW = Cfg::TW, WP = Cfg::WP, NT = Cfg::NT, SEG = Cfg::SEG, L1 = Cfg::L1, L2 = Cfg::L2;
+    constexpr int TPITCH = Cfg::TPITCH, RING = Cfg::RING;
+
+    __shared__ float s_p[BY][WP];            // truncated cost p (0 outside the clip)
+    __shared__ uint32_t s_ipk[BY][WP];       // packed guide pixel of the same p-rows
+    __shared__ float s_T[BY][TPITCH];        // H1 sums, then (in place) vertical stage-2 sums
+    __shared__ uint32_t s_ipk2[BY][TW];      // packed guide pixel of the output rows of this block
+    __shared__ float s_q[BY][TW];            // finished q of the output rows of this block
+    __shared__ double s_rtab[2 * R + 2];     // 1/n, n = 0..2R+1
+
+    // XCD-aware job order (guide T1): consecutive jobs (same strip, consecutive planes / neighbouring
+    // cells) run on the same XCD so that guide statistics and volume halos are shared in its L2.
+    int job_id;
+    {
+        const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        job_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    }
+    if (job_id >= njobs) return;
+    const Job job = jobs[job_id];
+    const float4 plane = planes[job.plane_idx];          // (a, b, c, v)
+    const int tid = (int)threadIdx.x;
+    const int Ttot = job.th + 4 * R;         // p-rows to march over
+
+    if (tid < 2 * R + 2) s_rtab[tid] = tid > 0 ? 1.0 / (double)tid : 0.0;
+
+    // ---- V-phase identity: lane quad = 4 quantities of stage-1 column vx
+    const int vx = tid >> 2, vk = tid & 3;
+    VLane<R> vl;
+    vl.k = vk;
+    const int gx1 = job.tx0 - R + vx;                                   // stage-1 column (image coords)
+    const bool col_in_clip = gx1 >= job.cx0 && gx1 < job.cx1;
+    const int nx1 = window_count(gx1, R, job.cx0, job.cx1);
+
+    // ---- H-phase identity: (segment, row, quantity); lanes of a wave differ in row first
+    const int hk = tid & 3, hrow = (tid >> 2) % BY, hseg = (tid >> 2) / BY;
+
+    __syncthreads();
+    const double rnx1 = s_rtab[nx1 > 2 * R + 1 ? 0 : nx1];
+
+    for (int t0 = 0; t0 < Ttot; t0 += BY) {
+        // ===================== G: gather =====================
+        for (int idx = tid; idx < BY * WP; idx += NT) {
+            const int i = idx / WP, xi = idx - i * WP;
+            const int t = t0 + i;
+            const int gy = job.ty0 - 2 * R + t, gx = job.tx0 - 2 * R + xi;
+            float pc = 0.0f;
+            uint32_t ip = 0;
+            if (t < Ttot && gx >= job.cx0 && gx < job.cx1 && gy >= job.cy0 && gy < job.cy1) {
+                pc = gather_cost(g, view.vol, plane.x, plane.y, plane.z, gx, gy);
+                ip = view.ipk[(size_t)gy * g.W + gx];
+            }
+            s_p[i][xi] = pc;
+            s_ipk[i][xi] = ip;
+        }
+        for (int idx = tid; idx < BY * TW; idx += NT) {
+            const int i = idx / TW, xo = idx - i * TW;
+            const int t = t0 + i;
+            const int gy2 = job.ty0 + t - 4 * R, gx2 = job.tx0 + xo;
+            uint32_t ip = 0;
+            if (t >= 4 * R && t < Ttot && xo < job.tw) ip = view.ipk[(size_t)gy2 * g.W + gx2];
+            s_ipk2[i][xo] = ip;
+        }
+        __syncthreads();
+
+        // ===================== H1: horizontal sums of F_k = I'_k p' =====================
+        {
+            double ring[RING];
+#pragma unroll
+            for (int i = 0; i < RING; i++) ring[i] = 0.0;
+            const int x0 = hseg * L1;
+#pragma unroll
+            for (int s = 0; s < L1 + 2 * R; s++) {
+                const int xi = x0 + s;                                  // p column index, < WP by construction
+                const float f = guide_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi];
+                const double C = ring[(s + RING - 1) % RING] + (double)f;
+                ring[s % RING] = C;
+                if (s >= 2 * R) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)(C - ring[(s + 1) % RING]);
+            }
+        }
+        __syncthreads();
+
+        // ===================== V: vertical sums, algebra, vertical sums =====================
+        for (int i = 0; i < BY; i++) {
+            const int t = t0 + i;
+            if (t >= Ttot) break;
+            const int gy1 = job.ty0 - 3 * R + t;                        // stage-1 row
+            vl.in = s_T[i][vx * 4 + vk];
+            vl.do_algebra = t >= 2 * R;
+            const bool row_in_clip = gy1 >= job.cy0 && gy1 < job.cy1;
+            vl.in_clip = col_in_clip && row_in_clip;
+            const int ny1 = window_count(gy1, R, job.cy0, job.cy1);
+            vl.rn1 = rnx1 * s_rtab[ny1 > 2 * R + 1 ? 0 : ny1];
+            vl.st = view.stats + ((size_t)(vl.in_clip ? gy1 : 0) * g.W + (vl.in_clip ? gx1 : 0)) * 3 + (vk < 3 ? vk : 0);
+            SlotDispatch<0, RING - 1>::run(t % RING, vl);
+            s_T[i][vx * 4 + vk] = vl.out;
+        }
+        __syncthreads();
+
+        // ===================== H2: horizontal sums + guide weighting + quad reduction =====================
+        {
+            const int t = t0 + hrow;
+            const bool row_ok = t >= 4 * R && t < Ttot;                 // uniform per (row) quad
+            const int gy2 = job.ty0 + t - 4 * R;
+            const int ny2 = window_count(gy2, R, job.cy0, job.cy1);
+            const double rny2 = s_rtab[ny2 > 2 * R + 1 ? 0 : ny2];
+            double ring[RING];
+#pragma unroll
+            for (int i = 0; i < RING; i++) ring[i] = 0.0;
+            const int x0 = hseg * L2;
+#pragma unroll
+            for (int s = 0; s < L2 + 2 * R; s++) {
+                const int xa = x0 + s;                                  // stage-1 column index
+                const float f = xa < WA ? s_T[hrow][xa * 4 + hk] : 0.0f;
+                const double C = ring[(s + RING - 1) % RING] + (double)f;
+                ring[s % RING] = C;
+                if (s >= 2 * R) {
+                    const int xo = x0 + s - 2 * R;                      // output column of the strip
+                    const double S2 = C - ring[(s + 1) % RING];
+                    const uint32_t ip = xo < TW ? s_ipk2[hrow][xo] : 0u;
+                    double term[4];
+                    quad_allgather(S2 * guide_centred_f64(ip, hk), term);
+                    if (hk == 0 && xo < TW && row_ok) {
+                        // LES/GuidedFilter.h:243: (b + a_r I_r + a_g I_g + a_b I_b) / N, then un-centre
+                        const int gx2 = job.tx0 + xo;
+                        const int nx2 = window_count(gx2, R, job.cx0, job.cx1);
+                        const double rn2 = rny2 * s_rtab[nx2 > 2 * R + 1 ? 0 : nx2];
+                        const double qn = ((term[3] + term[0]) + term[1]) + term[2];
+                        s_q[hrow][xo] = (float)(qn * rn2);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ===================== F: store =====================
+        for (int idx = tid; idx < BY * TW; idx += NT) {
+            const int i = idx / TW, xo = idx - i * TW;
+            const int t = t0 + i;
+            if (t >= 4 * R && t < Ttot && xo < job.tw) {
+                const int gy2 = job.ty0 + t - 4 * R, gx2 = job.tx0 + xo;
+                float q = s_q[i][xo];
+                if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx2, gy2)) q = LES_COST_INVALID;
+                out[job.out_off + (long long)(t - 4 * R) * job.out_stride + xo] = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Guide statistics (one-time per view): LES/GuidedFilter.h:58-102 in fp64, stored as fp32 AoS.
+// Pass 1: horizontal 2R+1 sums of the 9 moments (I_c, I_a I_b); pass 2: vertical sums + inverse.
+// ---------------------------------------------------------------------------------------------------
+__global__ void les_pack_guide_kernel(const uint8_t* __restrict__ bgr, uint32_t* __restrict__ ipk, int P)
+{
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < P) ipk[i] = (uint32_t)bgr[3 * (size_t)i] | ((uint32_t)bgr[3 * (size_t)i + 1] << 8) | ((uint32_t)bgr[3 * (size_t)i + 2] << 16);
+}
+
+__global__ void les_stats_hsum_kernel(const uint32_t* __restrict__ ipk, double* __restrict__ hs, int H, int W, int R)
+{
+    int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y;
+    if (x >= W) return;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dx = -R; dx <= R; dx++) {
+        int xx = x + dx;
+        if (xx < 0 || xx >= W) continue;
+        uint32_t v = ipk[(size_t)y * W + xx];
+        double I0 = (double)(v & 0xff) * (1.0 / 255), I1 = (double)((v >> 8) & 0xff) * (1.0 / 255),
+               I2 = (double)((v >> 16) & 0xff) * (1.0 / 255);
+        s[0] += I0; s[1] += I1; s[2] += I2;
+        s[3] += I0 * I0; s[4] += I0 * I1; s[5] += I0 * I2; s[6] += I1 * I1; s[7] += I1 * I2; s[8] += I2 * I2;
+    }
+    size_t P = (size_t)H * W;
+    for (int k = 0; k < 9; k++) hs[k * P + (size_t)y * W + x] = s[k];
+}
+
+__global__ void les_stats_finish_kernel(const double* __restrict__ hs, float4* __restrict__ stats, int H, int W, int R, double eps)
+{
+    int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y;
+    if (x >= W) return;
+    size_t P = (size_t)H * W;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dy = -R; dy <= R; dy++) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int k = 0; k < 9; k++) s[k] += hs[k * P + (size_t)yy * W + x];
+    }
+    double N = (double)(window_count(x, R, 0, W) * window_count(y, R, 0, H));     // :69
+    double m0 = s[0] / N, m1 = s[1] / N, m2 = s[2] / N;                             // :70-72
+    double rr = s[3] / N - m0 * m0 + eps, rg = s[4] / N - m0 * m1, rb = s[5] / N - m0 * m2;   // :79-84
+    double gg = s[6] / N - m1 * m1 + eps, gb = s[7] / N - m1 * m2, bb = s[8] / N - m2 * m2 + eps;
+    double irr = gg * bb - gb * gb, irg = gb * rb - rg * bb, irb = rg * gb - gg * rb;         // :87-92
+    double igg = rr * bb - rb * rb, igb = rb * rg - rr * gb, ibb = rr * gg - rg * rg;
+    double det = irr * rr + irg * rg + irb * rb;                                              // :94
+    irr /= det; irg /= det; irb /= det; igg /= det; igb /= det; ibb /= det;                   // :96-101
+    size_t px = (size_t)y * W + x;
+    stats[px * 3 + 0] = make_float4((float)(m0 - 0.5), (float)irr, (float)irg, (float)irb);
+    stats[px * 3 + 1] = make_float4((float)(m1 - 0.5), (float)irg, (float)igg, (float)igb);
+    stats[px * 3 + 2] = make_float4((float)(m2 - 0.5), (float)irb, (float)igb, (float)ibb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PatchMatch-style winner-take-all update (LES/FastGCStereo.h:56-60) for a batch of shared regions.
+// ---------------------------------------------------------------------------------------------------
+struct WtaJob { int x, y, w, h; };
+
+__global__ void les_wta_kernel(const WtaJob* __restrict__ jobs, const float4* __restrict__ planes,
+                               float* __restrict__ cur_cost, const float* __restrict__ prop_cost,
+                               float4* __restrict__ labels, int W)
+{
+    const WtaJob j = jobs[blockIdx.x];
+    const float4 pl = planes[blockIdx.x];
+    for (int idx = (int)threadIdx.x; idx < j.w * j.h; idx += (int)blockDim.x) {
+        int yy = idx / j.w, xx = idx - yy * j.w;
+        size_t k = (size_t)(j.y + yy) * W + j.x + xx;
+        float pc = prop_cost[k];
+        if (cur_cost[k] > pc) {                 // strict, as the reference
+            cur_cost[k] = pc;
+            labels[k] = pl;
+        }
+    }
+}
+
+}  // namespace les

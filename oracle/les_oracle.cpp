@@ -186,8 +186,10 @@ template <typename T>
 static void boxfilter(const T* src, T* dst, int rows, int cols, int R)
 {
     const int ksz = 2 * R + 1;
-    std::vector<double> rowsum((size_t)rows * cols);
-    std::vector<double> ext(cols + 2 * R);
+    // scratch is thread-local and reused across calls (allocation only, no effect on results)
+    static thread_local std::vector<double> rowsum, ext, SUM;
+    rowsum.resize((size_t)rows * cols);
+    ext.resize(cols + 2 * R);
     for (int y = 0; y < rows; y++) {
         for (int i = 0; i < R; i++) ext[i] = 0.0, ext[cols + R + i] = 0.0;
         for (int x = 0; x < cols; x++) ext[R + x] = (double)src[(size_t)y * cols + x];
@@ -200,7 +202,7 @@ static void boxfilter(const T* src, T* dst, int rows, int cols, int R)
             D[i + 1] = s;
         }
     }
-    std::vector<double> SUM(cols, 0.0);
+    SUM.assign(cols, 0.0);
     auto rowptr = [&](int y) -> const double* {   // rows outside [0,rows) are the zero border
         return (y < 0 || y >= rows) ? nullptr : &rowsum[(size_t)y * cols];
     };
@@ -284,9 +286,10 @@ struct GuideStats {
     {
         const int rows = rect.h, cols = rect.w;
         const size_t P = (size_t)rows * cols;
-        std::vector<T> Nloc(P), ones(P, (T)1);
+        // thread-local scratch reused across calls (allocation only, no effect on results)
+        static thread_local std::vector<T> Nloc, ones, p, mean_p, mIp[3], a[3], b, tmp, Ba[3], Bb;
+        Nloc.resize(P); ones.assign(P, (T)1); p.resize(P); mean_p.resize(P); b.resize(P); tmp.resize(P); Bb.resize(P);
         boxfilter(ones.data(), Nloc.data(), rows, cols, R);                          // :324
-        std::vector<T> p(P), mean_p(P), mIp[3], a[3], b(P), tmp(P);
         for (size_t i = 0; i < P; i++) p[i] = (T)p_in[i];                            // :251
         boxfilter(p.data(), mean_p.data(), rows, cols, R);                           // :145
         auto g = [&](const std::vector<T>& plane, int i, int j) -> T {               // ROI slice plane(rect)
@@ -314,7 +317,6 @@ struct GuideStats {
                 a[0][k] = ar; a[1][k] = ag; a[2][k] = ab;
                 b[k] = mp - ar * mIr - ag * mIg - ab * mIb;
             }
-        std::vector<T> Ba[3], Bb(P);
         for (int c = 0; c < 3; c++) { Ba[c].resize(P); boxfilter(a[c].data(), Ba[c].data(), rows, cols, R); }   // :224-226
         boxfilter(b.data(), Bb.data(), rows, cols, R);                                                           // :227
         for (int i = 0; i < rows; i++)                                               // :229-245
@@ -445,7 +447,8 @@ extern "C" void les_oracle_unary_nocheck(const les_oracle* o, int mode, les_rect
 {
     // LES/CostVolumeEnergy.h:55-174.  The Reusable scratch (pIL + sub-region filter, :57-62) is
     // recreated per call here; it only caches, it does not change results.
-    std::vector<float> pIL((size_t)fr.w * fr.h), q((size_t)fr.w * fr.h);
+    static thread_local std::vector<float> pIL, q;
+    pIL.resize((size_t)fr.w * fr.h); q.resize((size_t)fr.w * fr.h);
     les_oracle_gather(o, mode, fr, plane, pIL.data());
     les_oracle_filter_subregion(o, mode, fr, pIL.data(), q.data());                  // :171
     int sx = tr.x - fr.x, sy = tr.y - fr.y;                                          // :169 subrect = targetRect - filterRect.tl()
@@ -478,6 +481,23 @@ extern "C" void les_oracle_unary_batch(const les_oracle* o, int mode, int n, con
         float* origin = cost_map + (size_t)frs[i].y * o->W + frs[i].x;               // proposalCost(filterRect), LES/FastGCStereo.h:49
         if (check) les_oracle_unary(o, mode, frs[i], trs[i], origin, o->W, planes[i]);
         else       les_oracle_unary_nocheck(o, mode, frs[i], trs[i], origin, o->W, planes[i]);
+    }
+}
+
+extern "C" void les_oracle_aggregate_planes(const les_oracle* o, int mode, int n, const les_plane* planes,
+                                            float* out, int check, int nthreads)
+{
+    // whole-image aggregation of n hypothesis planes into out[n][H][W]: n calls of
+    // ComputeUnaryPotential with filterRect = targetRect = image, OpenMP over planes.
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const les_rect full = {0, 0, o->W, o->H};
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        float* slab = out + (size_t)i * o->H * o->W;
+        if (check) les_oracle_unary(o, mode, full, full, slab, o->W, planes[i]);
+        else       les_oracle_unary_nocheck(o, mode, full, full, slab, o->W, planes[i]);
     }
 }
 

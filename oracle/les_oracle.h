@@ -100,6 +100,10 @@ void les_oracle_unary_batch(const les_oracle* o, int mode, int n, const les_rect
                             const les_rect* targetRects, const les_plane* planes, float* cost_map,
                             int check, int nthreads);
 
+/* Whole-image aggregation of n hypothesis planes into out[n][H][W] (BASELINE.md H1/H2 workloads). */
+void les_oracle_aggregate_planes(const les_oracle* o, int mode, int n, const les_plane* planes, float* out,
+                                 int check, int nthreads);
+
 /* PatchMatch-style winner-take-all update, LES/FastGCStereo.h:56-60:
  * mask = cur > prop (strict); cur <- prop, label <- plane under mask, over rect (maps are H x W). */
 void les_oracle_wta_update(int W, les_rect rect, float* cur_cost, const float* prop_cost,

@@ -90,6 +90,7 @@ def lib():
         "les_oracle_unary_nocheck": (None, [vp, C.c_int, Rect, Rect, vp, C.c_int, Plane]),
         "les_oracle_unary": (None, [vp, C.c_int, Rect, Rect, vp, C.c_int, Plane]),
         "les_oracle_unary_batch": (None, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int]),
+        "les_oracle_aggregate_planes": (None, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]),
         "les_oracle_wta_update": (None, [C.c_int, Rect, vp, vp, vp, Plane]),
         "les_random_unit_vector": (None, [C.POINTER(Rng), C.c_double, dp]),
         "les_create_random_label": (Plane, [C.POINTER(Rng), C.c_float, C.c_float, C.c_int, C.c_int]),
@@ -113,6 +114,20 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def as_rects(r):
+    r = np.asarray(r)
+    if r.dtype != RECT_DT:
+        r = np.ascontiguousarray(r, np.int32).reshape(-1, 4).view(RECT_DT).reshape(-1)
+    return np.ascontiguousarray(r)
+
+
+def as_planes(p):
+    p = np.asarray(p)
+    if p.dtype != PLANE_DT:
+        p = np.ascontiguousarray(p, np.float32).reshape(-1, 4).view(PLANE_DT).reshape(-1)
+    return np.ascontiguousarray(p)
 
 
 class Layer:
@@ -196,12 +211,17 @@ class Oracle:
         f(self.h, mode, fr, tr, C.c_void_p(origin), self.W, Plane(*plane))
         return cost_map
 
+    def aggregate_planes(self, planes, mode=0, check=False, nthreads=0):
+        planes = as_planes(planes)
+        out = np.empty((len(planes), self.H, self.W), np.float32)
+        self.L.les_oracle_aggregate_planes(self.h, mode, len(planes), _ptr(planes), _ptr(out), int(check), nthreads)
+        return out
+
     def unary_batch(self, frs, trs, planes, cost_map=None, mode=0, check=True, nthreads=0):
         if cost_map is None:
             cost_map = np.full((self.H, self.W), np.nan, np.float32)
-        frs = np.ascontiguousarray(frs, RECT_DT)
-        trs = np.ascontiguousarray(trs, RECT_DT)
-        planes = np.ascontiguousarray(planes, PLANE_DT)
+        frs, trs, planes = as_rects(frs), as_rects(trs), as_planes(planes)
+        assert len(frs) == len(trs) == len(planes)
         self.L.les_oracle_unary_batch(self.h, mode, len(frs), _ptr(frs), _ptr(trs), _ptr(planes), _ptr(cost_map),
                                       int(check), nthreads)
         return cost_map

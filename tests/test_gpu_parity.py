@@ -1,0 +1,163 @@
+"""Parity of the gfx950 build against the CPU oracle, through the C ABI (-m gpu, needs an MI355X).
+
+Small/medium sizes: direct comparison with the oracle on seeded inputs and with the committed golden
+fixture.  BASELINE full size (1500x1000, ndisp 256 volume is not needed for these properties; a 24-slice
+volume keeps the host side light): size-independent properties + sampled oracle cells."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cones(oracle_mod):
+    pr = pc.cones_pair(None)
+    yield pr
+    pr.close()
+
+
+@pytest.fixture(scope="module")
+def mid(oracle_mod):
+    pr = pc.synth_pair(None, 375, 450, 64)          # BASELINE config 1 shape (cones 450x375, ndisp 64)
+    yield pr
+    pr.close()
+
+
+def test_native_library_loaded(cones):
+    maps = open("/proc/self/maps").read()
+    assert "liblocalexp_hip.so" in maps
+
+
+def test_gpu_stats(cones):
+    pc.case_stats(cones)
+
+
+def test_gpu_single_calls(cones):
+    assert pc.case_single_calls(cones) <= pc.TIGHT
+
+
+def test_gpu_special_planes(cones):
+    pc.case_special_planes(cones)
+
+
+def test_gpu_golden_fixture(cones):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_unary.npz"))
+    for i in range(int(g["n"])):
+        fr, tr = tuple(int(v) for v in g[f"fr{i}"]), tuple(int(v) for v in g[f"tr{i}"])
+        got = cones.e.ComputeUnaryPotential(fr, tr, np.full((cones.H, cones.W), np.nan, np.float32),
+                                            tuple(float(v) for v in g[f"plane{i}"]), mode=int(g[f"mode{i}"]))
+        x, y, w, h = tr
+        ref = np.full((cones.H, cones.W), np.nan, np.float32)
+        ref[y:y + h, x:x + w] = g[f"out{i}"]
+        pc.compare_maps(got, ref)
+
+
+def test_gpu_cell_batches_all_layers(mid):
+    for unit, sets in ((5, (0, 9)), (15, (0, 5, 15)), (25, (0, 7))):      # MiddV2 layers, LES/main.cpp:300-306
+        for mode in (0, 1):
+            pc.case_cell_batches(mid, unit=unit, sets=sets, mode=mode)
+
+
+def test_gpu_init_cells(mid):
+    pc.case_init_cells(mid, unit=5)
+
+
+def test_gpu_plane_slabs(mid):
+    pc.case_plane_slabs(mid, n=6, mode=0)
+
+
+def test_gpu_empty_and_errors(cones):
+    pc.case_empty_and_errors(cones)
+
+
+def test_gpu_wta(mid):
+    pc.case_wta(mid)
+
+
+def test_gpu_other_radii(oracle_mod):
+    for windR, eps, th in ((4, 1e-3, 0.8), (10, 1e-4, 0.5), (16, 1e-5, 1.5)):
+        pr = pc.synth_pair(None, 90, 130, 10, windR=windR, eps=eps, th_col=th)
+        try:
+            layer = pc.om.Layer(pr.W, pr.H, windR, 11)
+            for s in (0, 6):
+                cells = layer.sets[s]
+                planes = pc.random_planes(len(cells), pr.D, pr.H, pr.W, 4 + s)
+                ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+                got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+                pc.compare_maps(got, ref)
+        finally:
+            pr.close()
+
+
+def test_gpu_repeatable(mid):
+    """Same inputs -> bit-identical outputs (no atomics / order dependence)."""
+    layer = pc.om.Layer(mid.W, mid.H, 20, 15)
+    cells = layer.sets[2]
+    planes = pc.random_planes(len(cells), mid.D, mid.H, mid.W, 77)
+    a = mid.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+    b = mid.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+    assert a.tobytes() == b.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE full image size (1500 x 1000): size-independent properties + sampled oracle cells
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full(oracle_mod):
+    pr = pc.synth_pair(None, 1000, 1500, 24)
+    yield pr
+    pr.close()
+
+
+def test_full_size_constant_volume_is_fixed_point():
+    """vol == k  =>  aggregated cost == min(k, th) for every plane and pixel (guided filter of a
+    constant is that constant: LES/GuidedFilter.h:212-220,243)."""
+    from localexpstereo_amd import api, synth
+    H, W, D = 1000, 1500, 8
+    im = synth.make_guide(H, W, 1234)
+    vol = np.full((D, H, W), 0.3125, np.float32)
+    e = api.HipCostVolumeEnergy(im, None, vol, None)
+    pr = type("P", (), {"e": e, "H": H, "W": W, "D": D})()
+    planes = np.array([[0, 0, 3, 0], [0.002, -0.001, 3.3, 0], [0, 0, 100, 0]], np.float32)
+    out = pc.run_slabs(pr, planes)
+    assert np.max(np.abs(out - 0.3125)) <= 3e-7
+    e.close()
+
+
+def test_full_size_cells_equal_whole_image_and_oracle(full):
+    """(a) cell-batched results == the same plane aggregated over the whole image (sub-region filter
+    exactness, LES/GuidedFilter.h:298-300), for all cells of one disjoint set of every layer of the
+    1500x1000 geometry; (b) sampled cells against the oracle."""
+    pr = full
+    plane = np.array([[0.004, -0.006, 9.25, 0.0]], np.float32)
+    whole = pc.run_slabs(pr, plane, check=True)[0]
+    for unit in (15, 45, 135):                                           # LES/main.cpp:395-397 at w = 1500
+        layer = pc.om.Layer(pr.W, pr.H, 20, unit)
+        cells = layer.sets[len(layer.sets) // 2]
+        planes = np.repeat(plane, len(cells), axis=0)
+        got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, check=True)
+        m = ~np.isnan(got)
+        assert m.sum() == int(sum(int(r["w"]) * int(r["h"]) for r in layer.shared[cells]))
+        assert np.max(np.abs(got[m] - whole[m])) <= 3e-7
+        pick = cells[:: max(1, len(cells) // 6)]
+        ref = pr.o.unary_batch(layer.filter[pick], layer.shared[pick], np.repeat(plane, len(pick), axis=0), check=True)
+        mm = ~np.isnan(ref)
+        pc.compare_maps(np.where(mm, got, np.nan).astype(np.float32), ref)
+
+
+def test_full_size_linearity_in_cost(full):
+    """Below the truncation threshold the operator is linear in the volume: planes c=k and c=k+1 and
+    the half-way plane c=k+0.5 satisfy q(k+.5) = (q(k)+q(k+1))/2."""
+    pr = full
+    planes = np.array([[0, 0, 4, 0], [0, 0, 5, 0], [0, 0, 4.5, 0]], np.float32)
+    # costs U[0,1) truncated at 0.5 are not linear; use a context with a high threshold
+    from localexpstereo_amd import api, synth
+    e = api.HipCostVolumeEnergy(synth.make_guide(pr.H, pr.W, 1234), None, synth.make_volume(8, pr.H, pr.W, 42), None, th_col=10.0)
+    p2 = type("P", (), {"e": e, "H": pr.H, "W": pr.W, "D": 8})()
+    out = pc.run_slabs(p2, planes)
+    assert np.max(np.abs(out[2] - 0.5 * (out[0] + out[1]))) <= 5e-7
+    e.close()
