@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,20 +38,32 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 // ---- kernel configurations compiled into this build: guided-filter radius -> strip geometry
-constexpr int kWA = 64;     // stage-1 columns per workgroup (NT = 256 threads)
-constexpr int kBY = 16;     // rows per block
 typedef void (*StripKernel)(les::Geom, les::View, const les::Job*, const float4*, float*, int, int);
-struct StripEntry { int R; int TW; int NT; StripKernel fn; };
+struct StripEntry { int R; int variant; int TW; int NT; StripKernel fn; };
 
-#define LES_STRIP_ENTRY(R_) { R_, les::StripCfg<R_, kWA, kBY>::TW, les::StripCfg<R_, kWA, kBY>::NT, les::les_strip_kernel<R_, kWA, kBY> }
+// (radius, stage-1 columns WA, rows per block BY, H-phase segments SEG, min waves/SIMD MW); variant 0 is
+// the default of a radius, the others are selectable with LES_HIP_VARIANT for A/B measurements.
+#define LES_STRIP_ENTRY(R_, V_, WA_, BY_, SEG_, MW_) \
+    { R_, V_, les::StripCfg<R_, WA_, BY_, SEG_>::TW, les::StripCfg<R_, WA_, BY_, SEG_>::NT, les::les_strip_kernel<R_, WA_, BY_, SEG_, MW_> }
 const StripEntry kStrips[] = {
-    LES_STRIP_ENTRY(1), LES_STRIP_ENTRY(2), LES_STRIP_ENTRY(3), LES_STRIP_ENTRY(5), LES_STRIP_ENTRY(8), LES_STRIP_ENTRY(10),
+    // default per radius: no register spills at 2 waves/SIMD measured faster than 3-4 waves with spills
+    LES_STRIP_ENTRY(1, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(2, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(3, 0, 64, 16, 4, 2),
+    LES_STRIP_ENTRY(5, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(8, 0, 64, 16, 4, 2),
+    LES_STRIP_ENTRY(10, 0, 128, 16, 8, 2),
+    // A/B variants for radius 10 (LES_HIP_VARIANT=n)
+    LES_STRIP_ENTRY(10, 1, 64, 16, 4, 2), LES_STRIP_ENTRY(10, 2, 128, 16, 8, 3), LES_STRIP_ENTRY(10, 3, 128, 16, 4, 2),
 };
 const StripEntry* find_strip(int R)
 {
-    for (const auto& e : kStrips)
-        if (e.R == R) return &e;
-    return nullptr;
+    int variant = 0;
+    if (const char* v = getenv("LES_HIP_VARIANT")) variant = atoi(v);
+    const StripEntry* def = nullptr;
+    for (const auto& e : kStrips) {
+        if (e.R != R) continue;
+        if (e.variant == variant) return &e;
+        if (e.variant == 0) def = &e;
+    }
+    return def;
 }
 
 struct ViewData {
@@ -210,6 +223,7 @@ int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_
     *out = nullptr;
     const les_hip_params& p = *params;
     if (p.H <= 0 || p.W <= 0 || p.D <= 0 || p.windR < 2) return fail(LES_HIP_ERR_ARG, "bad dimensions");
+    if ((unsigned long long)p.H * p.W * p.D >= (1ull << 32)) return fail(LES_HIP_ERR_UNSUPPORTED, "volumes of 2^32 or more floats are not supported (32-bit element offsets)");
     const StripEntry* strip = find_strip(p.windR / 2);
     if (!strip) return fail(LES_HIP_ERR_UNSUPPORTED, "no kernel instantiated for guided-filter radius %d (windR %d)", p.windR / 2, p.windR);
     int ndev = 0;

@@ -32,6 +32,8 @@
 
 #include "les_simt.h"
 
+#include <utility>
+
 namespace les {
 
 struct Geom {
@@ -86,6 +88,42 @@ __device__ __forceinline__ float gather_cost(const Geom& g, const float* __restr
     return (g.th_col < C) ? g.th_col : C;       // std::min(C, th_col), NaN-propagating like the reference
 }
 
+// The same computation split into an address phase and an arithmetic phase so that a thread can put
+// the loads of several pixels in flight before it needs any of them (branch-free, bit-identical).
+// Element offsets are 32-bit (the context refuses volumes of 2^32 or more floats).
+struct GatherPrep {
+    uint32_t i0, i1;    // element offsets of the two volume taps (i1 == i0 when only one tap is used)
+    float f1;           // lerp weight of the second tap
+    int mode;           // 0: C = f0*v0 + f1*v1   1: C = v0 (clamped)   2: C = COST_FOR_INVALID   3: outside clip -> p = 0
+};
+// ax = a * x and d_base = b * y + c are the reference's own sub-expressions (LES/CostVolumeEnergy.h:73,76)
+__device__ __forceinline__ GatherPrep gather_prepare(const Geom& g, float ax, float d_base, uint32_t px, uint32_t HW, bool inside)
+{
+    GatherPrep r;
+    const float d = ax + d_base;
+    const bool lo = d < g.mind, hi = d >= g.maxd;
+    const bool mid = !(lo || hi || d != d);
+    // (int)d is only meaningful on the `mid` path; substitute 0 so the conversion is always defined
+    const float dsafe = mid ? d : 0.0f;
+    const int d0 = (int)dsafe + g.D0;
+    const bool ok = mid && d0 >= 0 && d0 + 1 < g.D;
+    r.f1 = dsafe - floorf(dsafe);
+    const uint32_t s0 = lo ? 0u : (hi ? (uint32_t)(g.D - 1) : (ok ? (uint32_t)d0 : 0u));
+    r.i0 = s0 * HW + px;
+    r.i1 = ok ? r.i0 + HW : r.i0;
+    r.mode = !inside ? 3 : ((lo || hi) ? 1 : (ok ? 0 : 2));
+    return r;
+}
+__device__ __forceinline__ float gather_finish(const Geom& g, const GatherPrep& r, float v0, float v1)
+{
+    const float f0 = 1.0f - r.f1;
+    float C = f0 * v0 + r.f1 * v1;
+    C = r.mode == 1 ? v0 : C;
+    C = r.mode == 2 ? LES_COST_INVALID : C;
+    const float p = (g.th_col < C) ? g.th_col : C;
+    return r.mode == 3 ? 0.0f : p;
+}
+
 // LES/StereoEnergy.h:560-610
 __device__ __forceinline__ bool label_valid(const Geom& g, float a, float b, float c, float v, int gx, int gy)
 {
@@ -121,102 +159,93 @@ __device__ __forceinline__ int window_count(int c, int R, int lo, int hi)
     return b > a ? b - a : 0;
 }
 
-// compile-time slot dispatch (binary search over [LO,HI]); `slot` is wave-uniform
-template <int LO, int HI>
-struct SlotDispatch {
-    template <typename F>
-    __device__ __forceinline__ static void run(int slot, F& f)
-    {
-        if constexpr (LO == HI) {
-            f.template step<LO>();
-        } else {
-            constexpr int MID = (LO + HI) / 2;
-            if (slot <= MID) SlotDispatch<LO, MID>::run(slot, f);
-            else SlotDispatch<MID + 1, HI>::run(slot, f);
-        }
-    }
-};
+template <int V>
+struct IntTag { static constexpr int value = V; };
+
+// compile-time loop: f(IntTag<0>{}), ..., f(IntTag<N-1>{})
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f)
+{
+    (f(IntTag<Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // ---------------------------------------------------------------------------------------------------
-// Vertical phase state of one (column, quantity) lane.
+// Vertical phase state of one (column, quantity) lane.  The window sums are exact running sums in
+// fp64 of fp32 inputs: S += in - out, with the last RS >= 2R+1 inputs held in a statically indexed
+// register ring (slot = row mod RS, RS a multiple of the block height so slots are compile-time).
 // ---------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, int RS>
 struct VLane {
-    static constexpr int RING = 2 * R + 2;
-    double ring1[RING] = {};
-    double ring2[RING] = {};
-    // per-row inputs / outputs
-    float in;            // H1 sum of this lane's quantity for the incoming p-row
-    float out;           // vertical stage-2 sum (centred R rows above the stage-1 row)
-    bool do_algebra;     // wave-uniform: t >= 2R
-    bool in_clip;        // stage-1 pixel inside the clip rect
-    int k;               // quantity: 0..2 -> I'_k p' / a_k, 3 -> p' / b
-    double rn1;          // 1 / N of the stage-1 pixel
-    const float4* st;    // statistics of the stage-1 pixel, valid when in_clip && k < 3
+    static constexpr int KS = 2 * R + 1;
+    static_assert(RS >= KS, "ring shorter than the window");
+    float ring1[RS] = {};
+    float ring2[RS] = {};
+    double S1 = 0.0, S2 = 0.0;
+    int k;               // quantity: 0..2 -> I'_k p / a_k, 3 -> p / b
 
+    // One row.  S = row index mod RS (compile time): the ring keeps the last RS inputs, the one that
+    // leaves the 2R+1 window is the input of KS rows ago.
+    //   in  : H1 sum of this lane's quantity for the incoming p-row
+    //   rn1 : 1/N of the stage-1 pixel;  st: its statistics {mean_I'_k, inv[k][0..2]} (used when in_clip && k < 3)
+    // returns the vertical stage-2 sum (centred R rows above the stage-1 row)
     template <int S>
-    __device__ __forceinline__ void step()
+    __device__ __forceinline__ float step(float in, bool do_algebra, bool in_clip, double rn1, float4 st)
     {
-        constexpr int PREV = (S + RING - 1) % RING, OLD = (S + 1) % RING;
-        double C1 = ring1[PREV] + (double)in;
-        ring1[S] = C1;
-        double S1 = C1 - ring1[OLD];                       // sum over the last 2R+1 p-rows
+        constexpr int OLD = (S + RS - KS) % RS;
+        S1 += (double)in - (double)ring1[OLD];             // sum over the last 2R+1 p-rows
+        ring1[S] = in;
         float val = 0.0f;
         if (do_algebra) {
-            // LES/GuidedFilter.h:204-221 on centred quantities
-            double m = S1 * rn1;                           // lane k<3: mean(I'_k p'), lane 3: mean(p')
-            double mq[4];
-            quad_allgather(m, mq);
+            // LES/GuidedFilter.h:204-221 on the centred guide
+            const double m = S1 * rn1;                     // lane k<3: mean(I'_k p), lane 3: mean(p)
+            const double mp = quad_bcast<3>(m);
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in_clip && k < 3) s = *st;
-            double cov = m - (double)s.x * mq[3];          // cov_k = mean(I'_k p') - mean_I'_k * mean_p'
-            float cv[4];
-            quad_allgather((float)cov, cv);
-            float ak = s.y * cv[0] + s.z * cv[1] + s.w * cv[2];
-            float tk = ak * s.x;
-            float tt[4];
-            quad_allgather(tk, tt);
-            float bb = (float)mq[3] - tt[0] - tt[1] - tt[2];
+            if (in_clip && k < 3) s = st;
+            const float cov = (float)(m - (double)s.x * mp);   // cov_k = mean(I'_k p) - mean_I'_k * mean_p
+            const float ak = s.y * quad_bcast<0>(cov) + s.z * quad_bcast<1>(cov) + s.w * quad_bcast<2>(cov);
+            const float tk = ak * s.x;
+            const float bb = (float)mp - quad_bcast<0>(tk) - quad_bcast<1>(tk) - quad_bcast<2>(tk);
             val = (k < 3) ? ak : bb;
             if (!in_clip) val = 0.0f;                      // a, b are zero-padded outside the sub-region
         }
-        double C2 = ring2[PREV] + (double)val;
-        ring2[S] = C2;
-        out = (float)(C2 - ring2[OLD]);                    // sum over the last 2R+1 stage-1 rows
-#if !defined(LES_SIM)
-        // Keeps the RING instantiations distinct up to their last instruction: otherwise the optimiser
-        // sinks the common tail of the dispatch leaves into one block with a run-time ring index,
-        // which forces both rings out of registers into scratch memory.
-        asm volatile("" ::"n"(S));
-#endif
+        S2 += (double)val - (double)ring2[OLD];            // sum over the last 2R+1 stage-1 rows
+        ring2[S] = val;
+        return (float)S2;
     }
 };
 
 // ---------------------------------------------------------------------------------------------------
-// The fused strip kernel.   NT = 4*WA threads; TW = WA-2R output columns per strip.
+// The fused strip kernel.   NT = 4*WA threads; TW = WA-2R output columns per strip; the H phases use
+// 4*BY*SEG lanes (row, quantity, segment).
 // ---------------------------------------------------------------------------------------------------
-template <int R, int WA, int BY>
+template <int R, int WA, int BY, int SEG>
 struct StripCfg {
     static constexpr int TW = WA - 2 * R;
     static constexpr int WP = WA + 2 * R;
     static constexpr int NT = 4 * WA;
-    static constexpr int SEG = NT / (4 * BY);              // segments per (row, quantity)
-    static constexpr int L1 = WA / SEG;                    // H1 outputs per segment
+    static constexpr int HL = 4 * BY * SEG;                // lanes active in the H phases
+    static constexpr int L1 = (WA + SEG - 1) / SEG;        // H1 outputs per segment
     static constexpr int L2 = (TW + SEG - 1) / SEG;        // H2 outputs per segment
     static constexpr int TPITCH = WA * 4 + 4;              // floats per T row (+4: bank spread across rows)
-    static constexpr int RING = 2 * R + 2;
-    static_assert(NT % (4 * BY) == 0 && WA % SEG == 0, "bad strip configuration");
+    static constexpr int KS = 2 * R + 1;
+    static constexpr int RS = ((KS + BY - 1) / BY) * BY;   // V ring length: multiple of BY, so a block's rows hit static slots
+    static_assert(HL <= NT, "more H lanes than threads");
     static_assert(TW > 0, "strip too narrow for this radius");
 };
 
-template <int R, int WA, int BY>
-__global__ void __launch_bounds__(4 * WA)
+template <int R, int WA, int BY, int SEG, int MW>
+__global__ void __launch_bounds__(4 * WA, MW)
 les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
                  float* __restrict__ out, int njobs, int check)
 {
-    using Cfg = StripCfg<R, WA, BY>;
-    constexpr int TW = Cfg::TW, WP = Cfg::WP, NT = Cfg::NT, SEG = Cfg::SEG, L1 = Cfg::L1, L2 = Cfg::L2;
-    constexpr int TPITCH = Cfg::TPITCH, RING = Cfg::RING;
+    using Cfg = StripCfg<R, WA, BY, SEG>;
+    constexpr int TW = Cfg::TW, WP = Cfg::WP, NT = Cfg::NT, HL = Cfg::HL, L1 = Cfg::L1, L2 = Cfg::L2;
+    constexpr int TPITCH = Cfg::TPITCH, KS = Cfg::KS, RS = Cfg::RS;
 
     __shared__ float s_p[BY][WP];            // truncated cost p (0 outside the clip)
     __shared__ uint32_t s_ipk[BY][WP];       // packed guide pixel of the same p-rows
@@ -243,106 +272,165 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 
     // ---- V-phase identity: lane quad = 4 quantities of stage-1 column vx
     const int vx = tid >> 2, vk = tid & 3;
-    VLane<R> vl;
+    VLane<R, RS> vl;
     vl.k = vk;
     const int gx1 = job.tx0 - R + vx;                                   // stage-1 column (image coords)
     const bool col_in_clip = gx1 >= job.cx0 && gx1 < job.cx1;
     const int nx1 = window_count(gx1, R, job.cx0, job.cx1);
 
     // ---- H-phase identity: (segment, row, quantity); lanes of a wave differ in row first
+    const bool h_active = tid < HL;
     const int hk = tid & 3, hrow = (tid >> 2) % BY, hseg = (tid >> 2) / BY;
 
     __syncthreads();
-    const double rnx1 = s_rtab[nx1 > 2 * R + 1 ? 0 : nx1];
+    const double rnx1 = s_rtab[nx1];
+
+    // ---- G-phase identity: a lane keeps one p column (and one output column) for the whole job
+    constexpr int GRP = NT / WP, GPASS = (BY + GRP - 1) / GRP;          // rows per pass, passes per block
+    constexpr int ORP = NT / TW, OPASS = (BY + ORP - 1) / ORP;
+    const int g_ri = tid / WP, g_xi = tid - g_ri * WP;
+    const bool g_lane = tid < GRP * WP;
+    const int g_gx = job.tx0 - 2 * R + g_xi;
+    const bool g_col_in = g_gx >= job.cx0 && g_gx < job.cx1;
+    const int g_sx = min(max(g_gx, job.cx0), job.cx1 - 1);
+    const float g_ax = plane.x * (float)g_sx;                           // a * x, LES/CostVolumeEnergy.h:76
+    const int o_ri = tid / TW, o_xo = tid - o_ri * TW;
+    const bool o_lane = tid < ORP * TW;
+    const int o_sx = min(max(job.tx0 + o_xo, job.cx0), job.cx1 - 1);
+    const uint32_t HWu = (uint32_t)g.H * (uint32_t)g.W;
+
+    // Guide statistics of the stage-1 pixels are prefetched PD rows ahead into registers (the pipeline
+    // runs across block boundaries), so their L2/HBM latency never sits on the V-phase critical path.
+    constexpr int PD = 4;
+    static_assert(BY % PD == 0, "prefetch distance must divide the block height");
+    const int sgx1 = min(max(gx1, job.cx0), job.cx1 - 1);
+    const float4* st_col = view.stats + (size_t)sgx1 * 3 + (vk < 3 ? vk : 0);
+    const size_t st_stride = (size_t)g.W * 3;
+    auto stats_row = [&](int t) -> float4 {
+        const int gy1 = min(max(job.ty0 - 3 * R + t, job.cy0), job.cy1 - 1);
+        return st_col[(size_t)gy1 * st_stride];
+    };
+    float4 pre[PD];
+#pragma unroll
+    for (int j = 0; j < PD; j++) pre[j] = stats_row(j);
 
     for (int t0 = 0; t0 < Ttot; t0 += BY) {
         // ===================== G: gather =====================
-        for (int idx = tid; idx < BY * WP; idx += NT) {
-            const int i = idx / WP, xi = idx - i * WP;
-            const int t = t0 + i;
-            const int gy = job.ty0 - 2 * R + t, gx = job.tx0 - 2 * R + xi;
-            float pc = 0.0f;
-            uint32_t ip = 0;
-            if (t < Ttot && gx >= job.cx0 && gx < job.cx1 && gy >= job.cy0 && gy < job.cy1) {
-                pc = gather_cost(g, view.vol, plane.x, plane.y, plane.z, gx, gy);
-                ip = view.ipk[(size_t)gy * g.W + gx];
+        // A lane keeps its column for the whole job (column terms hoisted out of the march); all loads
+        // of a block are issued before any is consumed (memory-level parallelism).
+        {
+            GatherPrep gp[GPASS];
+            float v0[GPASS], v1[GPASS];
+            uint32_t ipa[GPASS], ipo[OPASS];
+#pragma unroll
+            for (int j = 0; j < GPASS; j++) {
+                const int i = j * GRP + g_ri;
+                const int t = t0 + i;
+                const int gy = job.ty0 - 2 * R + t;
+                const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
+                const int sy = min(max(gy, job.cy0), job.cy1 - 1);
+                const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
+                const float d_base = plane.y * (float)sy + plane.z;
+                gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
+                v0[j] = view.vol[gp[j].i0];
+                v1[j] = view.vol[gp[j].i1];
+                ipa[j] = view.ipk[px];
             }
-            s_p[i][xi] = pc;
-            s_ipk[i][xi] = ip;
-        }
-        for (int idx = tid; idx < BY * TW; idx += NT) {
-            const int i = idx / TW, xo = idx - i * TW;
-            const int t = t0 + i;
-            const int gy2 = job.ty0 + t - 4 * R, gx2 = job.tx0 + xo;
-            uint32_t ip = 0;
-            if (t >= 4 * R && t < Ttot && xo < job.tw) ip = view.ipk[(size_t)gy2 * g.W + gx2];
-            s_ipk2[i][xo] = ip;
+#pragma unroll
+            for (int j = 0; j < OPASS; j++) {
+                const int i = j * ORP + o_ri;
+                const int sy = min(max(job.ty0 + t0 + i - 4 * R, job.cy0), job.cy1 - 1);
+                ipo[j] = view.ipk[(uint32_t)sy * (uint32_t)g.W + (uint32_t)o_sx];
+            }
+#pragma unroll
+            for (int j = 0; j < GPASS; j++) {
+                const int i = j * GRP + g_ri;
+                if (g_lane && i < BY) {
+                    s_p[i][g_xi] = gather_finish(g, gp[j], v0[j], v1[j]);
+                    s_ipk[i][g_xi] = ipa[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < OPASS; j++) {
+                const int i = j * ORP + o_ri;
+                if (o_lane && i < BY) s_ipk2[i][o_xo] = ipo[j];
+            }
         }
         __syncthreads();
 
-        // ===================== H1: horizontal sums of F_k = I'_k p' =====================
-        {
-            double ring[RING];
+        // ===================== H1: horizontal sums of F_k = I'_k p =====================
+        if (h_active) {
+            float ring[KS];
 #pragma unroll
-            for (int i = 0; i < RING; i++) ring[i] = 0.0;
+            for (int i = 0; i < KS; i++) ring[i] = 0.0f;
+            double S = 0.0;
             const int x0 = hseg * L1;
 #pragma unroll
             for (int s = 0; s < L1 + 2 * R; s++) {
-                const int xi = x0 + s;                                  // p column index, < WP by construction
-                const float f = guide_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi];
-                const double C = ring[(s + RING - 1) % RING] + (double)f;
-                ring[s % RING] = C;
-                if (s >= 2 * R) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)(C - ring[(s + 1) % RING]);
+                const int xi = x0 + s;                                  // p column index
+                const float f = xi < WP ? guide_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi] : 0.0f;
+                S += (double)f - (double)ring[s % KS];
+                ring[s % KS] = f;
+                if (s >= 2 * R && x0 + s - 2 * R < WA) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)S;
             }
         }
         __syncthreads();
 
         // ===================== V: vertical sums, algebra, vertical sums =====================
-        for (int i = 0; i < BY; i++) {
-            const int t = t0 + i;
-            if (t >= Ttot) break;
-            const int gy1 = job.ty0 - 3 * R + t;                        // stage-1 row
-            vl.in = s_T[i][vx * 4 + vk];
-            vl.do_algebra = t >= 2 * R;
-            const bool row_in_clip = gy1 >= job.cy0 && gy1 < job.cy1;
-            vl.in_clip = col_in_clip && row_in_clip;
-            const int ny1 = window_count(gy1, R, job.cy0, job.cy1);
-            vl.rn1 = rnx1 * s_rtab[ny1 > 2 * R + 1 ? 0 : ny1];
-            vl.st = view.stats + ((size_t)(vl.in_clip ? gy1 : 0) * g.W + (vl.in_clip ? gx1 : 0)) * 3 + (vk < 3 ? vk : 0);
-            SlotDispatch<0, RING - 1>::run(t % RING, vl);
-            s_T[i][vx * 4 + vk] = vl.out;
+        // Rows of a block map to compile-time ring slots: slot = (t0 % RS) + i, and t0 % RS takes only
+        // RS/BY distinct values, so the whole block is straight-line code selected by one uniform branch.
+        {
+            const float* trow = &s_T[0][vx * 4 + vk];
+            auto vblock = [&](auto base_tag) {
+                constexpr int BASE = decltype(base_tag)::value;
+                static_for<BY>([&](auto itag) {
+                    constexpr int i = decltype(itag)::value;
+                    const int t = t0 + i;
+                    const int gy1 = job.ty0 - 3 * R + t;                // stage-1 row
+                    const bool in_clip = col_in_clip && gy1 >= job.cy0 && gy1 < job.cy1;
+                    const double rn1 = rnx1 * s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+                    const float o = vl.template step<BASE + i>(trow[i * TPITCH], t >= 2 * R, in_clip, rn1, pre[i % PD]);
+                    pre[i % PD] = stats_row(t + PD);
+                    s_T[i][vx * 4 + vk] = o;
+                });
+            };
+            const int base = t0 % RS;
+            if constexpr (RS / BY == 1) vblock(IntTag<0>{});
+            else if constexpr (RS / BY == 2) { if (base == 0) vblock(IntTag<0>{}); else vblock(IntTag<BY>{}); }
+            else if constexpr (RS / BY == 3) { if (base == 0) vblock(IntTag<0>{}); else if (base == BY) vblock(IntTag<BY>{}); else vblock(IntTag<2 * BY>{}); }
+            else {
+                static_assert(RS / BY == 4, "unsupported ring/block ratio");
+                if (base == 0) vblock(IntTag<0>{}); else if (base == BY) vblock(IntTag<BY>{});
+                else if (base == 2 * BY) vblock(IntTag<2 * BY>{}); else vblock(IntTag<3 * BY>{});
+            }
         }
         __syncthreads();
 
         // ===================== H2: horizontal sums + guide weighting + quad reduction =====================
-        {
+        if (h_active) {
             const int t = t0 + hrow;
             const bool row_ok = t >= 4 * R && t < Ttot;                 // uniform per (row) quad
             const int gy2 = job.ty0 + t - 4 * R;
-            const int ny2 = window_count(gy2, R, job.cy0, job.cy1);
-            const double rny2 = s_rtab[ny2 > 2 * R + 1 ? 0 : ny2];
-            double ring[RING];
+            const double rny2 = s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
+            float ring[KS];
 #pragma unroll
-            for (int i = 0; i < RING; i++) ring[i] = 0.0;
+            for (int i = 0; i < KS; i++) ring[i] = 0.0f;
+            double S = 0.0;
             const int x0 = hseg * L2;
 #pragma unroll
             for (int s = 0; s < L2 + 2 * R; s++) {
                 const int xa = x0 + s;                                  // stage-1 column index
                 const float f = xa < WA ? s_T[hrow][xa * 4 + hk] : 0.0f;
-                const double C = ring[(s + RING - 1) % RING] + (double)f;
-                ring[s % RING] = C;
+                S += (double)f - (double)ring[s % KS];
+                ring[s % KS] = f;
                 if (s >= 2 * R) {
                     const int xo = x0 + s - 2 * R;                      // output column of the strip
-                    const double S2 = C - ring[(s + 1) % RING];
                     const uint32_t ip = xo < TW ? s_ipk2[hrow][xo] : 0u;
-                    double term[4];
-                    quad_allgather(S2 * guide_centred_f64(ip, hk), term);
+                    // LES/GuidedFilter.h:243: (b + a_r I_r + a_g I_g + a_b I_b) / N
+                    const double qn = quad_sum(S * guide_centred_f64(ip, hk));
                     if (hk == 0 && xo < TW && row_ok) {
-                        // LES/GuidedFilter.h:243: (b + a_r I_r + a_g I_g + a_b I_b) / N, then un-centre
                         const int gx2 = job.tx0 + xo;
-                        const int nx2 = window_count(gx2, R, job.cx0, job.cx1);
-                        const double rn2 = rny2 * s_rtab[nx2 > 2 * R + 1 ? 0 : nx2];
-                        const double qn = ((term[3] + term[0]) + term[1]) + term[2];
+                        const double rn2 = rny2 * s_rtab[window_count(gx2, R, job.cx0, job.cx1)];
                         s_q[hrow][xo] = (float)(qn * rn2);
                     }
                 }

@@ -124,7 +124,7 @@ def test_full_size_constant_volume_is_fixed_point():
     pr = type("P", (), {"e": e, "H": H, "W": W, "D": D})()
     planes = np.array([[0, 0, 3, 0], [0.002, -0.001, 3.3, 0], [0, 0, 100, 0]], np.float32)
     out = pc.run_slabs(pr, planes)
-    assert np.max(np.abs(out - 0.3125)) <= 3e-7
+    assert np.max(np.abs(out - 0.3125)) <= 1e-6
     e.close()
 
 

@@ -12,6 +12,8 @@
 
 #include <ucontext.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -54,6 +56,9 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, siz
 }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+using std::max;
+using std::min;
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
