@@ -92,6 +92,22 @@ int les_hip_batch_num_jobs(const les_hip_batch* b);     /* workgroups one run la
 int les_hip_batch_run(les_hip_ctx* ctx, const les_hip_batch* b, int mode, const les_hip_plane* planes,
                       int planes_on_device, float* out_dev, int check);
 
+/* ---- hypothesis generation for the cells of a prepared batch (one proposal per cell per call) ----
+ * replaces: IProposer::startIterations/getNextProposal as driven by LES/FastGCStereo.h:41-48, for
+ * ExpansionProposer (LES/Proposer.h:62-79), RandomProposer (:120-152, `m` = outerIter + iter) and
+ * RansacProposer (:163-311, MAX_SAM 500, conf 0.95, threshold 1.0), and the label part of
+ * FastGCStereo::initCurrentFast (LES/FastGCStereo.h:105-109: createRandomLabel + fill of the unit region).
+ * unitRects: the cells' unit regions (n rects, host).  labels_dev: H*W planes; rng_dev: n uint64
+ * generator states (cv::RNG-compatible multiply-with-carry; one per cell, advanced in place);
+ * planes_dev: n output labels.  Asynchronous. */
+enum { LES_HIP_PROPOSE_EXPANSION = 0, LES_HIP_PROPOSE_RANDOM = 1, LES_HIP_PROPOSE_RANSAC = 2, LES_HIP_PROPOSE_INIT = 3 };
+int les_hip_batch_set_units(les_hip_ctx* ctx, les_hip_batch* b, const les_hip_rect* unitRects);
+int les_hip_batch_propose(les_hip_ctx* ctx, const les_hip_batch* b, int kind, int m, les_hip_plane* labels_dev,
+                          uint64_t* rng_dev, les_hip_plane* planes_dev);
+/* winner-take-all update over the batch's target rects with one device-resident plane per cell */
+int les_hip_batch_wta(les_hip_ctx* ctx, const les_hip_batch* b, const les_hip_plane* planes_dev, float* cur_cost_dev,
+                      const float* prop_cost_dev, les_hip_plane* labels_dev);
+
 /* replaces: the winner-take-all update of the PatchMatch iterations, LES/FastGCStereo.h:56-60
  * (mask = cur > prop; cur <- prop, label <- plane under mask) for n shared regions, on DEVICE maps:
  * cur_cost/prop_cost H*W floats, labels H*W planes (row stride W).  Asynchronous. */

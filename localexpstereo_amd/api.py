@@ -19,9 +19,13 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
+    "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
 ]
+
+
+PROPOSE_EXPANSION, PROPOSE_RANDOM, PROPOSE_RANSAC, PROPOSE_INIT = 0, 1, 2, 3
 
 
 class LesHipError(RuntimeError):
@@ -59,6 +63,9 @@ def load(path=None):
         "les_hip_batch_destroy": (None, [vp]),
         "les_hip_batch_num_jobs": (ci, [vp]),
         "les_hip_batch_run": (ci, [vp, vp, ci, vp, ci, vp, ci]),
+        "les_hip_batch_set_units": (ci, [vp, vp, vp]),
+        "les_hip_batch_propose": (ci, [vp, vp, ci, ci, vp, vp, vp]),
+        "les_hip_batch_wta": (ci, [vp, vp, vp, vp, vp, vp]),
         "les_hip_wta_update": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
         "les_hip_malloc": (ci, [vp, C.POINTER(vp), C.c_size_t]),
         "les_hip_free": (ci, [vp, vp]),
@@ -152,6 +159,20 @@ class Batch:
             assert len(self._planes) == self.n
             pp = _ptr(self._planes)
         self.e._chk(self.e.L.les_hip_batch_run(self.e.h, self.h, mode, pp, int(planes_on_device), C.c_void_p(int(out_dev_ptr)), int(check)))
+
+    def set_units(self, unit_rects):
+        self.units = _rects(unit_rects)
+        assert len(self.units) == self.n
+        self.e._chk(self.e.L.les_hip_batch_set_units(self.e.h, self.h, _ptr(self.units)))
+
+    def propose(self, kind, labels_dev, rng_dev, planes_dev, m=0):
+        """kind: PROPOSE_EXPANSION / _RANDOM / _RANSAC / _INIT; all pointers are device addresses (int)."""
+        self.e._chk(self.e.L.les_hip_batch_propose(self.e.h, self.h, kind, m, C.c_void_p(int(labels_dev)), C.c_void_p(int(rng_dev)),
+                                                   C.c_void_p(int(planes_dev))))
+
+    def wta(self, planes_dev, cur_cost_dev, prop_cost_dev, labels_dev):
+        self.e._chk(self.e.L.les_hip_batch_wta(self.e.h, self.h, C.c_void_p(int(planes_dev)), C.c_void_p(int(cur_cost_dev)),
+                                               C.c_void_p(int(prop_cost_dev)), C.c_void_p(int(labels_dev))))
 
     def destroy(self):
         if self.h:

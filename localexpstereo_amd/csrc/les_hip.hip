@@ -6,6 +6,7 @@
 // (tools/hipsim compiles this same file against a CPU fiber simulator for logic tests only.)
 #include "../../include/localexp_hip.h"
 #include "les_kernels.h"
+#include "les_propose.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -94,6 +95,11 @@ struct les_hip_batch {
     les::Job* d_jobs = nullptr;
     std::vector<les_hip_rect> targets;
     int device = 0;
+    // cell geometry for the proposers / WTA
+    les::Rect4* d_units = nullptr;
+    les::WtaJob* d_targets = nullptr;
+    float* d_ransac = nullptr;           // n * ransac_stride floats: disparity snapshot of every unit region
+    int ransac_stride = 0;
 };
 
 namespace {
@@ -293,10 +299,18 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
     les_hip_batch* b = new les_hip_batch();
     b->n = n; b->njobs = (int)jobs.size(); b->out_slabs = out_slabs; b->R = c->R; b->device = c->p.device;
     b->targets.assign(trs, trs + n);
+    if (n > 0) {
+        static_assert(sizeof(les::WtaJob) == sizeof(les_hip_rect), "rect layout");
+        if (hipMalloc((void**)&b->d_targets, (size_t)n * sizeof(les::WtaJob)) != hipSuccess ||
+            hipMemcpy(b->d_targets, trs, (size_t)n * sizeof(les::WtaJob), hipMemcpyHostToDevice) != hipSuccess) {
+            les_hip_batch_destroy(b);
+            return fail(LES_HIP_ERR_DEVICE, "upload of the target table failed");
+        }
+    }
     if (!jobs.empty()) {
-        if (hipMalloc((void**)&b->d_jobs, jobs.size() * sizeof(les::Job)) != hipSuccess) { delete b; return fail(LES_HIP_ERR_DEVICE, "hipMalloc(jobs) failed"); }
+        if (hipMalloc((void**)&b->d_jobs, jobs.size() * sizeof(les::Job)) != hipSuccess) { les_hip_batch_destroy(b); return fail(LES_HIP_ERR_DEVICE, "hipMalloc(jobs) failed"); }
         if (hipMemcpy(b->d_jobs, jobs.data(), jobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(b->d_jobs); delete b; return fail(LES_HIP_ERR_DEVICE, "hipMemcpy(jobs) failed");
+            les_hip_batch_destroy(b); return fail(LES_HIP_ERR_DEVICE, "hipMemcpy(jobs) failed");
         }
     }
     *out = b;
@@ -307,7 +321,74 @@ void les_hip_batch_destroy(les_hip_batch* b)
 {
     if (!b) return;
     if (b->d_jobs) (void)hipFree(b->d_jobs);
+    if (b->d_units) (void)hipFree(b->d_units);
+    if (b->d_targets) (void)hipFree(b->d_targets);
+    if (b->d_ransac) (void)hipFree(b->d_ransac);
     delete b;
+}
+
+int les_hip_batch_set_units(les_hip_ctx* c, les_hip_batch* b, const les_hip_rect* units)
+{
+    if (!c || !b || (b->n > 0 && !units)) return fail(LES_HIP_ERR_ARG, "null argument");
+    int maxlen = 1;
+    for (int i = 0; i < b->n; i++) {
+        const les_hip_rect& u = units[i];
+        if (u.w <= 0 || u.h <= 0 || u.x < 0 || u.y < 0 || u.x + u.w > c->p.W || u.y + u.h > c->p.H)
+            return fail(LES_HIP_ERR_ARG, "unit rect %d empty or outside the image", i);
+        maxlen = std::max(maxlen, u.w * u.h);
+    }
+    if (b->n == 0) return LES_HIP_OK;
+    static_assert(sizeof(les::Rect4) == sizeof(les_hip_rect), "rect layout");
+    if (!b->d_units) HIPCHECK(hipMalloc((void**)&b->d_units, (size_t)b->n * sizeof(les::Rect4)));
+    HIPCHECK(hipMemcpy(b->d_units, units, (size_t)b->n * sizeof(les::Rect4), hipMemcpyHostToDevice));
+    if (b->d_ransac) HIPCHECK(hipFree(b->d_ransac));
+    b->d_ransac = nullptr;
+    b->ransac_stride = maxlen;
+    HIPCHECK(hipMalloc((void**)&b->d_ransac, (size_t)b->n * maxlen * sizeof(float)));
+    return LES_HIP_OK;
+}
+
+int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int m, les_hip_plane* labels, uint64_t* rng,
+                          les_hip_plane* planes)
+{
+    if (!c || !b || !labels || !rng || !planes) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (b->n == 0) return LES_HIP_OK;
+    if (!b->d_units) return fail(LES_HIP_ERR_ARG, "les_hip_batch_set_units was not called for this batch");
+    float4* lab = reinterpret_cast<float4*>(labels);
+    float4* pl = reinterpret_cast<float4*>(planes);
+    const int n = b->n, W = c->p.W;
+    const float mind = c->p.min_disparity, maxd = c->p.max_disparity;
+    switch (kind) {
+    case LES_HIP_PROPOSE_EXPANSION:
+        hipLaunchKernelGGL(les::les_expansion_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n);
+        break;
+    case LES_HIP_PROPOSE_RANDOM:
+        hipLaunchKernelGGL(les::les_random_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n, m, mind, maxd);
+        break;
+    case LES_HIP_PROPOSE_RANSAC:
+        hipLaunchKernelGGL(les::les_ransac_kernel, dim3(n), dim3(les::kRansacThreads), 0, c->stream, b->d_units, lab, W, rng, pl,
+                           b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
+        break;
+    case LES_HIP_PROPOSE_INIT:
+        hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, mind, maxd);
+        break;
+    default:
+        return fail(LES_HIP_ERR_ARG, "unknown proposer kind %d", kind);
+    }
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plane* planes, float* cur, const float* prop,
+                      les_hip_plane* labels)
+{
+    if (!c || !b || !planes || !cur || !prop || !labels) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (b->n == 0) return LES_HIP_OK;
+    if (!b->d_targets) return fail(LES_HIP_ERR_ARG, "batch has no target table");
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(b->n), dim3(256), 0, c->stream, b->d_targets, reinterpret_cast<const float4*>(planes),
+                       cur, prop, reinterpret_cast<float4*>(labels), c->p.W);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
 }
 
 int les_hip_batch_num_jobs(const les_hip_batch* b) { return b ? b->njobs : 0; }

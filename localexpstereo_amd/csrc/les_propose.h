@@ -1,0 +1,337 @@
+// les_propose.h -- PatchMatch-style hypothesis generation on the device (reference: LES/Proposer.h,
+// LES/StereoEnergy.h:120-129, LES/Utilities.hpp:254-261, LES/FastGCStereo.h:94-115,231-238).
+//
+// One lock-step of the local-expansion loop draws one proposal per grid cell of a disjoint set
+// (LES/FastGCStereo.h:41-48).  Here every cell owns a cv::RNG-compatible generator state
+// (multiply-with-carry, [recollection] of OpenCV 3.1) kept in device memory, so a proposal for a cell
+// is a pure function of (label map, cell rect, generator state) and can be checked against the CPU
+// restatement draw for draw.  The reference seeds its per-thread generators from time(NULL)
+// (LES/main.cpp:430,444-450): trajectories are not reproducible there, only the distributions are.
+//
+// Kernels:
+//   les_expansion_kernel : ExpansionProposer::getNextProposal      (LES/Proposer.h:69-75)
+//   les_random_kernel    : RandomProposer::getNextProposal         (LES/Proposer.h:120-148)
+//   les_ransac_kernel    : RansacProposer::startIterations + RANSACPlane (LES/Proposer.h:177-301), one
+//                          64-thread workgroup per cell
+//   les_init_labels_kernel : FastGCStereo::initCurrentFast label part (LES/FastGCStereo.h:105-109)
+#pragma once
+
+#include "les_simt.h"
+
+namespace les {
+
+struct Rect4 { int x, y, w, h; };
+
+// ---- cv::RNG [recollection]
+struct Rng {
+    uint64_t state;
+    __device__ __forceinline__ uint32_t next()
+    {
+        state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    __device__ __forceinline__ int uniform_int(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
+    __device__ __forceinline__ float uniform_float(float a, float b)
+    {
+        float f = next() * 2.3283064365386962890625e-10f;
+        return f * (b - a) + a;
+    }
+    __device__ __forceinline__ double uniform_double(double a, double b)
+    {
+        uint32_t t = next();
+        double d = (double)(((uint64_t)t << 32) | next()) * 5.4210108624275221700372640043497e-20;
+        return d * (b - a) + a;
+    }
+};
+
+// LES/Plane.h:23-31
+__device__ __forceinline__ float4 plane_create(float nx, float ny, float nz, float z, float x, float y, float v)
+{
+    float4 p;
+    p.x = -nx / nz;
+    p.y = -ny / nz;
+    p.z = z - p.x * x - p.y * y;
+    p.w = v;
+    return p;
+}
+// LES/Plane.h:42-50 (sqrt in double, then cast)
+__device__ __forceinline__ void plane_normal(const float4& p, float n[3])
+{
+    float nz = (float)(1.0 / sqrt(1.0 + p.x * p.x + p.y * p.y));
+    n[0] = -p.x * nz;
+    n[1] = -p.y * nz;
+    n[2] = nz;
+}
+// LES/Utilities.hpp:254-261
+__device__ __forceinline__ void random_unit_vector(Rng& r, double thetaRange, double n[3])
+{
+    const double PI = 3.1415926535897932384626433832795;
+    double theta = r.uniform_double(0.0, thetaRange);
+    double phi = r.uniform_double(0.0, PI * 2.0);
+    double cosT = cos(theta), sinT = sin(theta);
+    double cosP = cos(phi), sinP = sin(phi);
+    n[0] = sinT * cosP; n[1] = sinT * sinP; n[2] = cosT;
+}
+// (MAX - MIN) * pow(0.5f, m + 1): exact powers of two (LES/Proposer.h:93-96)
+__device__ __forceinline__ float perturbation_width(float mind, float maxd, int m)
+{
+    return (float)((double)(maxd - mind) * ldexp(1.0, -(m + 1)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void les_expansion_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
+                                     uint64_t* __restrict__ rng, float4* __restrict__ planes, int n)
+{
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const Rect4 u = units[i];
+    Rng r{rng[i]};
+    int k = r.uniform_int(0, u.h * u.w);                              // LES/Proposer.h:37-44
+    int px = k % u.w, py = k / u.w;
+    planes[i] = labels[(size_t)(u.y + py) * W + u.x + px];            // :72
+    rng[i] = r.state;
+}
+
+__global__ void les_random_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
+                                  uint64_t* __restrict__ rng, float4* __restrict__ planes, int n, int m,
+                                  float mind, float maxd)
+{
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const double PI = 3.1415926535897932384626433832795;
+    const Rect4 u = units[i];
+    Rng r{rng[i]};
+    int k = r.uniform_int(0, u.h * u.w);                              // :122
+    int px = k % u.w, py = k / u.w;
+    const float4 in = labels[(size_t)(u.y + py) * W + u.x + px];      // :123
+    const int sx = u.x + px, sy = u.y + py;                           // :127
+    float zs = in.x * (float)sx + in.y * (float)sy + in.z;            // :128 Plane::GetZ
+    const float dz = perturbation_width(mind, maxd, m);               // :129
+    const float minz = fmaxf(mind, zs - dz);                          // :130
+    const float maxz = fminf(maxd, zs + dz);                          // :131
+    zs = r.uniform_float(minz, maxz);                                 // :132
+    const float nr = (float)ldexp(1.0, -m);                           // :142 randomNmax * pow(0.5f, m)
+    float n0[3];
+    plane_normal(in, n0);
+    double uv[3];
+    random_unit_vector(r, PI, uv);                                    // :143
+    float nv[3];
+    for (int c = 0; c < 3; c++) nv[c] = n0[c] + (float)uv[c] * nr;
+    const double dd = (double)nv[0] * nv[0] + (double)nv[1] * nv[1] + (double)nv[2] * nv[2];
+    const double inv = 1. / sqrt(dd);                                 // :145
+    for (int c = 0; c < 3; c++) nv[c] = (float)(nv[c] * inv);
+    planes[i] = plane_create(nv[0], nv[1], nv[2], zs, (float)sx, (float)sy, in.w);   // :147
+    rng[i] = r.state;
+}
+
+// createRandomLabel + fill of the unit region (LES/FastGCStereo.h:105-109, LES/StereoEnergy.h:120-129)
+__global__ void les_init_labels_kernel(const Rect4* __restrict__ units, float4* __restrict__ labels, int W,
+                                       uint64_t* __restrict__ rng, float4* __restrict__ planes, float mind, float maxd)
+{
+    const double PI = 3.1415926535897932384626433832795;
+    const int i = (int)blockIdx.x;
+    const Rect4 u = units[i];
+    __shared__ float4 s_plane;
+    if (threadIdx.x == 0) {
+        Rng r{rng[i]};
+        int k = r.uniform_int(0, u.h * u.w);                          // selectRandomPixelInRect, LES/FastGCStereo.h:231-238
+        int sx = u.x + k % u.w, sy = u.y + k / u.w;
+        float zs = r.uniform_float(mind, maxd);                       // LES/StereoEnergy.h:122
+        double nn[3];
+        random_unit_vector(r, PI / 3, nn);                            // :126
+        s_plane = plane_create((float)nn[0], (float)nn[1], (float)nn[2], zs, (float)sx, (float)sy, 0.0f);
+        planes[i] = s_plane;
+        rng[i] = r.state;
+    }
+    __syncthreads();
+    const float4 pl = s_plane;
+    for (int idx = (int)threadIdx.x; idx < u.w * u.h; idx += (int)blockDim.x)
+        labels[(size_t)(u.y + idx / u.w) * W + u.x + idx % u.w] = pl;  // currentLabeling(unit) = label, :109
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RANSAC.  cv::solve(A, b, x, DECOMP_SVD) of an m x 3 system is restated as the pseudo-inverse through
+// the 3x3 eigen-decomposition of A^T A in double, exactly as oracle/les_oracle.cpp:solve_svd_mx3.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void solve_normal_3x3(double M[3][3], const double rhs[3], float x[3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(M[0][1]) + fabs(M[0][2]) + fabs(M[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(M[p][q]) < 1e-300) continue;
+                double theta = (M[q][q] - M[p][p]) / (2 * M[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    double mkp = M[k][p], mkq = M[k][q];
+                    M[k][p] = c * mkp - s * mkq; M[k][q] = s * mkp + c * mkq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double mpk = M[p][k], mqk = M[q][k];
+                    M[p][k] = c * mpk - s * mqk; M[q][k] = s * mpk + c * mqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double w[3], wsum = 0;
+    for (int k = 0; k < 3; k++) { w[k] = sqrt(M[k][k] > 0.0 ? M[k][k] : 0.0); wsum += w[k]; }
+    const double thr = wsum * 2 * 1.1920929e-07;
+    double out[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        if (w[k] <= thr) continue;
+        double proj = (V[0][k] * rhs[0] + V[1][k] * rhs[1] + V[2][k] * rhs[2]) / (w[k] * w[k]);
+        for (int r = 0; r < 3; r++) out[r] += V[r][k] * proj;
+    }
+    for (int r = 0; r < 3; r++) x[r] = (float)out[r];
+}
+
+// LES/Proposer.h:243-262
+__device__ inline int ransac_sample_count(int ni, int ptNum, int pf, double conf)
+{
+    double q = 1.0;
+    for (double a = (ni - pf + 1), b = (ptNum - pf + 1); a <= ni; a += 1.0, b += 1.0) q *= (a / b);
+    int cnt;
+    if ((1.0 - q) < 1e-4) cnt = 1;
+    else cnt = (int)(log(1.0 - conf) / log(1.0 - q));
+    return cnt < 1 ? 1 : cnt;
+}
+
+constexpr int kRansacThreads = 64;
+
+// point i of the unit region -> (x, y, 1) and its disparity under the current labelling (:290-300)
+__device__ __forceinline__ void ransac_point(const Rect4& u, const float4* labels, int W, int i, float c[3], float& d)
+{
+    const int yy = i / u.w, xx = i - yy * u.w;
+    c[0] = (float)xx + u.x; c[1] = (float)yy + u.y; c[2] = 1.0f;
+    const float4 v = labels[(size_t)(yy + u.y) * W + xx + u.x];
+    d = v.x * c[0] + v.y * c[1] + v.z;                                // :297
+}
+
+__global__ void les_ransac_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
+                                  uint64_t* __restrict__ rng, float4* __restrict__ planes, float* __restrict__ disp_scratch,
+                                  int scratch_stride, int MAX_SAM, float conf, float threshold)
+{
+    const int cell = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const Rect4 u = units[cell];
+    const int len = u.w * u.h;
+    float* disp = disp_scratch + (size_t)cell * scratch_stride;
+    __shared__ float s_N[3];
+    __shared__ int s_cnt[kRansacThreads];
+    __shared__ double s_acc[kRansacThreads][9];
+    __shared__ int s_flag;
+
+    // startIterations snapshot (:283-301)
+    for (int i = tid; i < len; i += kRansacThreads) {
+        float c[3], d;
+        ransac_point(u, labels, W, i, c, d);
+        disp[i] = d;
+    }
+    __syncthreads();
+
+    auto count_inliers = [&](int upto) -> int {        // number of i < upto with |pts_i . N - disp_i| < threshold
+        const float n0 = s_N[0], n1 = s_N[1], n2 = s_N[2];
+        int c = 0;
+        for (int i = tid; i < upto; i += kRansacThreads) {
+            const int yy = i / u.w, xx = i - yy * u.w;
+            const float x = (float)xx + u.x, y = (float)yy + u.y;
+            const float dot = (float)((double)x * n0 + (double)y * n1 + (double)1.0f * n2);
+            c += fabsf(dot - disp[i]) < threshold;
+        }
+        s_cnt[tid] = c;
+        __syncthreads();
+        int tot = 0;
+        for (int k = 0; k < kRansacThreads; k++) tot += s_cnt[k];
+        __syncthreads();
+        return tot;
+    };
+
+    Rng r{rng[cell]};
+    int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;
+    float result[3] = {0, 0, 0};
+    while (no_sam < max_sam) {
+        no_sam++;
+        if (tid == 0) {
+            // three distinct uniformly random indices (the first three entries of randperm, :163-174,196-201)
+            int idx[3];
+            for (int i = 0; i < 3; i++) {
+                bool again;
+                do {
+                    idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
+                    again = false;
+                    for (int j = 0; j < i; j++) if (idx[j] == idx[i] && len > i) again = true;
+                } while (again);
+            }
+            double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
+            for (int i = 0; i < 3; i++) {
+                float c[3];
+                const int yy = idx[i] / u.w, xx = idx[i] - yy * u.w;
+                c[0] = (float)xx + u.x; c[1] = (float)yy + u.y; c[2] = 1.0f;
+                const float d = disp[idx[i]];
+                for (int a = 0; a < 3; a++) {
+                    rhs[a] += (double)c[a] * d;
+                    for (int b = 0; b < 3; b++) M[a][b] += (double)c[a] * c[b];
+                }
+            }
+            float N[3];
+            solve_normal_3x3(M, rhs, N);                               // :203
+            s_N[0] = N[0]; s_N[1] = N[1]; s_N[2] = N[2];
+        }
+        __syncthreads();
+        const int no_i = count_inliers(len);                           // :204-206
+        if (max_i < no_i) {
+            // refit on the inliers among the FIRST no_i points (the reference's loop bound quirk, :216);
+            // normal equations as 64 interleaved partial sums (lane = i mod 64) combined in lane order --
+            // the same order as oracle/les_oracle.cpp:solve_svd_mx3, so both give bit-identical planes
+            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            {
+                const float n0 = s_N[0], n1 = s_N[1], n2 = s_N[2];
+                for (int i = tid; i < no_i; i += kRansacThreads) {
+                    const int yy = i / u.w, xx = i - yy * u.w;
+                    const float x = (float)xx + u.x, y = (float)yy + u.y;
+                    const float dot = (float)((double)x * n0 + (double)y * n1 + (double)1.0f * n2);
+                    const float d = disp[i];
+                    if (fabsf(dot - d) < threshold) {
+                        const double dx = x, dy = y, dz = 1.0f, dd = d;
+                        acc[0] += dx * dx; acc[1] += dx * dy; acc[2] += dx * dz; acc[3] += dy * dy; acc[4] += dy * dz; acc[5] += dz * dz;
+                        acc[6] += dx * dd; acc[7] += dy * dd; acc[8] += dz * dd;
+                    }
+                }
+            }
+            for (int k = 0; k < 9; k++) s_acc[tid][k] = acc[k];
+            __syncthreads();
+            if (tid == 0) {
+                double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int l = 0; l < kRansacThreads; l++)
+                    for (int k = 0; k < 9; k++) t[k] += s_acc[l][k];
+                double M[3][3] = {{t[0], t[1], t[2]}, {t[1], t[3], t[4]}, {t[2], t[4], t[5]}};
+                double rhs[3] = {t[6], t[7], t[8]};
+                float N[3];
+                solve_normal_3x3(M, rhs, N);                           // :224
+                s_N[0] = N[0]; s_N[1] = N[1]; s_N[2] = N[2];
+            }
+            __syncthreads();
+            const int no = count_inliers(len);                         // :225-227
+            if (no > no_i_c) {                                         // :229-236
+                result[0] = s_N[0]; result[1] = s_N[1]; result[2] = s_N[2];
+                no_i_c = no;
+                max_i = no_i;
+                const int sc = ransac_sample_count(no, len, 3, conf);
+                max_sam = max_sam < sc ? max_sam : sc;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        planes[cell] = make_float4(result[0], result[1], result[2], 0.0f);   // :239
+        rng[cell] = r.state;
+    }
+    (void)s_flag;
+}
+
+}  // namespace les

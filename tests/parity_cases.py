@@ -219,3 +219,252 @@ def case_wta(pr, seed=5):
     assert gl.tobytes() == rl.tobytes()
     for d in (dc, dp, dl):
         d.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# hypothesis generation (LES/Proposer.h, LES/StereoEnergy.h:120-129) and the PatchMatch lock-step
+# ------------------------------------------------------------------------------------------------
+def _seeds(n, seed):
+    """Non-zero 64-bit generator states, one per cell."""
+    x = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(31)
+    return np.where(x == 0, np.uint64(0xFFFFFFFF), x).astype(np.uint64)
+
+
+def _label_map(H, W, D, seed, noise=0.0):
+    rng = np.random.default_rng(seed)
+    lab = np.zeros((H, W), api.PLANE_DT)
+    ys, xs = np.mgrid[0:H, 0:W]
+    by, bx = ys // 9, xs // 11
+    na, nb = by.max() + 1, bx.max() + 1
+    A = rng.uniform(-0.2, 0.2, (na, nb)).astype(np.float32)
+    B = rng.uniform(-0.2, 0.2, (na, nb)).astype(np.float32)
+    Z = rng.uniform(1, D - 2, (na, nb)).astype(np.float32)
+    lab["a"], lab["b"] = A[by, bx], B[by, bx]
+    lab["c"] = Z[by, bx] - lab["a"] * xs.astype(np.float32) - lab["b"] * ys.astype(np.float32)
+    if noise:
+        lab["c"] += rng.normal(0, noise, (H, W)).astype(np.float32)
+    return lab
+
+
+def _oracle_proposals(kind, labels, W, units, seeds, m, mind, maxd):
+    import ctypes as C
+    L = om.lib()
+    out = np.zeros(len(units), api.PLANE_DT)
+    states = np.zeros(len(units), np.uint64)
+    lp = labels.ctypes.data_as(C.c_void_p)
+    for i, u in enumerate(units):
+        r = om.Rng(int(seeds[i]))
+        rect = om.Rect(int(u["x"]), int(u["y"]), int(u["w"]), int(u["h"]))
+        if kind == api.PROPOSE_EXPANSION:
+            p = L.les_expansion_proposal(C.byref(r), lp, W, rect)
+        elif kind == api.PROPOSE_RANDOM:
+            p = L.les_random_proposal(C.byref(r), lp, W, rect, m, mind, maxd)
+        elif kind == api.PROPOSE_RANSAC:
+            p = L.les_ransac_proposal(C.byref(r), lp, W, rect, 500, 0.95, 1.0)
+        else:
+            px, py = C.c_int(), C.c_int()
+            L.les_select_random_pixel(C.byref(r), rect, C.byref(px), C.byref(py))
+            p = L.les_create_random_label(C.byref(r), mind, maxd, px.value, py.value)
+        out[i] = (p.a, p.b, p.c, p.v)
+        states[i] = r.state
+    return out, states
+
+
+def case_proposers(pr, unit=14, set_index=5, seed=11):
+    H, W, D = pr.H, pr.W, pr.D
+    mind, maxd = 0.0, float(D - 1)
+    layer = om.Layer(W, H, 20, unit)
+    cells = layer.sets[min(set_index, len(layer.sets) - 1)]
+    units = layer.unit[cells]
+    n = len(cells)
+    b = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+    b.set_units(units)
+    labels = _label_map(H, W, D, seed, noise=0.3)
+    d_lab = api.DeviceBuffer(pr.e, labels.nbytes)
+    d_rng = api.DeviceBuffer(pr.e, 8 * n)
+    d_pl = api.DeviceBuffer(pr.e, 16 * n)
+    try:
+        for kind, m in ((api.PROPOSE_EXPANSION, 0), (api.PROPOSE_RANDOM, 0), (api.PROPOSE_RANDOM, 4), (api.PROPOSE_RANSAC, 0),
+                        (api.PROPOSE_INIT, 0)):
+            seeds = _seeds(n, seed + 7 * kind + m)
+            d_lab.upload(labels)
+            d_rng.upload(seeds)
+            b.propose(kind, d_lab.ptr, d_rng.ptr, d_pl.ptr, m=m)
+            pr.e.synchronize()
+            got = d_pl.download((n,), api.PLANE_DT)
+            st = d_rng.download((n,), np.uint64)
+            ref, rst = _oracle_proposals(kind, labels, W, units, seeds, m, mind, maxd)
+            g4 = got.view(np.float32).reshape(n, 4)
+            r4 = ref.view(np.float32).reshape(n, 4)
+            if kind == api.PROPOSE_EXPANSION:
+                assert got.tobytes() == ref.tobytes() and np.array_equal(st, rst)
+            elif kind in (api.PROPOSE_RANDOM, api.PROPOSE_INIT):
+                assert np.array_equal(st, rst)
+                # device vs host libm (cos/sin in double) may differ in the last bit after the cast to float
+                np.testing.assert_allclose(g4, r4, rtol=2e-6, atol=2e-6)
+                assert np.mean(np.all(g4 == r4, axis=1)) > 0.8
+                if kind == api.PROPOSE_INIT:
+                    lab_after = d_lab.download((H, W), api.PLANE_DT)
+                    for i, u in enumerate(units):
+                        blk = lab_after[u["y"]:u["y"] + u["h"], u["x"]:u["x"] + u["w"]]
+                        assert np.all(blk == got[i])
+            else:
+                same = np.all(np.abs(g4 - r4) <= 1e-4 * np.maximum(1, np.abs(r4)), axis=1)
+                assert same.mean() >= 0.95, f"ransac agreement {same.mean()}"
+                assert np.mean(st == rst) >= 0.95
+    finally:
+        for d in (d_lab, d_rng, d_pl):
+            d.free()
+        b.destroy()
+
+
+def pm_iteration_oracle(pr, layers_units, proposer_table, seeds_per_layer, labels, cur, iteration, mode=0):
+    """CPU PatchMatch iteration (doGC = false) with the oracle: LES/FastGCStereo.h:22-72 in lock-step
+    order (all cells of a set draw proposal k, evaluate, WTA), which is equivalent to the reference's
+    per-cell order because cells of a set are independent."""
+    import ctypes as C
+    L = om.lib()
+    H, W, D = pr.H, pr.W, pr.D
+    mind, maxd = 0.0, float(D - 1)
+    for li, unit in enumerate(layers_units):
+        layer = om.Layer(W, H, 20, unit)
+        states = seeds_per_layer[li]
+        for cells in layer.sets:
+            units, shared, filt = layer.unit[cells], layer.shared[cells], layer.filter[cells]
+            for kind, K in proposer_table[li]:
+                it = 0
+                while True:
+                    if kind == api.PROPOSE_RANDOM:
+                        if not L.les_random_is_continued(it, K, iteration, mind, maxd):
+                            break
+                    elif it >= K:
+                        break
+                    planes, new_states = _oracle_proposals(kind, labels, W, units, states[cells], iteration + it, mind, maxd)
+                    states[cells] = new_states
+                    prop = pr.o.unary_batch(filt, shared, planes, mode=mode, check=True)
+                    for r, p in zip(shared, planes):
+                        L.les_oracle_wta_update(W, om.Rect(*[int(v) for v in r]), cur.ctypes.data_as(C.c_void_p),
+                                                prop.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p),
+                                                om.Plane(*[float(v) for v in p]))
+                    it += 1
+    return labels, cur
+
+
+def pm_iteration_device(pr, layers_units, proposer_table, seeds_per_layer, labels, cur, iteration, mode=0):
+    """The same iteration with everything resident on the device (labels, costs, generator states)."""
+    L = om.lib()
+    H, W, D = pr.H, pr.W, pr.D
+    mind, maxd = 0.0, float(D - 1)
+    d_lab = api.DeviceBuffer(pr.e, labels.nbytes)
+    d_cur = api.DeviceBuffer(pr.e, cur.nbytes)
+    d_prop = api.DeviceBuffer(pr.e, cur.nbytes)
+    d_lab.upload(labels)
+    d_cur.upload(cur)
+    for li, unit in enumerate(layers_units):
+        layer = om.Layer(W, H, 20, unit)
+        for cells in layer.sets:
+            n = len(cells)
+            b = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+            b.set_units(layer.unit[cells])
+            d_rng = api.DeviceBuffer(pr.e, 8 * n)
+            d_pl = api.DeviceBuffer(pr.e, 16 * n)
+            d_rng.upload(np.ascontiguousarray(seeds_per_layer[li][cells]))
+            for kind, K in proposer_table[li]:
+                it = 0
+                while True:
+                    if kind == api.PROPOSE_RANDOM:
+                        if not L.les_random_is_continued(it, K, iteration, mind, maxd):
+                            break
+                    elif it >= K:
+                        break
+                    b.propose(kind, d_lab.ptr, d_rng.ptr, d_pl.ptr, m=iteration + it)
+                    b.run(d_pl.ptr, d_prop.ptr, mode=mode, check=True, planes_on_device=True)
+                    b.wta(d_pl.ptr, d_cur.ptr, d_prop.ptr, d_lab.ptr)
+                    it += 1
+            pr.e.synchronize()
+            seeds_per_layer[li][cells] = d_rng.download((n,), np.uint64)
+            d_rng.free(); d_pl.free(); b.destroy()
+    out_l, out_c = d_lab.download((H, W), api.PLANE_DT), d_cur.download((H, W), np.float32)
+    for d in (d_lab, d_cur, d_prop):
+        d.free()
+    return out_l, out_c
+
+
+def case_pm_iteration(pr, layers_units=(12, 36), seed=21, plane_exact=True):
+    """One PatchMatch iteration (doGC=false): proposals -> unary costs -> winner-take-all
+    (LES/FastGCStereo.h:41-61), device vs oracle.
+
+    (a) lock-step check with the device state re-synchronised to the oracle's before every step: proposals
+        equal (exactly in the simulator; to float round-off of device trig on the GPU), proposal costs within
+        tolerance, and identical WTA decisions wherever the two costs differ by more than the float noise
+        (a decision between two labels whose costs agree to 1e-5 is a tie at equal energy: either is valid).
+    (b) free-running iteration on the device: the resulting total cost agrees with the oracle-driven run."""
+    import ctypes as C
+    L = om.lib()
+    H, W, D = pr.H, pr.W, pr.D
+    mind, maxd = 0.0, float(D - 1)
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)],     # LES/main.cpp:391-397
+             [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]]
+    labels0 = _label_map(H, W, D, seed, noise=0.2)
+    cur0 = np.full((H, W), np.float32(1e6))
+    seeds = [_seeds(len(om.Layer(W, H, 20, u).unit), seed + i) for i, u in enumerate(layers_units)]
+
+    # ---- (a) teacher-forced lock-steps
+    rl, rc = labels0.copy(), cur0.copy()
+    d_lab, d_cur, d_prop = (api.DeviceBuffer(pr.e, a.nbytes) for a in (rl, rc, rc))
+    steps = 0
+    worst = 0.0
+    for li, unit in enumerate(layers_units):
+        layer = om.Layer(W, H, 20, unit)
+        st = seeds[li].copy()
+        for cells in layer.sets:
+            n = len(cells)
+            units, shared, filt = layer.unit[cells], layer.shared[cells], layer.filter[cells]
+            b = api.Batch(pr.e, filt, shared)
+            b.set_units(units)
+            d_rng, d_pl = api.DeviceBuffer(pr.e, 8 * n), api.DeviceBuffer(pr.e, 16 * n)
+            for kind, K in table[li]:
+                it = 0
+                while (L.les_random_is_continued(it, K, 0, mind, maxd) if kind == api.PROPOSE_RANDOM else it < K):
+                    d_lab.upload(rl); d_cur.upload(rc); d_rng.upload(np.ascontiguousarray(st[cells]))
+                    b.propose(kind, d_lab.ptr, d_rng.ptr, d_pl.ptr, m=it)
+                    b.run(d_pl.ptr, d_prop.ptr, check=True, planes_on_device=True)
+                    b.wta(d_pl.ptr, d_cur.ptr, d_prop.ptr, d_lab.ptr)
+                    pr.e.synchronize()
+                    planes, new_st = _oracle_proposals(kind, rl, W, units, st[cells], it, mind, maxd)
+                    prop = pr.o.unary_batch(filt, shared, planes, check=True)
+                    old_c = rc.copy()
+                    for r, p in zip(shared, planes):
+                        L.les_oracle_wta_update(W, om.Rect(*[int(v) for v in r]), rc.ctypes.data_as(C.c_void_p),
+                                                prop.ctypes.data_as(C.c_void_p), rl.ctypes.data_as(C.c_void_p),
+                                                om.Plane(*[float(v) for v in p]))
+                    gp = d_pl.download((n,), api.PLANE_DT)
+                    g4, r4 = gp.view(np.float32).reshape(n, 4), planes.view(np.float32).reshape(n, 4)
+                    if plane_exact:
+                        assert gp.tobytes() == planes.tobytes(), f"proposals differ (kind {kind})"
+                        assert np.array_equal(d_rng.download((n,), np.uint64), new_st)
+                    else:
+                        ok = np.all(np.abs(g4 - r4) <= 1e-4 * np.maximum(1, np.abs(r4)), axis=1)
+                        assert ok.mean() >= 0.9, f"proposal agreement {ok.mean()} (kind {kind})"
+                    if gp.tobytes() == planes.tobytes():
+                        gprop = d_prop.download((H, W), np.float32)
+                        worst = max(worst, compare_maps(np.where(np.isnan(prop), np.nan, gprop).astype(np.float32), prop))
+                        gl, gc = d_lab.download((H, W), api.PLANE_DT), d_cur.download((H, W), np.float32)
+                        decisive = np.isnan(prop) | (np.abs(old_c - np.nan_to_num(prop, nan=0.0)) > 1e-5)
+                        assert np.all((gl == rl)[decisive]), "WTA decision differs away from a tie"
+                        assert np.max(np.abs(gc - rc)[rc < 1e5], initial=0.0) <= 1e-5
+                    st[cells] = new_st
+                    steps += 1
+                    it += 1
+            d_rng.free(); d_pl.free(); b.destroy()
+    for d in (d_lab, d_cur, d_prop):
+        d.free()
+
+    # ---- (b) free-running device iteration vs oracle-driven iteration: same energy
+    _, rc2 = pm_iteration_oracle(pr, layers_units, table, [s.copy() for s in seeds], labels0.copy(), cur0.copy(), 0)
+    _, gc2 = pm_iteration_device(pr, layers_units, table, [s.copy() for s in seeds], labels0.copy(), cur0.copy(), 0)
+    e_ref, e_got = float(rc2[rc2 < 1e5].sum()), float(gc2[gc2 < 1e5].sum())
+    assert (rc2 < 1e5).mean() > 0.95 and (gc2 < 1e5).mean() > 0.95
+    assert abs(e_got - e_ref) <= 0.02 * e_ref, (e_got, e_ref)
+    return steps, worst

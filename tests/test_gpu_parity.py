@@ -161,3 +161,17 @@ def test_full_size_linearity_in_cost(full):
     out = pc.run_slabs(p2, planes)
     assert np.max(np.abs(out[2] - 0.5 * (out[0] + out[1]))) <= 5e-7
     e.close()
+
+
+def test_gpu_proposers(mid):
+    pc.case_proposers(mid, unit=15, set_index=5)
+
+
+def test_gpu_pm_iteration(oracle_mod):
+    """PatchMatch lock-steps on the device vs the oracle (proposal generation, unary costs, WTA)."""
+    pr = pc.synth_pair(None, 120, 160, 16)
+    try:
+        steps, worst = pc.case_pm_iteration(pr, layers_units=(10, 30), plane_exact=False)
+        assert steps > 100 and worst <= pc.TIGHT
+    finally:
+        pr.close()

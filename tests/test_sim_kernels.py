@@ -85,3 +85,16 @@ def test_sim_matches_golden_fixture(cones):
         ref = np.full((cones.H, cones.W), np.nan, np.float32)
         ref[y:y + h, x:x + w] = g[f"out{i}"]
         pc.compare_maps(got, ref)
+
+
+def test_sim_proposers(cones):
+    pc.case_proposers(cones, unit=14, set_index=5)
+
+
+def test_sim_pm_iteration(sim_lib, oracle_mod):
+    pr = pc.synth_pair(sim_lib, 72, 96, 12)
+    try:
+        steps, worst = pc.case_pm_iteration(pr, layers_units=(10, 30), plane_exact=True)
+        assert steps > 100 and worst <= pc.TIGHT
+    finally:
+        pr.close()
