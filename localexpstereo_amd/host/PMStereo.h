@@ -1,0 +1,249 @@
+// PMStereo.h -- host loop of the PatchMatch-style iterations of the local expansion framework
+// (reference: PMStereoBase state LES/PMStereoBase.h:14-61, FastGCStereo::addLayer / initCurrentFast /
+// localExpansionMovesForLayer_CPU / run with doGC == false, LES/FastGCStereo.h:22-72,88-169).
+//
+// Two equivalent drivers over one energy operator:
+//   run()        the reference's loop shape: OpenMP over the cells of a disjoint set, each thread calling
+//                stereoEnergy->ComputeUnaryPotential for its cell (the drop-in path: any StereoEnergy works)
+//   runDevice()  the same iteration with label map, cost maps, generator states and proposers resident on
+//                the GPU: per proposal index one lock-step  propose -> unary -> winner-take-all  for all
+//                cells of the set, no host synchronisation inside an iteration.
+// The graph-cut fusion (doGC == true) needs a max-flow solver that the reference does not ship; it stays
+// outside this path ("next" row N2).
+#pragma once
+
+#include <chrono>
+#include <memory>
+
+#include "HipCostVolumeEnergy.h"
+#include "LayerManager.h"
+#include "Proposer.h"
+
+namespace les_host {
+
+struct ProposerSpec { int kind; int K; };   // kind: LES_HIP_PROPOSE_EXPANSION / _RANDOM / _RANSAC
+
+class PMStereo {
+public:
+    PMStereo(int width, int height, Parameters params, float maxDisparity, float minDisparity = 0)
+        : width(width), height(height), params(params), MAX_DISPARITY(maxDisparity), MIN_DISPARITY(minDisparity),
+          layermng(width, height, params.windR)
+    {
+        for (int m = 0; m < 2; m++) {
+            currentLabeling_[m] = LabelMap(height, width);
+            currentCost_[m] = CostMap(height, width, 0.f);
+        }
+    }
+
+    // replaces PMStereoBase::setStereoEnergyCPU (LES/PMStereoBase.h:58-61)
+    void setStereoEnergy(std::unique_ptr<StereoEnergy> energy) { stereoEnergy = std::move(energy); }
+    const StereoEnergy& getEnergyInstance() const { return *stereoEnergy; }
+
+    // replaces FastGCStereo::addLayer (LES/FastGCStereo.h:88-92)
+    void addLayer(int unitRegionSize, std::vector<ProposerSpec> proposers)
+    {
+        layermng.addLayer(unitRegionSize);
+        layerProposers.push_back(std::move(proposers));
+        // one generator per cell: proposals of a cell are a pure function of (labels, rect, state)
+        const size_t n = layermng.layers.back().unitRegions.size();
+        std::vector<uint64_t> st(n);
+        for (size_t i = 0; i < n; i++) st[i] = splitmix(seed_ + 0x9E3779B97F4A7C15ULL * (layermng.layers.size() * 1000003ULL + i));
+        rngStates.push_back(std::move(st));
+    }
+    void setSeed(uint64_t s) { seed_ = s; }
+
+    // ---------------------------------------------------------------------------------------------
+    // Drop-in driver: LES/FastGCStereo.h:94-115 (init) and :22-72 (moves, doGC == false)
+    // ---------------------------------------------------------------------------------------------
+    void initCurrentFast(int mode)
+    {
+        CostMap& cost = currentCost_[mode];
+        LabelMap& lab = currentLabeling_[mode];
+        std::fill(cost.data.begin(), cost.data.end(), 0.f);
+        const auto& layer = layermng.layers[0];
+        const Rect image(0, 0, width, height);
+        const int R = params.windR;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int j = 0; j < (int)layer.unitRegions.size(); j++) {
+            const Rect unit = layer.unitRegions[j];
+            RNG rng(rngStates[0][j]);
+            const int n = rng.uniform(0, unit.height * unit.width);
+            const Point pnt{unit.x + n % unit.width, unit.y + n / unit.width};
+            const Plane label = stereoEnergy->createRandomLabel(pnt, rng);
+            for (int y = 0; y < unit.height; y++)
+                for (int x = 0; x < unit.width; x++) lab.at(unit.y + y, unit.x + x) = label;
+            const Rect filterRegion = Rect(unit.x - R, unit.y - R, unit.width + 2 * R, unit.height + 2 * R) & image;
+            StereoEnergy::Reusable tmp;
+            stereoEnergy->ComputeUnaryPotential(filterRegion, unit, cost.view(filterRegion), width, label, tmp, mode);
+            rngStates[0][j] = rng.state;
+        }
+    }
+
+    void localExpansionMovesForLayer(int li, int mode, int iteration)
+    {
+        const auto& layer = layermng.layers[li];
+        CostMap& currentCost = currentCost_[mode];
+        LabelMap& currentLabeling = currentLabeling_[mode];
+        CostMap proposalCost(height, width);
+        for (const auto& set : layer.disjointRegionSets) {
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int n = 0; n < (int)set.size(); n++) {
+                const int r = set[n];
+                const Rect& sharedRegion = layer.sharedRegions[r];
+                const Rect& unitRegion = layer.unitRegions[r];
+                RNG rng(rngStates[li][r]);
+                StereoEnergy::Reusable reusable;
+                for (const ProposerSpec& spec : layerProposers[li]) {
+                    std::unique_ptr<IProposer> prop(makeHostProposer(spec));
+                    if (!prop) continue;                       // RANSAC: device-only in this framework
+                    prop->startIterations(currentLabeling, unitRegion, iteration, &rng);
+                    while (prop->isContinued()) {
+                        const Plane label = prop->getNextProposal();
+                        stereoEnergy->ComputeUnaryPotential(layer.filterRegions[r], sharedRegion, proposalCost.view(layer.filterRegions[r]),
+                                                            width, label, reusable, mode);
+                        for (int y = sharedRegion.y; y < sharedRegion.y + sharedRegion.height; y++)       // LES/FastGCStereo.h:57-60
+                            for (int x = sharedRegion.x; x < sharedRegion.x + sharedRegion.width; x++)
+                                if (currentCost.at(y, x) > proposalCost.at(y, x)) {
+                                    currentCost.at(y, x) = proposalCost.at(y, x);
+                                    currentLabeling.at(y, x) = label;
+                                }
+                    }
+                }
+                rngStates[li][r] = rng.state;
+            }
+        }
+    }
+
+    void run(int pmInit, const std::vector<int>& viewModes = {0})
+    {
+        for (int mode : viewModes) initCurrentFast(mode);
+        for (int iteration = 0; iteration < pmInit; iteration++)
+            for (int mode : viewModes)
+                for (int li = 0; li < (int)layermng.layers.size(); li++) localExpansionMovesForLayer(li, mode, iteration);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // Device-resident driver (needs a HipCostVolumeEnergy)
+    // ---------------------------------------------------------------------------------------------
+    bool runDevice(int pmInit, const std::vector<int>& viewModes = {0}, double* seconds = nullptr)
+    {
+        auto* hip = dynamic_cast<HipCostVolumeEnergy*>(stereoEnergy.get());
+        if (!hip) return false;
+        les_hip_ctx* ctx = hip->handle();
+        const size_t P = (size_t)width * height;
+        bool ok = true;
+        auto chk = [&](int rc) { if (rc != LES_HIP_OK) { if (ok) fprintf(stderr, "PMStereo::runDevice: %s\n", les_hip_last_error()); ok = false; } };
+        // prepared geometry: one batch per (layer, disjoint set) + the init batch (unit +- windR -> unit)
+        struct SetBatch { les_hip_batch* b = nullptr; uint64_t* rng = nullptr; les_hip_plane* planes = nullptr; int n = 0; std::vector<int> cells; };
+        std::vector<std::vector<SetBatch>> batches(layermng.layers.size());
+        auto make = [&](const std::vector<Rect>& fr, const std::vector<Rect>& tr, const std::vector<Rect>& un, const std::vector<uint64_t>& st) {
+            SetBatch sb;
+            sb.n = (int)fr.size();
+            chk(les_hip_batch_create(ctx, sb.n, reinterpret_cast<const les_hip_rect*>(fr.data()), reinterpret_cast<const les_hip_rect*>(tr.data()), 0, &sb.b));
+            if (sb.b) chk(les_hip_batch_set_units(ctx, sb.b, reinterpret_cast<const les_hip_rect*>(un.data())));
+            chk(les_hip_malloc(ctx, (void**)&sb.rng, sizeof(uint64_t) * std::max(1, sb.n)));
+            chk(les_hip_malloc(ctx, (void**)&sb.planes, sizeof(les_hip_plane) * std::max(1, sb.n)));
+            if (ok) chk(les_hip_memcpy_h2d(ctx, sb.rng, st.data(), sizeof(uint64_t) * sb.n));
+            return sb;
+        };
+        const Rect image(0, 0, width, height);
+        for (size_t li = 0; li < layermng.layers.size() && ok; li++) {
+            const auto& L = layermng.layers[li];
+            for (const auto& set : L.disjointRegionSets) {
+                std::vector<Rect> fr, tr, un;
+                std::vector<uint64_t> st;
+                for (int r : set) { fr.push_back(L.filterRegions[r]); tr.push_back(L.sharedRegions[r]); un.push_back(L.unitRegions[r]); st.push_back(rngStates[li][r]); }
+                SetBatch sb = make(fr, tr, un, st);
+                sb.cells = set;
+                batches[li].push_back(sb);
+            }
+        }
+        SetBatch init;
+        {
+            const auto& L = layermng.layers[0];
+            std::vector<Rect> fr;
+            const int R = params.windR;
+            for (const Rect& u : L.unitRegions) fr.push_back(Rect(u.x - R, u.y - R, u.width + 2 * R, u.height + 2 * R) & image);
+            init = make(fr, L.unitRegions, L.unitRegions, rngStates[0]);
+        }
+        les_hip_plane* d_labels = nullptr;
+        float *d_cur = nullptr, *d_prop = nullptr;
+        chk(les_hip_malloc(ctx, (void**)&d_labels, P * sizeof(les_hip_plane)));
+        chk(les_hip_malloc(ctx, (void**)&d_cur, P * sizeof(float)));
+        chk(les_hip_malloc(ctx, (void**)&d_prop, P * sizeof(float)));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int mode : viewModes) {
+            if (!ok) break;
+            // initCurrentFast on the device: random label per layer-0 cell, cost of its unit region
+            chk(les_hip_memset(ctx, d_labels, 0, P * sizeof(les_hip_plane)));
+            chk(les_hip_batch_propose(ctx, init.b, LES_HIP_PROPOSE_INIT, 0, d_labels, init.rng, init.planes));
+            chk(les_hip_batch_run(ctx, init.b, mode, init.planes, 1, d_cur, 1));
+            for (int iteration = 0; iteration < pmInit && ok; iteration++)
+                for (size_t li = 0; li < batches.size(); li++)
+                    for (SetBatch& sb : batches[li])
+                        for (const ProposerSpec& spec : layerProposers[li])
+                            for (int it = 0; it < spec.K; it++) {
+                                const int m = iteration + it;
+                                if (spec.kind == LES_HIP_PROPOSE_RANDOM && randomWidth(m) < 0.1) break;      // LES/Proposer.h:149-152
+                                chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
+                                chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
+                                chk(les_hip_batch_wta(ctx, sb.b, sb.planes, d_cur, d_prop, d_labels));
+                            }
+            chk(les_hip_synchronize(ctx));
+            if (ok) {
+                chk(les_hip_memcpy_d2h(ctx, currentLabeling_[mode].data.data(), d_labels, P * sizeof(les_hip_plane)));
+                chk(les_hip_memcpy_d2h(ctx, currentCost_[mode].data.data(), d_cur, P * sizeof(float)));
+            }
+        }
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (auto& lb : batches)
+            for (SetBatch& sb : lb) { les_hip_batch_destroy(sb.b); les_hip_free(ctx, sb.rng); les_hip_free(ctx, sb.planes); }
+        les_hip_batch_destroy(init.b); les_hip_free(ctx, init.rng); les_hip_free(ctx, init.planes);
+        les_hip_free(ctx, d_labels); les_hip_free(ctx, d_cur); les_hip_free(ctx, d_prop);
+        return ok;
+    }
+
+    // disparity of the current labelling (StereoEnergy::computeDisparities, LES/StereoEnergy.h:269-272)
+    std::vector<float> computeDisparities(int mode) const
+    {
+        std::vector<float> d((size_t)width * height);
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) d[(size_t)y * width + x] = currentLabeling_[mode].at(y, x).GetZ((float)x, (float)y);
+        return d;
+    }
+    double totalCost(int mode) const
+    {
+        double s = 0;
+        for (float v : currentCost_[mode].data) s += v;
+        return s;
+    }
+
+    LabelMap currentLabeling_[2];
+    CostMap currentCost_[2];
+    LayerManager& layers() { return layermng; }
+
+private:
+    static uint64_t splitmix(uint64_t x)
+    {
+        x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; x ^= x >> 31;
+        return x ? x : 0xffffffffULL;
+    }
+    float randomWidth(int m) const { return (float)((double)(MAX_DISPARITY - MIN_DISPARITY) * std::ldexp(1.0, -(m + 1))); }
+    IProposer* makeHostProposer(const ProposerSpec& s) const
+    {
+        if (s.kind == LES_HIP_PROPOSE_EXPANSION) return new ExpansionProposer(s.K);
+        if (s.kind == LES_HIP_PROPOSE_RANDOM) return new RandomProposer(s.K, MAX_DISPARITY, MIN_DISPARITY);
+        return nullptr;
+    }
+
+    const int width, height;
+    const Parameters params;
+    const float MAX_DISPARITY, MIN_DISPARITY;
+    LayerManager layermng;
+    std::vector<std::vector<ProposerSpec>> layerProposers;
+    std::vector<std::vector<uint64_t>> rngStates;
+    std::unique_ptr<StereoEnergy> stereoEnergy;
+    uint64_t seed_ = 1234;
+};
+
+}  // namespace les_host

@@ -1,0 +1,172 @@
+"""Device-resident PatchMatch iterations of the local expansion loop, optionally sharded over the GPUs
+of one node.
+
+Reference loop: FastGCStereo::run / initCurrentFast / localExpansionMovesForLayer_CPU with doGC == false
+(LES/FastGCStereo.h:22-72, 94-115, 133-169).  Cells of one disjoint set are independent
+(LES/LayerManager.h:168-172), so every rank owns a contiguous band of the cells of each set, runs their
+lock-steps (propose -> unary -> winner-take-all, all on the device through the C ABI) and then one
+all-gather over RCCL/xGMI publishes the updated label/cost tiles of the set to every replica.  The
+volume, the guide statistics and the label/cost maps are replicated; nothing is ever reduced.
+
+torch is plumbing here: device buffers and torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" for
+the CPU tests that run against the simulator build of the same C ABI).
+"""
+import numpy as np
+import torch
+
+from . import api
+
+
+def layer_geometry(W, H, windR, unit):
+    """LayerManager::addLayer geometry (LES/LayerManager.h:44-185) as numpy rect arrays + disjoint sets."""
+    minsize = max(2, unit // 2)
+    frac_w, frac_h = W % unit, H % unit
+    split_w, split_h = frac_w >= minsize, frac_h >= minsize
+    wb, hb = W // unit + int(split_w), H // unit + int(split_h)
+
+    def clip(x0, y0, x1, y1):
+        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, W), min(y1, H)
+        return (x0, y0, x1 - x0, y1 - y0) if x1 > x0 and y1 > y0 else (0, 0, 0, 0)
+
+    units, shared, filt = [], [], []
+    for i in range(hb):
+        for j in range(wb):
+            ux1 = (j + 1) * unit + (frac_w if (not split_w and j == wb - 1) else 0)
+            uy1 = (i + 1) * unit + (frac_h if (not split_h and i == hb - 1) else 0)
+            units.append(clip(j * unit, i * unit, ux1, uy1))
+            ex = frac_w if (not split_w and j == wb - 2) else 0
+            ey = frac_h if (not split_h and i == hb - 2) else 0
+            s = clip((j - 1) * unit, (i - 1) * unit, (j + 2) * unit, (i + 2) * unit)
+            shared.append((s[0], s[1], s[2] + ex, s[3] + ey))
+            f = clip((j - 1) * unit - windR, (i - 1) * unit - windR, (j + 2) * unit + windR, (i + 2) * unit + windR)
+            filt.append(clip(f[0], f[1], f[0] + f[2] + ex, f[1] + f[3] + ey))
+    sets = [[] for _ in range(16)]
+    for i in range(hb):
+        for j in range(wb):
+            sets[(i % 4) * 4 + (j % 4)].append(i * wb + j)
+    to = lambda a: np.array(a, np.int32).reshape(-1, 4).view(api.RECT_DT).reshape(-1)
+    return to(units), to(shared), to(filt), [np.array(s, np.int64) for s in sets if s]
+
+
+def seeds_for(n, seed):
+    """Non-zero 64-bit cv::RNG states, one per cell."""
+    x = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(31)
+    return np.where(x == 0, np.uint64(0xFFFFFFFF), x).astype(np.uint64)
+
+
+def _pixel_indices(rects, W):
+    parts = []
+    for r in rects:
+        ys = np.arange(r["y"], r["y"] + r["h"], dtype=np.int64)[:, None]
+        xs = np.arange(r["x"], r["x"] + r["w"], dtype=np.int64)[None, :]
+        parts.append((ys * W + xs).reshape(-1))
+    return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+
+
+class _Shard:
+    """One (layer, disjoint set) on one rank: prepared batch of the rank's own cells + exchange indices."""
+
+    def __init__(self, runner, units, shared, filt, cells, seeds, target_is_unit=False):
+        e, dev = runner.e, runner.device
+        world, rank = runner.world, runner.rank
+        bounds = np.linspace(0, len(cells), world + 1).astype(int)          # contiguous bands of cells
+        self.own = cells[bounds[rank]:bounds[rank + 1]]
+        tgt = units if target_is_unit else shared
+        self.n = len(self.own)
+        self.batch = api.Batch(e, filt[self.own], tgt[self.own])
+        self.batch.set_units(units[self.own])
+        self.rng = torch.from_numpy(seeds[self.own].view(np.int64).copy()).to(dev)
+        self.planes = torch.zeros((max(1, self.n), 4), dtype=torch.float32, device=dev)
+        self.idx = [torch.from_numpy(_pixel_indices(tgt[cells[bounds[r]:bounds[r + 1]]], runner.W)).to(dev) for r in range(world)]
+        self.lmax = max(int(i.numel()) for i in self.idx)
+
+
+class PMRunner:
+    def __init__(self, energy, layer_units, proposer_table, seed=1, rank=0, world=1, device="cuda", mode=0):
+        self.e, self.rank, self.world, self.mode = energy, rank, world, mode
+        self.device = torch.device(device)
+        self.H, self.W = energy.H, energy.W
+        self.table = proposer_table
+        self.maxd, self.mind = float(energy.max_disp), float(energy.params.min_disparity)
+        windR = energy.params.windR
+        self.labels = torch.zeros((self.H, self.W, 4), dtype=torch.float32, device=self.device)
+        self.cur = torch.zeros((self.H, self.W), dtype=torch.float32, device=self.device)
+        self.prop = torch.zeros((self.H, self.W), dtype=torch.float32, device=self.device)
+        self.shards = []
+        for li, unit in enumerate(layer_units):
+            units, shared, filt, sets = layer_geometry(self.W, self.H, windR, unit)
+            seeds = seeds_for(len(units), seed + 1000 * li)
+            self.shards.append([_Shard(self, units, shared, filt, cells, seeds) for cells in sets])
+            if li == 0:
+                x0 = np.maximum(units["x"] - windR, 0); y0 = np.maximum(units["y"] - windR, 0)
+                x1 = np.minimum(units["x"] + units["w"] + windR, self.W); y1 = np.minimum(units["y"] + units["h"] + windR, self.H)
+                fr = np.stack([x0, y0, x1 - x0, y1 - y0], 1).astype(np.int32).view(api.RECT_DT).reshape(-1)
+                self.init = _Shard(self, units, shared, fr, np.arange(len(units)), seeds_for(len(units), seed + 777), target_is_unit=True)
+        self.bytes_exchanged = 0
+
+    # -- exchange: one all-gather of the updated tiles of a set (labels 16 B/px + cost 4 B/px)
+    def _exchange(self, sh):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        lab, cur = self.labels.view(-1, 4), self.cur.view(-1)
+        send = torch.zeros((sh.lmax, 5), dtype=torch.float32, device=self.device)
+        own = sh.idx[self.rank]
+        send[: own.numel(), :4] = lab.index_select(0, own)
+        send[: own.numel(), 4] = cur.index_select(0, own)
+        recv = torch.empty((self.world * sh.lmax, 5), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(recv, send)
+        self.bytes_exchanged += recv.numel() * 4
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            idx = sh.idx[r]
+            blk = recv[r * sh.lmax: r * sh.lmax + idx.numel()]
+            lab.index_copy_(0, idx, blk[:, :4].contiguous())
+            cur.index_copy_(0, idx, blk[:, 4].contiguous())
+
+    def _sync(self):
+        self.e.synchronize()
+
+    def init_labels(self):
+        """initCurrentFast (LES/FastGCStereo.h:94-115): random label per layer-0 cell + its unit-region cost."""
+        sh = self.init
+        if sh.n:
+            sh.batch.propose(api.PROPOSE_INIT, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr())
+            sh.batch.run(sh.planes.data_ptr(), self.cur.data_ptr(), mode=self.mode, check=True, planes_on_device=True)
+        self._sync()
+        self._exchange(sh)
+
+    def iteration(self, iteration):
+        """One PatchMatch iteration over all layers (LES/FastGCStereo.h:143-157 with doGC == false)."""
+        for li, layer in enumerate(self.shards):
+            for sh in layer:
+                if sh.n:
+                    for kind, K in self.table[li]:
+                        for it in range(K):
+                            m = iteration + it
+                            if kind == api.PROPOSE_RANDOM and (self.maxd - self.mind) * 0.5 ** (m + 1) < 0.1:      # LES/Proposer.h:149-152
+                                break
+                            sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=m)
+                            sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=self.mode, check=True, planes_on_device=True)
+                            sh.batch.wta(sh.planes.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
+                self._sync()
+                self._exchange(sh)
+
+    def run(self, pm_iterations):
+        self.init_labels()
+        for it in range(pm_iterations):
+            self.iteration(it)
+        return self.labels, self.cur
+
+    def disparities(self):
+        ys, xs = torch.meshgrid(torch.arange(self.H, device=self.device, dtype=torch.float32),
+                                torch.arange(self.W, device=self.device, dtype=torch.float32), indexing="ij")
+        return self.labels[..., 0] * xs + self.labels[..., 1] * ys + self.labels[..., 2]
+
+    def close(self):
+        for layer in self.shards:
+            for sh in layer:
+                sh.batch.destroy()
+        self.init.batch.destroy()

@@ -1,0 +1,45 @@
+"""Multi-rank path: cells of every disjoint set are sharded across ranks, one
+all-gather per set publishes the updated label/cost tiles.  world_size-2 gloo run on CPU (against the
+simulator build of the C ABI) must reproduce the single-rank result bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_layer_geometry_matches_oracle(oracle_mod):
+    from localexpstereo_amd import pm
+    for W, H, u in ((450, 375, 5), (450, 375, 25), (1436, 992, 43), (1500, 1000, 135), (97, 61, 13), (120, 96, 14)):
+        units, shared, filt, sets = pm.layer_geometry(W, H, 20, u)
+        L = oracle_mod.Layer(W, H, 20, u)
+        assert units.tobytes() == L.unit.tobytes() and shared.tobytes() == L.shared.tobytes() and filt.tobytes() == L.filter.tobytes()
+        assert len(sets) == len(L.sets) and all(np.array_equal(a, b) for a, b in zip(sets, L.sets))
+
+
+def _run(world, out, H=64, W=88, D=10, iters=1):
+    from localexpstereo_amd import build
+    lib = build.build_sim()
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    args = [out, lib, str(H), str(W), str(D), str(iters)]
+    if world == 1:
+        cmd = [sys.executable, worker] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", "29517", worker] + args
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return np.load(out)
+
+
+def test_two_ranks_equal_one_rank(tmp_path, oracle_mod):
+    one = _run(1, str(tmp_path / "one.npz"))
+    two = _run(2, str(tmp_path / "two.npz"))
+    assert int(one["bytes_exchanged"]) == 0 and int(two["bytes_exchanged"]) > 0
+    assert one["labels"].tobytes() == two["labels"].tobytes()
+    assert one["cur"].tobytes() == two["cur"].tobytes()
+    # the run did something: every pixel has a finite cost below the initial sentinel for most of the image
+    assert np.isfinite(one["cur"]).all() and (one["cur"] < 1e5).mean() > 0.9
