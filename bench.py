@@ -114,6 +114,18 @@ def main():
     alg_bytes = float(P) * D * bytes_per_eval + float(P) * 48.0        # per launch (= per rank per step)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate
+    # passes; see profiles/): cannot be collected live inside this process, so the committed measurement is quoted.
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf)).get(args.workload)
+            if t and t.get("strip_width") == e.strip_width() and (H, W, D) == tuple(t.get("shape", ())):
+                traffic = t["bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     result = {
         "metric": "Mcost-evals/s (pixels x hypotheses / s), guided-filter cost aggregation, 1500x1000x256 vol",
         "value": round(value, 2),
@@ -141,8 +153,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
-            "kernel": "les_strip_kernel<10,64,16>",
+            "traffic": traffic,
+            "kernel": "les_strip_kernel<R=10> (gather + guided filter fused; strip width %d)" % e.strip_width(),
             "kernel_ms": round(kern_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
         },
