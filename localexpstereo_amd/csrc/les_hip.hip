@@ -47,12 +47,14 @@ struct StripEntry { int R; int variant; int TW; int NT; StripKernel fn; };
 #define LES_STRIP_ENTRY(R_, V_, WA_, BY_, SEG_, MW_) \
     { R_, V_, les::StripCfg<R_, WA_, BY_, SEG_>::TW, les::StripCfg<R_, WA_, BY_, SEG_>::NT, les::les_strip_kernel<R_, WA_, BY_, SEG_, MW_> }
 const StripEntry kStrips[] = {
-    // default per radius: no register spills at 2 waves/SIMD measured faster than 3-4 waves with spills
+    // Defaults per radius.  Measured on MI355X (R = 10, 1500x1000x256): occupancy without register spills wins --
+    // (WA 64, BY 21 = ring length, SEG 3, 3 waves/SIMD, 0 B scratch) 7.0 ms vs 9.2 ms for (128,16,8,2 waves) and
+    // 12+ ms for anything that spills.
     LES_STRIP_ENTRY(1, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(2, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(3, 0, 64, 16, 4, 2),
     LES_STRIP_ENTRY(5, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(8, 0, 64, 16, 4, 2),
-    LES_STRIP_ENTRY(10, 0, 128, 16, 8, 2),
+    LES_STRIP_ENTRY(10, 0, 64, 21, 3, 3),
     // A/B variants for radius 10 (LES_HIP_VARIANT=n)
-    LES_STRIP_ENTRY(10, 1, 64, 16, 4, 2), LES_STRIP_ENTRY(10, 2, 128, 16, 8, 3), LES_STRIP_ENTRY(10, 3, 128, 16, 4, 2),
+    LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
 };
 const StripEntry* find_strip(int R)
 {
@@ -366,8 +368,13 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
         hipLaunchKernelGGL(les::les_random_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n, m, mind, maxd);
         break;
     case LES_HIP_PROPOSE_RANSAC:
-        hipLaunchKernelGGL(les::les_ransac_kernel, dim3(n), dim3(les::kRansacThreads), 0, c->stream, b->d_units, lab, W, rng, pl,
-                           b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
+        // one candidate per lane: big unit regions get wider workgroups (more candidates in flight per batch)
+        if (b->ransac_stride > 1024)
+            hipLaunchKernelGGL(les::les_ransac_kernel<256>, dim3(n), dim3(256), 0, c->stream, b->d_units, lab, W, rng, pl,
+                               b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
+        else
+            hipLaunchKernelGGL(les::les_ransac_kernel<64>, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl,
+                               b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
         break;
     case LES_HIP_PROPOSE_INIT:
         hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, mind, maxd);

@@ -159,6 +159,14 @@ __device__ __forceinline__ int window_count(int c, int R, int lo, int hi)
     return b > a ? b - a : 0;
 }
 
+// The H chains are fully unrolled; without a fence the scheduler hoists dozens of LDS loads to the top and
+// the register footprint (and with it the occupancy) is set by that phase alone.
+#if defined(LES_SIM)
+#define LES_SCHED_FENCE(step) ((void)0)
+#else
+#define LES_SCHED_FENCE(step) do { if (((step) & 3) == 3) __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
 template <int V>
 struct IntTag { static constexpr int value = V; };
 
@@ -247,12 +255,12 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     constexpr int TW = Cfg::TW, WP = Cfg::WP, NT = Cfg::NT, HL = Cfg::HL, L1 = Cfg::L1, L2 = Cfg::L2;
     constexpr int TPITCH = Cfg::TPITCH, KS = Cfg::KS, RS = Cfg::RS;
 
-    __shared__ float s_p[BY][WP];            // truncated cost p (0 outside the clip)
+    __shared__ float s_p[BY][WP];            // truncated cost p (0 outside the clip); dead after H1 ...
     __shared__ uint32_t s_ipk[BY][WP];       // packed guide pixel of the same p-rows
     __shared__ float s_T[BY][TPITCH];        // H1 sums, then (in place) vertical stage-2 sums
     __shared__ uint32_t s_ipk2[BY][TW];      // packed guide pixel of the output rows of this block
-    __shared__ float s_q[BY][TW];            // finished q of the output rows of this block
     __shared__ double s_rtab[2 * R + 2];     // 1/n, n = 0..2R+1
+    float (*s_q)[WP] = s_p;                  // ... so the finished q of the block's output rows reuses it (H2 -> F)
 
     // XCD-aware job order (guide T1): consecutive jobs (same strip, consecutive planes / neighbouring
     // cells) run on the same XCD so that guide statistics and volume halos are shared in its L2.
@@ -301,8 +309,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 
     // Guide statistics of the stage-1 pixels are prefetched PD rows ahead into registers (the pipeline
     // runs across block boundaries), so their L2/HBM latency never sits on the V-phase critical path.
-    constexpr int PD = 4;
-    static_assert(BY % PD == 0, "prefetch distance must divide the block height");
+    constexpr int PD = (BY % 4 == 0) ? 4 : ((BY % 3 == 0) ? 3 : 1);      // must divide BY (static register names)
     const int sgx1 = min(max(gx1, job.cx0), job.cx1 - 1);
     const float4* st_col = view.stats + (size_t)sgx1 * 3 + (vk < 3 ? vk : 0);
     const size_t st_stride = (size_t)g.W * 3;
@@ -316,39 +323,46 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 
     for (int t0 = 0; t0 < Ttot; t0 += BY) {
         // ===================== G: gather =====================
-        // A lane keeps its column for the whole job (column terms hoisted out of the march); all loads
-        // of a block are issued before any is consumed (memory-level parallelism).
+        // A lane keeps its column for the whole job (column terms hoisted out of the march); the loads of
+        // up to GB rows per lane are issued before any is consumed (memory-level parallelism, bounded so
+        // that the register footprint stays small).
         {
-            GatherPrep gp[GPASS];
-            float v0[GPASS], v1[GPASS];
-            uint32_t ipa[GPASS], ipo[OPASS];
+            constexpr int GB = 4;
+            static_for<(GPASS + GB - 1) / GB>([&](auto btag) {
+                constexpr int J0 = decltype(btag)::value * GB;
+                constexpr int JN = (GPASS - J0) < GB ? (GPASS - J0) : GB;
+                GatherPrep gp[JN];
+                float v0[JN], v1[JN];
+                uint32_t ipa[JN];
 #pragma unroll
-            for (int j = 0; j < GPASS; j++) {
-                const int i = j * GRP + g_ri;
-                const int t = t0 + i;
-                const int gy = job.ty0 - 2 * R + t;
-                const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
-                const int sy = min(max(gy, job.cy0), job.cy1 - 1);
-                const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
-                const float d_base = plane.y * (float)sy + plane.z;
-                gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
-                v0[j] = view.vol[gp[j].i0];
-                v1[j] = view.vol[gp[j].i1];
-                ipa[j] = view.ipk[px];
-            }
+                for (int j = 0; j < JN; j++) {
+                    const int i = (J0 + j) * GRP + g_ri;
+                    const int t = t0 + i;
+                    const int gy = job.ty0 - 2 * R + t;
+                    const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
+                    const int sy = min(max(gy, job.cy0), job.cy1 - 1);
+                    const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
+                    const float d_base = plane.y * (float)sy + plane.z;
+                    gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
+                    v0[j] = view.vol[gp[j].i0];
+                    v1[j] = view.vol[gp[j].i1];
+                    ipa[j] = view.ipk[px];
+                }
+#pragma unroll
+                for (int j = 0; j < JN; j++) {
+                    const int i = (J0 + j) * GRP + g_ri;
+                    if (g_lane && i < BY) {
+                        s_p[i][g_xi] = gather_finish(g, gp[j], v0[j], v1[j]);
+                        s_ipk[i][g_xi] = ipa[j];
+                    }
+                }
+            });
+            uint32_t ipo[OPASS];
 #pragma unroll
             for (int j = 0; j < OPASS; j++) {
                 const int i = j * ORP + o_ri;
                 const int sy = min(max(job.ty0 + t0 + i - 4 * R, job.cy0), job.cy1 - 1);
                 ipo[j] = view.ipk[(uint32_t)sy * (uint32_t)g.W + (uint32_t)o_sx];
-            }
-#pragma unroll
-            for (int j = 0; j < GPASS; j++) {
-                const int i = j * GRP + g_ri;
-                if (g_lane && i < BY) {
-                    s_p[i][g_xi] = gather_finish(g, gp[j], v0[j], v1[j]);
-                    s_ipk[i][g_xi] = ipa[j];
-                }
             }
 #pragma unroll
             for (int j = 0; j < OPASS; j++) {
@@ -372,6 +386,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                 S += (double)f - (double)ring[s % KS];
                 ring[s % KS] = f;
                 if (s >= 2 * R && x0 + s - 2 * R < WA) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)S;
+                LES_SCHED_FENCE(s);
             }
         }
         __syncthreads();
@@ -434,6 +449,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                         s_q[hrow][xo] = (float)(qn * rn2);
                     }
                 }
+                LES_SCHED_FENCE(s);
             }
         }
         __syncthreads();

@@ -156,9 +156,9 @@ __global__ void les_init_labels_kernel(const Rect4* __restrict__ units, float4* 
 __device__ inline void solve_normal_3x3(double M[3][3], const double rhs[3], float x[3])
 {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; sweep++) {
+    for (int sweep = 0; sweep < 16; sweep++) {
         double off = fabs(M[0][1]) + fabs(M[0][2]) + fabs(M[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-15 * (fabs(M[0][0]) + fabs(M[1][1]) + fabs(M[2][2]))) break;   // off-diagonals at the rounding floor of the diagonal
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 if (fabs(M[p][q]) < 1e-300) continue;
@@ -202,136 +202,143 @@ __device__ inline int ransac_sample_count(int ni, int ptNum, int pf, double conf
     return cnt < 1 ? 1 : cnt;
 }
 
-constexpr int kRansacThreads = 64;
-
-// point i of the unit region -> (x, y, 1) and its disparity under the current labelling (:290-300)
-__device__ __forceinline__ void ransac_point(const Rect4& u, const float4* labels, int W, int i, float c[3], float& d)
-{
-    const int yy = i / u.w, xx = i - yy * u.w;
-    c[0] = (float)xx + u.x; c[1] = (float)yy + u.y; c[2] = 1.0f;
-    const float4 v = labels[(size_t)(yy + u.y) * W + xx + u.x];
-    d = v.x * c[0] + v.y * c[1] + v.z;                                // :297
-}
-
-__global__ void les_ransac_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
-                                  uint64_t* __restrict__ rng, float4* __restrict__ planes, float* __restrict__ disp_scratch,
-                                  int scratch_stride, int MAX_SAM, float conf, float threshold)
+// RANSACPlane (LES/Proposer.h:177-240) with the reference's sequential semantics, evaluated NTHR samples at
+// a time.  The samples of a batch are drawn in order by one lane (the generator is sequential); then every
+// lane owns one candidate: it solves the 3-point plane, counts its inliers and -- if the candidate could
+// trigger the reference's "better than max_i" branch -- also computes the least-squares refit on the inliers
+// among the first no_i points and the refit's inlier count.  None of that depends on the evolving RANSAC
+// state, so it is embarrassingly parallel.  Finally the candidates are walked IN ORDER with the reference's
+// acceptance / adaptive-termination logic on the precomputed numbers.  Candidates beyond the point where the
+// sequential algorithm stops are discarded and the generator state is rewound to the last consumed sample, so
+// result and state are exactly those of the sequential algorithm.
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR)
+les_ransac_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
+                  uint64_t* __restrict__ rng, float4* __restrict__ planes, float* __restrict__ disp_scratch,
+                  int scratch_stride, int MAX_SAM, float conf, float threshold)
 {
     const int cell = (int)blockIdx.x, tid = (int)threadIdx.x;
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     float* disp = disp_scratch + (size_t)cell * scratch_stride;
-    __shared__ float s_N[3];
-    __shared__ int s_cnt[kRansacThreads];
-    __shared__ double s_acc[kRansacThreads][9];
-    __shared__ int s_flag;
+    __shared__ int s_idx[NTHR][3];
+    __shared__ uint64_t s_state[NTHR + 1];
+    __shared__ float s_refit[NTHR][3];
+    __shared__ int s_noi[NTHR], s_no[NTHR];
 
     // startIterations snapshot (:283-301)
-    for (int i = tid; i < len; i += kRansacThreads) {
-        float c[3], d;
-        ransac_point(u, labels, W, i, c, d);
-        disp[i] = d;
+    for (int i = tid; i < len; i += NTHR) {
+        const int yy = i / u.w, xx = i - yy * u.w;
+        const float c0 = (float)xx + u.x, c1 = (float)yy + u.y;
+        const float4 v = labels[(size_t)(yy + u.y) * W + xx + u.x];
+        disp[i] = v.x * c0 + v.y * c1 + v.z;                           // :297
     }
     __syncthreads();
 
-    auto count_inliers = [&](int upto) -> int {        // number of i < upto with |pts_i . N - disp_i| < threshold
-        const float n0 = s_N[0], n1 = s_N[1], n2 = s_N[2];
-        int c = 0;
-        for (int i = tid; i < upto; i += kRansacThreads) {
-            const int yy = i / u.w, xx = i - yy * u.w;
-            const float x = (float)xx + u.x, y = (float)yy + u.y;
-            const float dot = (float)((double)x * n0 + (double)y * n1 + (double)1.0f * n2);
-            c += fabsf(dot - disp[i]) < threshold;
+    // visits the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
+    auto scan = [&](int upto, const float N[3], auto&& f) {
+        int i = 0;
+        for (int yy = 0; yy < u.h && i < upto; yy++) {
+            const float y = (float)yy + u.y;
+            const double ty = (double)y * N[1];
+            for (int xx = 0; xx < u.w && i < upto; xx++, i++) {
+                const float x = (float)xx + u.x;
+                const float d = disp[i];
+                const float dot = (float)(((double)x * N[0] + ty) + (double)1.0f * N[2]);   // pts * N (:204): x*N0 + y*N1 + 1*N2
+                f(x, y, d, fabsf(dot - d) < threshold);
+            }
         }
-        s_cnt[tid] = c;
-        __syncthreads();
-        int tot = 0;
-        for (int k = 0; k < kRansacThreads; k++) tot += s_cnt[k];
-        __syncthreads();
-        return tot;
     };
 
-    Rng r{rng[cell]};
+    uint64_t state = rng[cell];
     int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;
     float result[3] = {0, 0, 0};
-    while (no_sam < max_sam) {
-        no_sam++;
+    bool done = false;
+    while (!done && no_sam < max_sam) {
+        const int nb = (max_sam - no_sam) < NTHR ? (max_sam - no_sam) : NTHR;
         if (tid == 0) {
-            // three distinct uniformly random indices (the first three entries of randperm, :163-174,196-201)
-            int idx[3];
-            for (int i = 0; i < 3; i++) {
-                bool again;
-                do {
-                    idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
-                    again = false;
-                    for (int j = 0; j < i; j++) if (idx[j] == idx[i] && len > i) again = true;
-                } while (again);
+            Rng r{state};
+            s_state[0] = state;
+            for (int j = 0; j < nb; j++) {
+                // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
+                int idx[3];
+                for (int i = 0; i < 3; i++) {
+                    bool again;
+                    do {
+                        idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
+                        again = false;
+                        for (int q = 0; q < i; q++) if (idx[q] == idx[i] && len > i) again = true;
+                    } while (again);
+                }
+                s_idx[j][0] = idx[0]; s_idx[j][1] = idx[1]; s_idx[j][2] = idx[2];
+                s_state[j + 1] = r.state;
             }
+        }
+        __syncthreads();
+        if (tid < nb) {
             double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
             for (int i = 0; i < 3; i++) {
-                float c[3];
-                const int yy = idx[i] / u.w, xx = idx[i] - yy * u.w;
-                c[0] = (float)xx + u.x; c[1] = (float)yy + u.y; c[2] = 1.0f;
-                const float d = disp[idx[i]];
+                const int id = s_idx[tid][i];
+                const int yy = id / u.w, xx = id - yy * u.w;
+                const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
+                const double d = disp[id];
                 for (int a = 0; a < 3; a++) {
-                    rhs[a] += (double)c[a] * d;
-                    for (int b = 0; b < 3; b++) M[a][b] += (double)c[a] * c[b];
+                    rhs[a] += c[a] * d;
+                    for (int b = 0; b < 3; b++) M[a][b] += c[a] * c[b];
                 }
             }
             float N[3];
-            solve_normal_3x3(M, rhs, N);                               // :203
-            s_N[0] = N[0]; s_N[1] = N[1]; s_N[2] = N[2];
+            solve_normal_3x3(M, rhs, N);                               // cv::solve(ranpts, div, N, DECOMP_SVD) :203
+            int no_i = 0;
+            scan(len, N, [&](float, float, float, bool in) { no_i += in; });          // :204-206
+            s_noi[tid] = no_i;
+            s_no[tid] = -1;
+            if (no_i > max_i) {
+                // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound
+                // quirk, :216), rows accumulated in increasing order like oracle/les_oracle.cpp:solve_svd_mx3
+                double A[3][3] = {{0}}, r3[3] = {0, 0, 0};
+                scan(no_i, N, [&](float x, float y, float d, bool in) {
+                    if (in) {
+                        const double c[3] = {(double)x, (double)y, 1.0};
+                        const double dd = d;
+                        for (int a = 0; a < 3; a++) {
+                            r3[a] += c[a] * dd;
+                            for (int b = 0; b < 3; b++) A[a][b] += c[a] * c[b];
+                        }
+                    }
+                });
+                float N2[3];
+                solve_normal_3x3(A, r3, N2);                           // :224
+                int no = 0;
+                scan(len, N2, [&](float, float, float, bool in) { no += in; });      // :225-227
+                s_refit[tid][0] = N2[0]; s_refit[tid][1] = N2[1]; s_refit[tid][2] = N2[2];
+                s_no[tid] = no;
+            }
         }
         __syncthreads();
-        const int no_i = count_inliers(len);                           // :204-206
-        if (max_i < no_i) {
-            // refit on the inliers among the FIRST no_i points (the reference's loop bound quirk, :216);
-            // normal equations as 64 interleaved partial sums (lane = i mod 64) combined in lane order --
-            // the same order as oracle/les_oracle.cpp:solve_svd_mx3, so both give bit-identical planes
-            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            {
-                const float n0 = s_N[0], n1 = s_N[1], n2 = s_N[2];
-                for (int i = tid; i < no_i; i += kRansacThreads) {
-                    const int yy = i / u.w, xx = i - yy * u.w;
-                    const float x = (float)xx + u.x, y = (float)yy + u.y;
-                    const float dot = (float)((double)x * n0 + (double)y * n1 + (double)1.0f * n2);
-                    const float d = disp[i];
-                    if (fabsf(dot - d) < threshold) {
-                        const double dx = x, dy = y, dz = 1.0f, dd = d;
-                        acc[0] += dx * dx; acc[1] += dx * dy; acc[2] += dx * dz; acc[3] += dy * dy; acc[4] += dy * dz; acc[5] += dz * dz;
-                        acc[6] += dx * dd; acc[7] += dy * dd; acc[8] += dz * dd;
-                    }
+        // walk the candidates in the reference's order (all threads take the same decisions)
+        for (int j = 0; j < nb && !done; j++) {
+            no_sam++;
+            const int no_i = s_noi[j];
+            if (max_i < no_i) {                                        // :208 (s_no[j] >= 0: max_i only grows within a batch)
+                const int no = s_no[j];
+                if (no > no_i_c) {                                     // :229-236
+                    result[0] = s_refit[j][0]; result[1] = s_refit[j][1]; result[2] = s_refit[j][2];
+                    no_i_c = no;
+                    max_i = no_i;
+                    const int sc = ransac_sample_count(no, len, 3, conf);
+                    max_sam = max_sam < sc ? max_sam : sc;
                 }
             }
-            for (int k = 0; k < 9; k++) s_acc[tid][k] = acc[k];
-            __syncthreads();
-            if (tid == 0) {
-                double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int l = 0; l < kRansacThreads; l++)
-                    for (int k = 0; k < 9; k++) t[k] += s_acc[l][k];
-                double M[3][3] = {{t[0], t[1], t[2]}, {t[1], t[3], t[4]}, {t[2], t[4], t[5]}};
-                double rhs[3] = {t[6], t[7], t[8]};
-                float N[3];
-                solve_normal_3x3(M, rhs, N);                           // :224
-                s_N[0] = N[0]; s_N[1] = N[1]; s_N[2] = N[2];
-            }
-            __syncthreads();
-            const int no = count_inliers(len);                         // :225-227
-            if (no > no_i_c) {                                         // :229-236
-                result[0] = s_N[0]; result[1] = s_N[1]; result[2] = s_N[2];
-                no_i_c = no;
-                max_i = no_i;
-                const int sc = ransac_sample_count(no, len, 3, conf);
-                max_sam = max_sam < sc ? max_sam : sc;
-            }
-            __syncthreads();
+            if (no_sam >= max_sam) { done = true; state = s_state[j + 1]; }
         }
+        if (!done) state = s_state[nb];
+        __syncthreads();
     }
     if (tid == 0) {
         planes[cell] = make_float4(result[0], result[1], result[2], 0.0f);   // :239
-        rng[cell] = r.state;
+        rng[cell] = state;
     }
-    (void)s_flag;
 }
 
 }  // namespace les

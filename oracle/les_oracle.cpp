@@ -599,37 +599,22 @@ extern "C" int les_ransac_sample_count(int ni, int ptNum, int pf, double conf)
 // one-sided Jacobi SVD in float, so agreement is to float round-off, not bitwise).
 static void solve_svd_mx3(const float* A, const float* b, int m, float x[3])
 {
-    // Normal equations in double.  The accumulation order is part of this restatement's definition (the
-    // reference delegates to OpenCV's SVD, whose internal order is unknowable here): 64 interleaved
-    // partial sums (row i goes to partial i mod 64, rows in increasing order), combined in order 0..63.
-    // The device implementation (localexpstereo_amd/csrc/les_propose.h) uses the same order, so both
-    // produce bit-identical planes.
+    // Normal equations in double, rows accumulated in increasing order (the device implementation,
+    // localexpstereo_amd/csrc/les_propose.h, accumulates in the same order, so both give bit-identical planes;
+    // the reference delegates to OpenCV's float SVD whose internal order is unknowable here).
     double M[3][3] = {{0}}, rhs[3] = {0};
-    if (m <= 3) {
-        for (int i = 0; i < m; i++)
-            for (int r = 0; r < 3; r++) {
-                rhs[r] += (double)A[i * 3 + r] * b[i];
-                for (int c = 0; c < 3; c++) M[r][c] += (double)A[i * 3 + r] * A[i * 3 + c];
-            }
-    } else {
-        static thread_local double part[64][9];
-        for (int l = 0; l < 64; l++) for (int k = 0; k < 9; k++) part[l][k] = 0.0;
-        for (int i = 0; i < m; i++) {
-            double* t = part[i % 64];
-            const double dx = A[i * 3], dy = A[i * 3 + 1], dz = A[i * 3 + 2], d = b[i];
-            t[0] += dx * dx; t[1] += dx * dy; t[2] += dx * dz; t[3] += dy * dy; t[4] += dy * dz; t[5] += dz * dz;
-            t[6] += dx * d; t[7] += dy * d; t[8] += dz * d;
+    for (int i = 0; i < m; i++) {
+        const double c[3] = {A[i * 3], A[i * 3 + 1], A[i * 3 + 2]};
+        const double d = b[i];
+        for (int r = 0; r < 3; r++) {
+            rhs[r] += c[r] * d;
+            for (int q = 0; q < 3; q++) M[r][q] += c[r] * c[q];
         }
-        double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int l = 0; l < 64; l++) for (int k = 0; k < 9; k++) t[k] += part[l][k];
-        M[0][0] = t[0]; M[0][1] = M[1][0] = t[1]; M[0][2] = M[2][0] = t[2];
-        M[1][1] = t[3]; M[1][2] = M[2][1] = t[4]; M[2][2] = t[5];
-        rhs[0] = t[6]; rhs[1] = t[7]; rhs[2] = t[8];
     }
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; sweep++) {
+    for (int sweep = 0; sweep < 16; sweep++) {
         double off = fabs(M[0][1]) + fabs(M[0][2]) + fabs(M[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-15 * (fabs(M[0][0]) + fabs(M[1][1]) + fabs(M[2][2]))) break;   // off-diagonals at the rounding floor of the diagonal
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 if (fabs(M[p][q]) < 1e-300) continue;
