@@ -115,6 +115,13 @@ int les_hip_wta_update(les_hip_ctx* ctx, int n, const les_hip_rect* rects, const
                        int planes_on_device, float* cur_cost_dev, const float* prop_cost_dev,
                        les_hip_plane* labels_dev);
 
+/* ---- volume preparation on the device ("next" row N3 of the scope table) ----
+ * replaces: fillOutOfView (LES/main.cpp:146-176) and convertVolumeL2R (LES/main.cpp:178-199), margin 0, on a
+ * DEVICE float [D][H][W] volume (e.g. before handing it to les_hip_create with volumes_on_device).
+ * mode 0 = left view, 1 = right view.  Asynchronous on hip_stream (NULL = default stream) of `device`. */
+int les_hip_fill_out_of_view(float* vol_dev, int D, int H, int W, int mode, int device, void* hip_stream);
+int les_hip_convert_volume_l2r(const float* src_dev, float* dst_dev, int D, int H, int W, int device, void* hip_stream);
+
 /* Device memory helpers for callers without a HIP toolchain (host C++ adapter, ctypes). */
 int les_hip_malloc(les_hip_ctx* ctx, void** dev_ptr, size_t bytes);
 int les_hip_free(les_hip_ctx* ctx, void* dev_ptr);

@@ -22,6 +22,7 @@ SYMBOLS = [
     "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
+    "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r",
 ]
 
 
@@ -74,6 +75,8 @@ def load(path=None):
         "les_hip_memset": (ci, [vp, vp, ci, C.c_size_t]),
         "les_hip_get_stats": (ci, [vp, ci, vp]),
         "les_hip_strip_width": (ci, [ci]),
+        "les_hip_fill_out_of_view": (ci, [vp, ci, ci, ci, ci, ci, vp]),
+        "les_hip_convert_volume_l2r": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -103,6 +106,22 @@ def _planes(p):
     if p.dtype != PLANE_DT:
         p = np.ascontiguousarray(p, np.float32).reshape(-1, 4).view(PLANE_DT).reshape(-1)
     return np.ascontiguousarray(p)
+
+
+def fill_out_of_view(vol_dev_ptr, D, H, W, mode, device=0, stream=0, lib=None):
+    """fillOutOfView (LES/main.cpp:146-176) in place on a device volume."""
+    L = load(lib)
+    rc = L.les_hip_fill_out_of_view(C.c_void_p(int(vol_dev_ptr)), D, H, W, mode, device, C.c_void_p(int(stream)))
+    if rc:
+        raise LesHipError(L.les_hip_last_error().decode())
+
+
+def convert_volume_l2r(src_dev_ptr, dst_dev_ptr, D, H, W, device=0, stream=0, lib=None):
+    """convertVolumeL2R (LES/main.cpp:178-199): right-view volume synthesised from the left-view one."""
+    L = load(lib)
+    rc = L.les_hip_convert_volume_l2r(C.c_void_p(int(src_dev_ptr)), C.c_void_p(int(dst_dev_ptr)), D, H, W, device, C.c_void_p(int(stream)))
+    if rc:
+        raise LesHipError(L.les_hip_last_error().decode())
 
 
 class DeviceBuffer:

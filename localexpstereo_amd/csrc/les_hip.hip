@@ -51,8 +51,9 @@ const StripEntry kStrips[] = {
     // (WA 64, BY 21 = ring length, SEG 3, 3 waves/SIMD, 0 B scratch) 7.0 ms vs 9.2 ms for (128,16,8,2 waves) and
     // 12+ ms for anything that spills.
     LES_STRIP_ENTRY(1, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(2, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(3, 0, 64, 16, 4, 2),
-    LES_STRIP_ENTRY(5, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(8, 0, 64, 16, 4, 2),
-    LES_STRIP_ENTRY(10, 0, 64, 21, 3, 3),
+    LES_STRIP_ENTRY(4, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(5, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(6, 0, 64, 16, 4, 2),
+    LES_STRIP_ENTRY(7, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(8, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(9, 0, 64, 16, 4, 2),
+    LES_STRIP_ENTRY(10, 0, 64, 21, 3, 3), LES_STRIP_ENTRY(12, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(15, 0, 96, 16, 6, 2),
     // A/B variants for radius 10 (LES_HIP_VARIANT=n)
     LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
 };
@@ -102,6 +103,7 @@ struct les_hip_batch {
     les::WtaJob* d_targets = nullptr;
     float* d_ransac = nullptr;           // n * ransac_stride floats: disparity snapshot of every unit region
     int ransac_stride = 0;
+    int wta_chunks = 1;                  // blocks per target rect in the WTA kernel
 };
 
 namespace {
@@ -301,6 +303,11 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
     les_hip_batch* b = new les_hip_batch();
     b->n = n; b->njobs = (int)jobs.size(); b->out_slabs = out_slabs; b->R = c->R; b->device = c->p.device;
     b->targets.assign(trs, trs + n);
+    {
+        int max_area = 1;
+        for (int i = 0; i < n; i++) max_area = std::max(max_area, trs[i].w * trs[i].h);
+        b->wta_chunks = std::min(32, std::max(1, (max_area + 4095) / 4096));
+    }
     if (n > 0) {
         static_assert(sizeof(les::WtaJob) == sizeof(les_hip_rect), "rect layout");
         if (hipMalloc((void**)&b->d_targets, (size_t)n * sizeof(les::WtaJob)) != hipSuccess ||
@@ -392,7 +399,7 @@ int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plan
     if (!c || !b || !planes || !cur || !prop || !labels) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
     if (!b->d_targets) return fail(LES_HIP_ERR_ARG, "batch has no target table");
-    hipLaunchKernelGGL(les::les_wta_kernel, dim3(b->n), dim3(256), 0, c->stream, b->d_targets, reinterpret_cast<const float4*>(planes),
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, b->d_targets, reinterpret_cast<const float4*>(planes),
                        cur, prop, reinterpret_cast<float4*>(labels), c->p.W);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
@@ -487,8 +494,29 @@ int les_hip_wta_update(les_hip_ctx* c, int n, const les_hip_rect* rects, const l
         HIPCHECK(hipMemcpyAsync(c->d_wta_planes, planes, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         d_planes = c->d_wta_planes;
     }
-    hipLaunchKernelGGL(les::les_wta_kernel, dim3(n), dim3(256), 0, c->stream, c->d_wta, d_planes, cur, prop,
+    int max_area = 1;
+    for (int i = 0; i < n; i++) max_area = std::max(max_area, rects[i].w * rects[i].h);
+    const int chunks = std::min(32, std::max(1, (max_area + 4095) / 4096));
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(n, chunks), dim3(256), 0, c->stream, c->d_wta, d_planes, cur, prop,
                        reinterpret_cast<float4*>(labels), c->p.W);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_fill_out_of_view(float* vol, int D, int H, int W, int mode, int device, void* stream)
+{
+    if (!vol || D <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 1) return fail(LES_HIP_ERR_ARG, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    hipLaunchKernelGGL(les::les_fill_out_of_view_kernel, dim3((W + 255) / 256, H, D), dim3(256), 0, (hipStream_t)stream, vol, D, H, W, mode);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_convert_volume_l2r(const float* src, float* dst, int D, int H, int W, int device, void* stream)
+{
+    if (!src || !dst || src == dst || D <= 0 || H <= 0 || W <= 0) return fail(LES_HIP_ERR_ARG, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    hipLaunchKernelGGL(les::les_convert_l2r_kernel, dim3((W + 255) / 256, H, D), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }

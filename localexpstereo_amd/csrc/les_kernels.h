@@ -523,6 +523,35 @@ __global__ void les_stats_finish_kernel(const double* __restrict__ hs, float4* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Volume preparation ("next" row N3): LES/main.cpp:146-176 fillOutOfView and :178-199 convertVolumeL2R with
+// margin = 0 (interp_margin, LES/main.cpp:359).  grid = (ceil(W/256), H, D).
+// ---------------------------------------------------------------------------------------------------
+__global__ void les_fill_out_of_view_kernel(float* __restrict__ vol, int D, int H, int W, int mode)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y, d = (int)blockIdx.z;
+    float* row = vol + ((size_t)d * H + y) * W;
+    if (mode == 0) {                                    // left view: columns x < d see nothing -> first valid column
+        const int q = d < W - 1 ? d : W - 1;
+        if (x < q) row[x] = row[q];
+    } else {                                            // right view: columns x >= W-d -> last valid column
+        int p = W - d;
+        if (p < 1) p = 1;
+        if (x >= p && x < W) row[x] = row[p - 1];
+    }
+}
+
+__global__ void les_convert_l2r_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y, d = (int)blockIdx.z;
+    if (x >= W) return;
+    const float* s0 = src + ((size_t)d * H + y) * W;
+    float v;
+    if (d >= W) v = s0[x];                               // (the reference assumes d < W)
+    else v = x < W - 1 - d ? s0[x + d] : s0[W - 1];      // slice d shifted left by d, right edge replicated
+    dst[((size_t)d * H + y) * W + x] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // PatchMatch-style winner-take-all update (LES/FastGCStereo.h:56-60) for a batch of shared regions.
 // ---------------------------------------------------------------------------------------------------
 struct WtaJob { int x, y, w, h; };
@@ -533,7 +562,8 @@ __global__ void les_wta_kernel(const WtaJob* __restrict__ jobs, const float4* __
 {
     const WtaJob j = jobs[blockIdx.x];
     const float4 pl = planes[blockIdx.x];
-    for (int idx = (int)threadIdx.x; idx < j.w * j.h; idx += (int)blockDim.x) {
+    // grid = (regions, chunks): large shared regions (layer 2: ~400 x 390 px) are split over several blocks
+    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < j.w * j.h; idx += (int)(blockDim.x * gridDim.y)) {
         int yy = idx / j.w, xx = idx - yy * j.w;
         size_t k = (size_t)(j.y + yy) * W + j.x + xx;
         float pc = prop_cost[k];

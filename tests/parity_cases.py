@@ -468,3 +468,28 @@ def case_pm_iteration(pr, layers_units=(12, 36), seed=21, plane_exact=True):
     assert (rc2 < 1e5).mean() > 0.95 and (gc2 < 1e5).mean() > 0.95
     assert abs(e_got - e_ref) <= 0.02 * e_ref, (e_got, e_ref)
     return steps, worst
+
+
+def case_volume_preparation(pr, lib):
+    """N3: fillOutOfView / convertVolumeL2R on the device vs the oracle (bit exact), LES/main.cpp:146-199."""
+    import ctypes as C
+    L = om.lib()
+    rng = np.random.default_rng(5)
+    D, H, W = 9, 7, 40
+    vol = rng.random((D, H, W), dtype=np.float32)
+    src = api.DeviceBuffer(pr.e, vol.nbytes)
+    dst = api.DeviceBuffer(pr.e, vol.nbytes)
+    for mode in (0, 1):
+        ref = vol.copy()
+        L.les_fill_out_of_view(ref.ctypes.data_as(C.c_void_p), D, H, W, mode)
+        src.upload(vol)
+        api.fill_out_of_view(src.ptr, D, H, W, mode, lib=lib)
+        pr.e.synchronize()
+        assert src.download((D, H, W), np.float32).tobytes() == ref.tobytes()
+    ref = np.zeros_like(vol)
+    L.les_convert_volume_l2r(vol.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p), D, H, W)
+    src.upload(vol)
+    api.convert_volume_l2r(src.ptr, dst.ptr, D, H, W, lib=lib)
+    pr.e.synchronize()
+    assert dst.download((D, H, W), np.float32).tobytes() == ref.tobytes()
+    src.free(); dst.free()

@@ -79,7 +79,9 @@ def test_gpu_wta(mid):
 
 
 def test_gpu_other_radii(oracle_mod):
-    for windR, eps, th in ((4, 1e-3, 0.8), (10, 1e-4, 0.5), (16, 1e-5, 1.5)):
+    # guided-filter radius = windR / 2: every radius instantiated in csrc/les_hip.hip (1..10, 12, 15)
+    for windR, eps, th in ((2, 1e-2, 0.5), (4, 1e-3, 0.8), (6, 1e-4, 0.5), (8, 1e-4, 0.5), (10, 1e-4, 0.5), (12, 1e-4, 0.3),
+                           (14, 1e-4, 0.5), (16, 1e-5, 1.5), (18, 1e-4, 0.5), (24, 1e-4, 0.5), (30, 1e-3, 0.5)):
         pr = pc.synth_pair(None, 90, 130, 10, windR=windR, eps=eps, th_col=th)
         try:
             layer = pc.om.Layer(pr.W, pr.H, windR, 11)
@@ -175,3 +177,7 @@ def test_gpu_pm_iteration(oracle_mod):
         assert steps > 100 and worst <= pc.TIGHT
     finally:
         pr.close()
+
+
+def test_gpu_volume_preparation(cones):
+    pc.case_volume_preparation(cones, None)

@@ -67,6 +67,37 @@ def test_sim_small_radius(sim_lib, oracle_mod):
         pr.close()
 
 
+@pytest.mark.parametrize("windR", [8, 30])
+def test_sim_other_radii(sim_lib, oracle_mod, windR):
+    pr = pc.synth_pair(sim_lib, 60, 100, 6, windR=windR, eps=1e-4, th_col=0.5)
+    try:
+        layer = pc.om.Layer(pr.W, pr.H, windR, 13)
+        cells = layer.sets[1]
+        planes = pc.random_planes(len(cells), pr.D, pr.H, pr.W, 8)
+        ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+        got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+        pc.compare_maps(got, ref)
+    finally:
+        pr.close()
+
+
+def test_sim_min_disparity_and_unsupported(sim_lib, oracle_mod):
+    """MIN_DISPARITY != 0 (D0 = int(-MIN), LES/CostVolumeEnergy.h:67) and the error path for radii without a kernel."""
+    from localexpstereo_amd import api, synth
+    pr = pc.synth_pair(sim_lib, 50, 80, 8, max_disp=5.0, min_disp=-2.0)
+    try:
+        for pl in [(0.0, 0.0, 1.5, 0.0), (0.05, -0.02, -1.25, 0.0), (0.0, 0.0, -3.0, 0.0), (0.0, 0.0, 5.0, 0.0)]:
+            fr, tr = (5, 4, 70, 44), (25, 24, 30, 10)
+            ref = pr.o.unary(fr, tr, pl)
+            got = pr.e.ComputeUnaryPotential(fr, tr, np.full((pr.H, pr.W), np.nan, np.float32), pl)
+            pc.compare_maps(got, ref)
+    finally:
+        pr.close()
+    im, vol = synth.make_guide(40, 60, 1), synth.make_volume(4, 40, 60, 2)
+    with pytest.raises(api.LesHipError):
+        api.HipCostVolumeEnergy(im, None, vol, None, windR=44, lib=sim_lib)      # radius 22: no kernel instantiated
+
+
 def test_sim_empty_and_errors(cones):
     pc.case_empty_and_errors(cones)
 
@@ -98,3 +129,7 @@ def test_sim_pm_iteration(sim_lib, oracle_mod):
         assert steps > 100 and worst <= pc.TIGHT
     finally:
         pr.close()
+
+
+def test_sim_volume_preparation(cones, sim_lib):
+    pc.case_volume_preparation(cones, sim_lib)

@@ -56,7 +56,7 @@ static void fiber_entry()
     // returning resumes uc_link (the scheduler)
 }
 
-static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bx, unsigned by)
+static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz)
 {
     Block* B = &t_block;
     g_block = B;
@@ -79,7 +79,7 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     std::fill(B->done.begin(), B->done.end(), 0);
     gridDim = grid;
     blockDim = block;
-    blockIdx = dim3(bx, by, 0);
+    blockIdx = dim3(bx, by, bz);
     for (int i = 0; i < n; i++) {
         getcontext(&B->ctx[i]);
         B->ctx[i].uc_stack.ss_sp = &B->stacks[(size_t)i * kStack];
@@ -99,9 +99,10 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 {
-    const long nblocks = (long)grid.x * grid.y;
+    const long nblocks = (long)grid.x * grid.y * grid.z;
 #pragma omp parallel for schedule(dynamic, 1)
-    for (long b = 0; b < nblocks; b++) run_block(body, grid, block, (unsigned)(b % grid.x), (unsigned)(b / grid.x));
+    for (long b = 0; b < nblocks; b++)
+        run_block(body, grid, block, (unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
 }
 
 }  // namespace hipsim
