@@ -56,6 +56,7 @@ const StripEntry kStrips[] = {
     LES_STRIP_ENTRY(10, 0, 64, 21, 3, 3), LES_STRIP_ENTRY(12, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(15, 0, 96, 16, 6, 2),
     // A/B variants for radius 10 (LES_HIP_VARIANT=n)
     LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
+    LES_STRIP_ENTRY(10, 4, 96, 21, 4, 3), LES_STRIP_ENTRY(10, 5, 80, 21, 3, 3),
 };
 const StripEntry* find_strip(int R)
 {

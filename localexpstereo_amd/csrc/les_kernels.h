@@ -166,6 +166,12 @@ __device__ __forceinline__ int window_count(int c, int R, int lo, int hi)
 #else
 #define LES_SCHED_FENCE(step) do { if (((step) & 3) == 3) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
+// In phase V the rows are overlapped in groups of 3 (more would spill at the 168-VGPR occupancy target).
+#if defined(LES_SIM)
+#define LES_SCHED_FENCE_V(row) ((void)0)
+#else
+#define LES_SCHED_FENCE_V(row) do { if (((row) % 3) == 2) __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 template <int V>
 struct IntTag { static constexpr int value = V; };
@@ -207,20 +213,18 @@ struct VLane {
         constexpr int OLD = (S + RS - KS) % RS;
         S1 += (double)in - (double)ring1[OLD];             // sum over the last 2R+1 p-rows
         ring1[S] = in;
-        float val = 0.0f;
-        if (do_algebra) {
-            // LES/GuidedFilter.h:204-221 on the centred guide
-            const double m = S1 * rn1;                     // lane k<3: mean(I'_k p), lane 3: mean(p)
-            const double mp = quad_bcast<3>(m);
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in_clip && k < 3) s = st;
-            const float cov = (float)(m - (double)s.x * mp);   // cov_k = mean(I'_k p) - mean_I'_k * mean_p
-            const float ak = s.y * quad_bcast<0>(cov) + s.z * quad_bcast<1>(cov) + s.w * quad_bcast<2>(cov);
-            const float tk = ak * s.x;
-            const float bb = (float)mp - quad_bcast<0>(tk) - quad_bcast<1>(tk) - quad_bcast<2>(tk);
-            val = (k < 3) ? ak : bb;
-            if (!in_clip) val = 0.0f;                      // a, b are zero-padded outside the sub-region
-        }
+        // LES/GuidedFilter.h:204-221 on the centred guide.  No branch on do_algebra: straight-line code lets the
+        // scheduler overlap the dependent chains of consecutive rows (they only meet in S1 / S2).
+        const double m = S1 * rn1;                         // lane k<3: mean(I'_k p), lane 3: mean(p)
+        const double mp = quad_bcast<3>(m);
+        const bool use = in_clip && k < 3;
+        const float4 s = make_float4(use ? st.x : 0.f, use ? st.y : 0.f, use ? st.z : 0.f, use ? st.w : 0.f);
+        const float cov = (float)(m - (double)s.x * mp);   // cov_k = mean(I'_k p) - mean_I'_k * mean_p
+        const float ak = s.y * quad_bcast<0>(cov) + s.z * quad_bcast<1>(cov) + s.w * quad_bcast<2>(cov);
+        // b = mean_p - sum_k a_k mean_I'_k : lanes 0..2 contribute a_k * mean_I'_k, lane 3 contributes 0
+        const float bb = (float)mp - quad_sum(ak * s.x);
+        float val = (k < 3) ? ak : bb;
+        if (!(in_clip && do_algebra)) val = 0.0f;          // a, b are zero-padded outside the sub-region
         S2 += (double)val - (double)ring2[OLD];            // sum over the last 2R+1 stage-1 rows
         ring2[S] = val;
         return (float)S2;
@@ -407,6 +411,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                     const float o = vl.template step<BASE + i>(trow[i * TPITCH], t >= 2 * R, in_clip, rn1, pre[i % PD]);
                     pre[i % PD] = stats_row(t + PD);
                     s_T[i][vx * 4 + vk] = o;
+                    LES_SCHED_FENCE_V(i);
                 });
             };
             const int base = t0 % RS;

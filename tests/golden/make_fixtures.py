@@ -27,6 +27,12 @@ def main():
         rgb = np.asarray(Image.open(os.path.join(ref, name + ".png")).convert("RGB"))
         bgr = rgb[:, :, ::-1]
         out[name] = np.ascontiguousarray(bgr[150:246, 200:320])  # 96 rows x 120 cols
+    # wider right-view crop (the disparity search range of the crop) and the ground-truth crop, for the
+    # end-to-end quality test: groundtruth.png / scale (data/MiddV2/cones/info.txt: "4 59"), 0 = unknown
+    rgbR = np.asarray(Image.open(os.path.join(ref, "imR.png")).convert("RGB"))[:, :, ::-1]
+    out["imR_wide"] = np.ascontiguousarray(rgbR[150:246, 200 - 64:320])          # 96 rows x 184 cols, col 64 == x 200
+    gt = np.asarray(Image.open(os.path.join(ref, "groundtruth.png"))).astype(np.float32) / 4.0
+    out["gt"] = np.ascontiguousarray(gt[150:246, 200:320])
     np.savez_compressed(os.path.join(HERE, "cones_crop.npz"), **out)
 
     from oracle import oracle as om

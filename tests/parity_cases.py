@@ -493,3 +493,52 @@ def case_volume_preparation(pr, lib):
     pr.e.synchronize()
     assert dst.download((D, H, W), np.float32).tobytes() == ref.tobytes()
     src.free(); dst.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# end-to-end quality on real data (scaled to what can travel to the GPU box)
+# ------------------------------------------------------------------------------------------------
+def cones_ad_volume(D=64):
+    """Truncated absolute-difference matching cost between the cones crop and its (wider) right view:
+    vol[d][y][x] = mean_c |imL(y,x,c) - imR(y,x-d,c)| / 255.  Returns (imL, vol, gt)."""
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "cones_crop.npz"))
+    imL, imRw, gt = z["imL"], z["imR_wide"], z["gt"]
+    H, W = imL.shape[:2]
+    L = imL.astype(np.float32)
+    vol = np.empty((D, H, W), np.float32)
+    for d in range(D):
+        R = imRw[:, 64 - d:64 - d + W].astype(np.float32)
+        vol[d] = np.abs(L - R).mean(axis=2) / 255.0
+    return imL, vol, gt
+
+
+def case_quality_cones(lib, device, iters=3):
+    """PatchMatch iterations (MiddV2 layer set-up, LES/main.cpp:300-306, without the graph cut) on a crop of the
+    reference's bundled cones pair: the label map must converge towards the ground truth (Evaluator semantics,
+    LES/Evaluator.h:133-140: bad pixel = |d - gt| > threshold where gt is known)."""
+    import torch
+    from localexpstereo_amd import pm
+    imL, vol, gt = cones_ad_volume()
+    e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0, lib=lib)
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)],
+             [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]]
+    r = pm.PMRunner(e, (5, 15, 25), table, seed=11, device=device)
+    known = gt > 0
+
+    def bad(thr):
+        d = r.disparities().cpu().numpy()
+        return float((np.abs(d - gt)[known] > thr).mean() * 100)
+
+    r.init_labels()
+    e.synchronize()
+    hist = [(bad(1.0), float(r.cur.sum()))]
+    for it in range(iters):
+        r.iteration(it)
+        e.synchronize()
+        hist.append((bad(1.0), float(r.cur.sum())))
+    r.close()
+    e.close()
+    assert hist[0][0] > 80.0                                     # random initial labels
+    assert all(b[1] <= a[1] + 1e-3 for a, b in zip(hist, hist[1:])), hist      # WTA never increases the energy
+    assert hist[-1][0] < 20.0, hist                              # converged to the surface almost everywhere
+    return hist

@@ -181,3 +181,41 @@ def test_gpu_pm_iteration(oracle_mod):
 
 def test_gpu_volume_preparation(cones):
     pc.case_volume_preparation(cones, None)
+
+
+def test_gpu_quality_on_cones_crop():
+    hist = pc.case_quality_cones(None, "cuda", iters=3)
+    print("bad1.0 %, energy per iteration:", hist)
+
+
+def test_max_size_volume_32bit_offsets(oracle_mod):
+    """BASELINE configs[4] shape: 3000 x 2000 x 512 (12.3 GB, 3.07e9 floats: element offsets above 2^31).
+    Fronto-parallel planes in the lowest and the highest slices are checked against the oracle on host copies of
+    just those slices (same arithmetic: the lerp fraction is exact)."""
+    import torch
+    from localexpstereo_amd import api, synth
+    H, W, D = 2000, 3000, 512
+    free, _ = torch.cuda.mem_get_info()
+    if free < 16 * 2**30:
+        pytest.skip("not enough free HBM")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    vol = torch.rand((D, H, W), device="cuda", dtype=torch.float32, generator=gen)
+    guide = synth.make_guide(H, W, 99)
+    e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, volumes_on_device=True, shape=(D, H, W), max_disp=D - 1)
+    pr = type("P", (), {"e": e, "H": H, "W": W, "D": D})()
+    planes = np.array([[0, 0, 0.5, 0], [0, 0, 510.5, 0]], np.float32)
+    layer = pc.om.Layer(W, H, 20, 30)                                     # int(w * 0.01) at w = 3000
+    cells = layer.sets[7][::97]
+    for pl, lo in ((planes[0], 0), (planes[1], 509)):
+        sub = vol[lo:lo + 3].cpu().numpy()
+        o = pc.om.Oracle(guide, None, sub, None, max_disp=2.0)
+        pl_o = pl.copy()
+        pl_o[2] -= lo
+        n = len(cells)
+        got = e.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl[None], n, 0), check=False)
+        ref = o.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl_o[None], n, 0), check=False)
+        pc.compare_maps(got, ref)
+    e.close()
+    del vol
+    torch.cuda.empty_cache()

@@ -133,3 +133,13 @@ def test_sim_pm_iteration(sim_lib, oracle_mod):
 
 def test_sim_volume_preparation(cones, sim_lib):
     pc.case_volume_preparation(cones, sim_lib)
+
+
+def test_sim_quality_on_cones_crop(sim_lib):
+    """The same end-to-end check through the simulator build (1 iteration: the simulator is slow)."""
+    imL, vol, gt = pc.cones_ad_volume()
+    assert vol.shape == (64, 96, 120) and (gt > 0).mean() > 0.9
+    # ground-truth planes score far better than wrong ones under this volume (sanity of the cost construction)
+    ys, xs = np.mgrid[0:96, 0:120]
+    d = np.clip(np.rint(gt).astype(int), 0, 63)
+    assert float(vol[d, ys, xs][gt > 0].mean()) < 0.5 * float(vol[(d + 7) % 64, ys, xs][gt > 0].mean())
