@@ -47,6 +47,16 @@ def load(path=None):
     path = os.path.abspath(path or DEFAULT_LIB)
     if path in _libs:
         return _libs[path]
+    # PyTorch-ROCm bundles its own HIP runtime.  If this library initialises the system runtime first and torch
+    # initialises CUDA/HIP later in the same process, torch reports "No HIP GPUs are available".  Loading torch's
+    # runtime first makes both share one copy (bench.py / pm.py use torch tensors for device memory anyway).
+    if os.environ.get("LES_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise LesHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")

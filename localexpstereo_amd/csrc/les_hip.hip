@@ -71,6 +71,8 @@ const StripEntry* find_strip(int R)
     return def;
 }
 
+constexpr int kRansacMaxSam = 500;   // RansacProposer default MAX_SAM, LES/Proposer.h:265
+
 struct ViewData {
     float* vol = nullptr;
     bool own_vol = false;
@@ -102,8 +104,7 @@ struct les_hip_batch {
     // cell geometry for the proposers / WTA
     les::Rect4* d_units = nullptr;
     les::WtaJob* d_targets = nullptr;
-    float* d_ransac = nullptr;           // n * ransac_stride floats: disparity snapshot of every unit region
-    int ransac_stride = 0;
+    les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // RANSAC proposer scratch
     int wta_chunks = 1;                  // blocks per target rect in the WTA kernel
 };
 
@@ -333,7 +334,12 @@ void les_hip_batch_destroy(les_hip_batch* b)
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_units) (void)hipFree(b->d_units);
     if (b->d_targets) (void)hipFree(b->d_targets);
-    if (b->d_ransac) (void)hipFree(b->d_ransac);
+    if (b->rs.disp) (void)hipFree(b->rs.disp);
+    if (b->rs.idx) (void)hipFree(b->rs.idx);
+    if (b->rs.state) (void)hipFree(b->rs.state);
+    if (b->rs.noi) (void)hipFree(b->rs.noi);
+    if (b->rs.no) (void)hipFree(b->rs.no);
+    if (b->rs.refit) (void)hipFree(b->rs.refit);
     delete b;
 }
 
@@ -351,10 +357,18 @@ int les_hip_batch_set_units(les_hip_ctx* c, les_hip_batch* b, const les_hip_rect
     static_assert(sizeof(les::Rect4) == sizeof(les_hip_rect), "rect layout");
     if (!b->d_units) HIPCHECK(hipMalloc((void**)&b->d_units, (size_t)b->n * sizeof(les::Rect4)));
     HIPCHECK(hipMemcpy(b->d_units, units, (size_t)b->n * sizeof(les::Rect4), hipMemcpyHostToDevice));
-    if (b->d_ransac) HIPCHECK(hipFree(b->d_ransac));
-    b->d_ransac = nullptr;
-    b->ransac_stride = maxlen;
-    HIPCHECK(hipMalloc((void**)&b->d_ransac, (size_t)b->n * maxlen * sizeof(float)));
+    if (!b->rs.idx) {
+        const size_t n = (size_t)b->n, S = kRansacMaxSam;
+        HIPCHECK(hipMalloc((void**)&b->rs.idx, n * S * 3 * sizeof(int)));
+        HIPCHECK(hipMalloc((void**)&b->rs.state, n * (S + 1) * sizeof(uint64_t)));
+        HIPCHECK(hipMalloc((void**)&b->rs.noi, n * S * sizeof(int)));
+        HIPCHECK(hipMalloc((void**)&b->rs.no, n * S * sizeof(int)));
+        HIPCHECK(hipMalloc((void**)&b->rs.refit, n * S * 3 * sizeof(float)));
+    }
+    if (b->rs.disp) HIPCHECK(hipFree(b->rs.disp));
+    b->rs.disp = nullptr;
+    b->rs.stride = maxlen;
+    HIPCHECK(hipMalloc((void**)&b->rs.disp, (size_t)b->n * maxlen * sizeof(float)));
     return LES_HIP_OK;
 }
 
@@ -376,13 +390,11 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
         hipLaunchKernelGGL(les::les_random_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n, m, mind, maxd);
         break;
     case LES_HIP_PROPOSE_RANSAC:
-        // one candidate per lane: big unit regions get wider workgroups (more candidates in flight per batch)
-        if (b->ransac_stride > 1024)
-            hipLaunchKernelGGL(les::les_ransac_kernel<256>, dim3(n), dim3(256), 0, c->stream, b->d_units, lab, W, rng, pl,
-                               b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
-        else
-            hipLaunchKernelGGL(les::les_ransac_kernel<64>, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl,
-                               b->d_ransac, b->ransac_stride, 500, 0.95f, 1.0f);
+        // RansacProposer(K, MAX_SAM = 500, conf = 0.95), threshold 1.0 (LES/Proposer.h:265,305)
+        hipLaunchKernelGGL(les::les_ransac_snapshot_kernel, dim3(n), dim3(256), 0, c->stream, b->d_units, lab, W, b->rs);
+        hipLaunchKernelGGL(les::les_ransac_draw_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, b->rs, n, kRansacMaxSam);
+        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 63) / 64), dim3(64), 0, c->stream, b->d_units, b->rs, kRansacMaxSam, 1.0f);
+        hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f);
         break;
     case LES_HIP_PROPOSE_INIT:
         hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, mind, maxd);

@@ -11,8 +11,8 @@
 // Kernels:
 //   les_expansion_kernel : ExpansionProposer::getNextProposal      (LES/Proposer.h:69-75)
 //   les_random_kernel    : RandomProposer::getNextProposal         (LES/Proposer.h:120-148)
-//   les_ransac_kernel    : RansacProposer::startIterations + RANSACPlane (LES/Proposer.h:177-301), one
-//                          64-thread workgroup per cell
+//   les_ransac_{snapshot,draw,eval,walk}_kernel : RansacProposer::startIterations + RANSACPlane
+//                          (LES/Proposer.h:177-301), one lane per (cell, candidate)
 //   les_init_labels_kernel : FastGCStereo::initCurrentFast label part (LES/FastGCStereo.h:105-109)
 #pragma once
 
@@ -202,38 +202,77 @@ __device__ inline int ransac_sample_count(int ni, int ptNum, int pf, double conf
     return cnt < 1 ? 1 : cnt;
 }
 
-// RANSACPlane (LES/Proposer.h:177-240) with the reference's sequential semantics, evaluated NTHR samples at
-// a time.  The samples of a batch are drawn in order by one lane (the generator is sequential); then every
-// lane owns one candidate: it solves the 3-point plane, counts its inliers and -- if the candidate could
-// trigger the reference's "better than max_i" branch -- also computes the least-squares refit on the inliers
-// among the first no_i points and the refit's inlier count.  None of that depends on the evolving RANSAC
-// state, so it is embarrassingly parallel.  Finally the candidates are walked IN ORDER with the reference's
-// acceptance / adaptive-termination logic on the precomputed numbers.  Candidates beyond the point where the
-// sequential algorithm stops are discarded and the generator state is rewound to the last consumed sample, so
-// result and state are exactly those of the sequential algorithm.
-template <int NTHR>
-__global__ void __launch_bounds__(NTHR)
-les_ransac_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W,
-                  uint64_t* __restrict__ rng, float4* __restrict__ planes, float* __restrict__ disp_scratch,
-                  int scratch_stride, int MAX_SAM, float conf, float threshold)
-{
-    const int cell = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const Rect4 u = units[cell];
-    const int len = u.w * u.h;
-    float* disp = disp_scratch + (size_t)cell * scratch_stride;
-    __shared__ int s_idx[NTHR][3];
-    __shared__ uint64_t s_state[NTHR + 1];
-    __shared__ float s_refit[NTHR][3];
-    __shared__ int s_noi[NTHR], s_no[NTHR];
+// RANSACPlane (LES/Proposer.h:177-240) with the reference's sequential semantics, split so that the whole GPU
+// works even when a disjoint set has only a handful of (large) cells:
+//   snapshot : disparities of the unit region under the current labelling (startIterations, :283-301)
+//   draw     : one lane per cell draws ALL MAX_SAM sample triples in order (the generator is sequential) and
+//              records the generator state after every sample
+//   eval     : one lane per (cell, candidate): solves the 3-point plane, counts its inliers and -- if the candidate
+//              could ever trigger the "better than max_i" branch (no_i > 3) -- computes the least-squares refit on
+//              the inliers among the first no_i points and the refit's inlier count.  None of this depends on the
+//              evolving RANSAC state, so it is embarrassingly parallel over candidates.
+//   walk     : one lane per cell replays the reference's acceptance / adaptive-termination logic over the
+//              precomputed candidates IN ORDER, stops where the sequential algorithm stops and rewinds the
+//              generator to the last consumed sample.
+// Result and generator state are exactly those of the sequential algorithm.
+struct RansacScratch {
+    float* disp;       // [n][stride]            disparity snapshot
+    int* idx;          // [n][MAX_SAM][3]        sample triples
+    uint64_t* state;   // [n][MAX_SAM + 1]       generator state before sample j
+    int* noi;          // [n][MAX_SAM]           inliers of the 3-point plane
+    int* no;           // [n][MAX_SAM]           inliers of the refit (-1: not computed)
+    float* refit;      // [n][MAX_SAM][3]        refitted plane
+    int stride;
+};
 
-    // startIterations snapshot (:283-301)
-    for (int i = tid; i < len; i += NTHR) {
+__global__ void les_ransac_snapshot_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W, RansacScratch sc)
+{
+    const int cell = (int)blockIdx.x;
+    const Rect4 u = units[cell];
+    float* disp = sc.disp + (size_t)cell * sc.stride;
+    for (int i = (int)threadIdx.x; i < u.w * u.h; i += (int)blockDim.x) {
         const int yy = i / u.w, xx = i - yy * u.w;
         const float c0 = (float)xx + u.x, c1 = (float)yy + u.y;
         const float4 v = labels[(size_t)(yy + u.y) * W + xx + u.x];
         disp[i] = v.x * c0 + v.y * c1 + v.z;                           // :297
     }
-    __syncthreads();
+}
+
+__global__ void les_ransac_draw_kernel(const Rect4* __restrict__ units, const uint64_t* __restrict__ rng, RansacScratch sc, int n, int MAX_SAM)
+{
+    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cell >= n) return;
+    const Rect4 u = units[cell];
+    const int len = u.w * u.h;
+    Rng r{rng[cell]};
+    int* idxp = sc.idx + (size_t)cell * MAX_SAM * 3;
+    uint64_t* st = sc.state + (size_t)cell * (MAX_SAM + 1);
+    st[0] = r.state;
+    for (int j = 0; j < MAX_SAM; j++) {
+        // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
+        int idx[3];
+        for (int i = 0; i < 3; i++) {
+            bool again;
+            do {
+                idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
+                again = false;
+                for (int q = 0; q < i; q++) if (idx[q] == idx[i] && len > i) again = true;
+            } while (again);
+        }
+        idxp[j * 3 + 0] = idx[0]; idxp[j * 3 + 1] = idx[1]; idxp[j * 3 + 2] = idx[2];
+        st[j + 1] = r.state;
+    }
+}
+
+__global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold)
+{
+    const int cell = (int)blockIdx.x;
+    const int j = (int)(blockIdx.y * blockDim.x + threadIdx.x);
+    if (j >= MAX_SAM) return;
+    const Rect4 u = units[cell];
+    const int len = u.w * u.h;
+    const float* disp = sc.disp + (size_t)cell * sc.stride;
+    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + j) * 3;
 
     // visits the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
     auto scan = [&](int upto, const float N[3], auto&& f) {
@@ -250,95 +289,74 @@ les_ransac_kernel(const Rect4* __restrict__ units, const float4* __restrict__ la
         }
     };
 
-    uint64_t state = rng[cell];
-    int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;
-    float result[3] = {0, 0, 0};
-    bool done = false;
-    while (!done && no_sam < max_sam) {
-        const int nb = (max_sam - no_sam) < NTHR ? (max_sam - no_sam) : NTHR;
-        if (tid == 0) {
-            Rng r{state};
-            s_state[0] = state;
-            for (int j = 0; j < nb; j++) {
-                // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
-                int idx[3];
-                for (int i = 0; i < 3; i++) {
-                    bool again;
-                    do {
-                        idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
-                        again = false;
-                        for (int q = 0; q < i; q++) if (idx[q] == idx[i] && len > i) again = true;
-                    } while (again);
-                }
-                s_idx[j][0] = idx[0]; s_idx[j][1] = idx[1]; s_idx[j][2] = idx[2];
-                s_state[j + 1] = r.state;
-            }
+    double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        const int id = idxp[i];
+        const int yy = id / u.w, xx = id - yy * u.w;
+        const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
+        const double d = disp[id];
+        for (int a = 0; a < 3; a++) {
+            rhs[a] += c[a] * d;
+            for (int b = 0; b < 3; b++) M[a][b] += c[a] * c[b];
         }
-        __syncthreads();
-        if (tid < nb) {
-            double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
-            for (int i = 0; i < 3; i++) {
-                const int id = s_idx[tid][i];
-                const int yy = id / u.w, xx = id - yy * u.w;
-                const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
-                const double d = disp[id];
+    }
+    float N[3];
+    solve_normal_3x3(M, rhs, N);                                       // cv::solve(ranpts, div, N, DECOMP_SVD) :203
+    int no_i = 0;
+    scan(len, N, [&](float, float, float, bool in) { no_i += in; });  // :204-206
+    int no = -1;
+    float N2[3] = {0, 0, 0};
+    if (no_i > 3) {                                                    // max_i starts at 3 and only grows (:180,:234)
+        // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound quirk,
+        // :216), rows accumulated in increasing order like oracle/les_oracle.cpp:solve_svd_mx3
+        double A[3][3] = {{0}}, r3[3] = {0, 0, 0};
+        scan(no_i, N, [&](float x, float y, float d, bool in) {
+            if (in) {
+                const double c[3] = {(double)x, (double)y, 1.0};
+                const double dd = d;
                 for (int a = 0; a < 3; a++) {
-                    rhs[a] += c[a] * d;
-                    for (int b = 0; b < 3; b++) M[a][b] += c[a] * c[b];
+                    r3[a] += c[a] * dd;
+                    for (int b = 0; b < 3; b++) A[a][b] += c[a] * c[b];
                 }
             }
-            float N[3];
-            solve_normal_3x3(M, rhs, N);                               // cv::solve(ranpts, div, N, DECOMP_SVD) :203
-            int no_i = 0;
-            scan(len, N, [&](float, float, float, bool in) { no_i += in; });          // :204-206
-            s_noi[tid] = no_i;
-            s_no[tid] = -1;
-            if (no_i > max_i) {
-                // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound
-                // quirk, :216), rows accumulated in increasing order like oracle/les_oracle.cpp:solve_svd_mx3
-                double A[3][3] = {{0}}, r3[3] = {0, 0, 0};
-                scan(no_i, N, [&](float x, float y, float d, bool in) {
-                    if (in) {
-                        const double c[3] = {(double)x, (double)y, 1.0};
-                        const double dd = d;
-                        for (int a = 0; a < 3; a++) {
-                            r3[a] += c[a] * dd;
-                            for (int b = 0; b < 3; b++) A[a][b] += c[a] * c[b];
-                        }
-                    }
-                });
-                float N2[3];
-                solve_normal_3x3(A, r3, N2);                           // :224
-                int no = 0;
-                scan(len, N2, [&](float, float, float, bool in) { no += in; });      // :225-227
-                s_refit[tid][0] = N2[0]; s_refit[tid][1] = N2[1]; s_refit[tid][2] = N2[2];
-                s_no[tid] = no;
+        });
+        solve_normal_3x3(A, r3, N2);                                   // :224
+        no = 0;
+        scan(len, N2, [&](float, float, float, bool in) { no += in; });   // :225-227
+    }
+    const size_t o = (size_t)cell * MAX_SAM + j;
+    sc.noi[o] = no_i;
+    sc.no[o] = no;
+    sc.refit[o * 3 + 0] = N2[0]; sc.refit[o * 3 + 1] = N2[1]; sc.refit[o * 3 + 2] = N2[2];
+}
+
+__global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t* __restrict__ rng, float4* __restrict__ planes,
+                                       RansacScratch sc, int n, int MAX_SAM, float conf)
+{
+    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cell >= n) return;
+    const Rect4 u = units[cell];
+    const int len = u.w * u.h;
+    const size_t base = (size_t)cell * MAX_SAM;
+    int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;          // :180-185
+    float result[3] = {0, 0, 0};
+    while (no_sam < max_sam) {                                         // :193
+        const int j = no_sam;
+        no_sam++;
+        const int no_i = sc.noi[base + j];
+        if (max_i < no_i) {                                            // :208
+            const int no = sc.no[base + j];
+            if (no > no_i_c) {                                         // :229-236
+                result[0] = sc.refit[(base + j) * 3]; result[1] = sc.refit[(base + j) * 3 + 1]; result[2] = sc.refit[(base + j) * 3 + 2];
+                no_i_c = no;
+                max_i = no_i;
+                const int cnt = ransac_sample_count(no, len, 3, conf);
+                max_sam = max_sam < cnt ? max_sam : cnt;
             }
         }
-        __syncthreads();
-        // walk the candidates in the reference's order (all threads take the same decisions)
-        for (int j = 0; j < nb && !done; j++) {
-            no_sam++;
-            const int no_i = s_noi[j];
-            if (max_i < no_i) {                                        // :208 (s_no[j] >= 0: max_i only grows within a batch)
-                const int no = s_no[j];
-                if (no > no_i_c) {                                     // :229-236
-                    result[0] = s_refit[j][0]; result[1] = s_refit[j][1]; result[2] = s_refit[j][2];
-                    no_i_c = no;
-                    max_i = no_i;
-                    const int sc = ransac_sample_count(no, len, 3, conf);
-                    max_sam = max_sam < sc ? max_sam : sc;
-                }
-            }
-            if (no_sam >= max_sam) { done = true; state = s_state[j + 1]; }
-        }
-        if (!done) state = s_state[nb];
-        __syncthreads();
     }
-    if (tid == 0) {
-        planes[cell] = make_float4(result[0], result[1], result[2], 0.0f);   // :239
-        rng[cell] = state;
-    }
+    planes[cell] = make_float4(result[0], result[1], result[2], 0.0f);   // :239
+    rng[cell] = sc.state[(size_t)cell * (MAX_SAM + 1) + no_sam];          // state after the last consumed sample
 }
 
 }  // namespace les

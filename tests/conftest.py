@@ -18,3 +18,15 @@ def oracle_mod():
     om.build()
     om.lib()
     return om
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """See localexpstereo_amd/api.py:load -- torch's bundled HIP runtime must be initialised before ours."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
