@@ -393,7 +393,7 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
         // RansacProposer(K, MAX_SAM = 500, conf = 0.95), threshold 1.0 (LES/Proposer.h:265,305)
         hipLaunchKernelGGL(les::les_ransac_snapshot_kernel, dim3(n), dim3(256), 0, c->stream, b->d_units, lab, W, b->rs);
         hipLaunchKernelGGL(les::les_ransac_draw_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, b->rs, n, kRansacMaxSam);
-        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 63) / 64), dim3(64), 0, c->stream, b->d_units, b->rs, kRansacMaxSam, 1.0f);
+        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 15) / 16), dim3(64), 0, c->stream, b->d_units, b->rs, kRansacMaxSam, 1.0f);
         hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f);
         break;
     case LES_HIP_PROPOSE_INIT:

@@ -264,20 +264,27 @@ __global__ void les_ransac_draw_kernel(const Rect4* __restrict__ units, const ui
     }
 }
 
+// One QUAD of lanes per (cell, candidate): lane s of the quad scans the rows yy = s (mod 4) of the unit region.
+// Inlier counts are integer sums over the quad.  The normal equations of the refit are accumulated per lane in
+// increasing (row, column) order and combined as (p0 + p1) + (p2 + p3) -- oracle/les_oracle.cpp:solve_svd_mx3
+// uses the same order (row_width argument), so both give bit-identical planes.
 __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold)
 {
     const int cell = (int)blockIdx.x;
-    const int j = (int)(blockIdx.y * blockDim.x + threadIdx.x);
-    if (j >= MAX_SAM) return;
+    const int tid = (int)threadIdx.x;
+    const int j = (int)blockIdx.y * ((int)blockDim.x / 4) + (tid >> 2);    // candidate
+    const int sub = tid & 3;                                               // row phase of this lane
+    const bool live = j < MAX_SAM;                                          // whole quads are live or not
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     const float* disp = sc.disp + (size_t)cell * sc.stride;
-    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + j) * 3;
+    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + (live ? j : 0)) * 3;
 
-    // visits the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
+    // visits this lane's rows of the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
     auto scan = [&](int upto, const float N[3], auto&& f) {
-        int i = 0;
-        for (int yy = 0; yy < u.h && i < upto; yy++) {
+        for (int yy = sub; yy < u.h; yy += 4) {
+            int i = yy * u.w;
+            if (i >= upto) break;
             const float y = (float)yy + u.y;
             const double ty = (double)y * N[1];
             for (int xx = 0; xx < u.w && i < upto; xx++, i++) {
@@ -301,33 +308,39 @@ __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacSc
         }
     }
     float N[3];
-    solve_normal_3x3(M, rhs, N);                                       // cv::solve(ranpts, div, N, DECOMP_SVD) :203
-    int no_i = 0;
-    scan(len, N, [&](float, float, float, bool in) { no_i += in; });  // :204-206
+    solve_normal_3x3(M, rhs, N);                                       // cv::solve(ranpts, div, N, DECOMP_SVD) :203 (all 4 lanes: same result)
+    int cnt = 0;
+    scan(len, N, [&](float, float, float, bool in) { cnt += in; });   // :204-206
+    const int no_i = quad_sum(cnt);
     int no = -1;
     float N2[3] = {0, 0, 0};
-    if (no_i > 3) {                                                    // max_i starts at 3 and only grows (:180,:234)
-        // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound quirk,
-        // :216), rows accumulated in increasing order like oracle/les_oracle.cpp:solve_svd_mx3
-        double A[3][3] = {{0}}, r3[3] = {0, 0, 0};
+    // max_i starts at 3 and only grows (:180,:234): candidates with no_i <= 3 can never enter the refit branch.
+    // no_i is uniform over the quad, so the quad operations below are executed by whole quads.
+    if (no_i > 3) {
+        // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound quirk, :216)
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                   // xx xy x yy y 1 | xd yd d
         scan(no_i, N, [&](float x, float y, float d, bool in) {
             if (in) {
-                const double c[3] = {(double)x, (double)y, 1.0};
-                const double dd = d;
-                for (int a = 0; a < 3; a++) {
-                    r3[a] += c[a] * dd;
-                    for (int b = 0; b < 3; b++) A[a][b] += c[a] * c[b];
-                }
+                const double dx = x, dy = y, dd = d;
+                acc[0] += dx * dx; acc[1] += dx * dy; acc[2] += dx; acc[3] += dy * dy; acc[4] += dy; acc[5] += 1.0;
+                acc[6] += dx * dd; acc[7] += dy * dd; acc[8] += dd;
             }
         });
+        double t[9];
+        for (int k = 0; k < 9; k++) t[k] = quad_sum(acc[k]);
+        double A[3][3] = {{t[0], t[1], t[2]}, {t[1], t[3], t[4]}, {t[2], t[4], t[5]}};
+        double r3[3] = {t[6], t[7], t[8]};
         solve_normal_3x3(A, r3, N2);                                   // :224
-        no = 0;
-        scan(len, N2, [&](float, float, float, bool in) { no += in; });   // :225-227
+        int c2 = 0;
+        scan(len, N2, [&](float, float, float, bool in) { c2 += in; });   // :225-227
+        no = quad_sum(c2);
     }
-    const size_t o = (size_t)cell * MAX_SAM + j;
-    sc.noi[o] = no_i;
-    sc.no[o] = no;
-    sc.refit[o * 3 + 0] = N2[0]; sc.refit[o * 3 + 1] = N2[1]; sc.refit[o * 3 + 2] = N2[2];
+    if (live && sub == 0) {
+        const size_t o = (size_t)cell * MAX_SAM + j;
+        sc.noi[o] = no_i;
+        sc.no[o] = no;
+        sc.refit[o * 3 + 0] = N2[0]; sc.refit[o * 3 + 1] = N2[1]; sc.refit[o * 3 + 2] = N2[2];
+    }
 }
 
 __global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t* __restrict__ rng, float4* __restrict__ planes,

@@ -59,6 +59,11 @@ __device__ __forceinline__ double quad_bcast(double v)
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
+__device__ __forceinline__ int quad_perm(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
 __device__ __forceinline__ float quad_perm(float v)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
