@@ -44,7 +44,7 @@ _libs = {}
 
 def load(path=None):
     """Load the C-ABI library (default: the in-tree HIP build).  Raises if it does not exist."""
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.abspath(path or os.environ.get("LES_HIP_LIB") or DEFAULT_LIB)     # LES_HIP_LIB: A/B builds of the same ABI
     if path in _libs:
         return _libs[path]
     # PyTorch-ROCm bundles its own HIP runtime.  If this library initialises the system runtime first and torch

@@ -173,6 +173,12 @@ __device__ __forceinline__ int window_count(int c, int R, int lo, int hi)
 #define LES_SCHED_FENCE_V(row) do { if (((row) % 3) == 2) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
+#ifndef LES_H1_F32
+typedef double H1ACC;
+#else
+typedef float H1ACC;      // experiment: fp32 running sums in the H1 chains (their output is rounded to fp32 anyway)
+#endif
+
 template <int V>
 struct IntTag { static constexpr int value = V; };
 
@@ -381,13 +387,13 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             float ring[KS];
 #pragma unroll
             for (int i = 0; i < KS; i++) ring[i] = 0.0f;
-            double S = 0.0;
+            H1ACC S = 0;
             const int x0 = hseg * L1;
 #pragma unroll
             for (int s = 0; s < L1 + 2 * R; s++) {
                 const int xi = x0 + s;                                  // p column index
                 const float f = xi < WP ? guide_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi] : 0.0f;
-                S += (double)f - (double)ring[s % KS];
+                S += (H1ACC)f - (H1ACC)ring[s % KS];
                 ring[s % KS] = f;
                 if (s >= 2 * R && x0 + s - 2 * R < WA) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)S;
                 LES_SCHED_FENCE(s);

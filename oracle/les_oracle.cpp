@@ -337,6 +337,10 @@ struct les_oracle {
     const float* vol[2];
     GuideStats<double> gd[2];
     GuideStats<float> gf[2];
+    // NaiveStereoEnergy (LES/StereoEnergy.h:629-764): kind == 1
+    int kind = 0;
+    std::vector<float> ExI[2];        // H x W x 4: (1-alpha)*B, (1-alpha)*G, (1-alpha)*R, alpha*Gx
+    float thresh_color = 0, thresh_gradient = 0;
 };
 
 extern "C" les_oracle* les_oracle_create(const uint8_t* imL, const uint8_t* imR, int H, int W,
@@ -356,7 +360,67 @@ extern "C" les_oracle* les_oracle_create(const uint8_t* imL, const uint8_t* imR,
     }
     return o;
 }
+// NaiveStereoEnergy constructor, LES/StereoEnergy.h:638-689 (filterName "GF").  [recollection] of the OpenCV calls:
+// convertTo(CV_32F) of the 8-bit image; cvtColor(BGR2GRAY) on float = 0.114 B + 0.587 G + 0.299 R;
+// Sobel(dx=1, dy=0, ksize=1, scale=0.5, BORDER_REPLICATE) = 0.5 * (g(x+1) - g(x-1)).
+extern "C" les_oracle* les_oracle_create_naive(const uint8_t* imL, const uint8_t* imR, int H, int W, int windR, double eps,
+                                               float alpha, float th_col, float th_grad, float max_disparity, float min_disparity)
+{
+    les_oracle* o = new les_oracle();
+    o->kind = 1;
+    o->H = H; o->W = W; o->D = 0; o->windR = windR; o->use_float = 0;
+    o->th_col = th_col; o->MAXD = max_disparity; o->MIND = min_disparity;
+    o->vol[0] = o->vol[1] = nullptr;
+    o->thresh_color = th_col * (1.0f - alpha);                                      // :662
+    o->thresh_gradient = th_grad * alpha;                                           // :663
+    const uint8_t* im[2] = {imL, imR};
+    const size_t P = (size_t)H * W;
+    for (int m = 0; m < 2; m++) {
+        o->gd[m].build(im[m], H, W, windR / 2, eps, 1.0 / 255);                     // :673-674
+        std::vector<float> gray(P);
+        for (size_t i = 0; i < P; i++)
+            gray[i] = (float)im[m][i * 3] * 0.114f + (float)im[m][i * 3 + 1] * 0.587f + (float)im[m][i * 3 + 2] * 0.299f;   // :651
+        o->ExI[m].resize(P * 4);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const size_t i = (size_t)y * W + x;
+                const float gx = 0.5f * (gray[(size_t)y * W + std::min(x + 1, W - 1)] - gray[(size_t)y * W + std::max(x - 1, 0)]);   // :654
+                for (int c = 0; c < 3; c++) o->ExI[m][i * 4 + c] = (float)((double)im[m][i * 3 + c] * (1.0 - (double)alpha));          // :658
+                o->ExI[m][i * 4 + 3] = gx * alpha;                                                                                     // :659
+            }
+    }
+    return o;
+}
 extern "C" void les_oracle_destroy(les_oracle* o) { delete o; }
+
+// NaiveStereoEnergy::ComputeUnaryPotentialWithoutCheck raw-cost part, LES/StereoEnergy.h:702-742.  The affine map
+// through the three corner points reproduces the plane warp x_src = x - sign * (a x + b y + c), y_src = y exactly
+// (the plane is affine).  [recollection] cv::warpAffine(INTER_LINEAR, BORDER_REPLICATE) on float images: source
+// coordinates are quantised to 1/32 pixel, bilinear weights from that fraction.  Tolerance-level restatement only.
+static void naive_raw(const les_oracle* o, int mode, les_rect fr, les_plane plane, float* raw)
+{
+    const float sign = mode ? -1.f : 1.f;
+    const std::vector<float>& I0 = o->ExI[mode];
+    const std::vector<float>& I1 = o->ExI[1 - mode];
+    const int W = o->W;
+    for (int y = 0; y < fr.h; y++)
+        for (int x = 0; x < fr.w; x++) {
+            const int X = fr.x + x, Y = fr.y + y;
+            const float z = plane.a * (float)X + plane.b * (float)Y + plane.c;
+            const double sx = (double)X - (double)sign * z;
+            const double q = std::floor(sx * 32.0 + 0.5) / 32.0;                     // INTER_BITS = 5
+            const int x0 = (int)std::floor(q);
+            const float w1 = (float)(q - x0), w0 = 1.0f - w1;
+            const int xa = std::min(std::max(x0, 0), W - 1), xb = std::min(std::max(x0 + 1, 0), W - 1);
+            const float* a = &I1[((size_t)Y * W + xa) * 4];
+            const float* b = &I1[((size_t)Y * W + xb) * 4];
+            const float* p0 = &I0[((size_t)Y * W + X) * 4];
+            float v[4];
+            for (int c = 0; c < 4; c++) v[c] = w0 * a[c] + w1 * b[c];
+            const float col = std::fabs(p0[0] - v[0]) + std::fabs(p0[1] - v[1]) + std::fabs(p0[2] - v[2]);
+            raw[(size_t)y * fr.w + x] = std::min(o->thresh_color, col) + std::min(o->thresh_gradient, std::fabs(p0[3] - v[3]));   // :738-740
+        }
+}
 
 extern "C" void les_oracle_get_stats(const les_oracle* o, int mode, double* out)
 {
@@ -449,8 +513,9 @@ extern "C" void les_oracle_unary_nocheck(const les_oracle* o, int mode, les_rect
     // recreated per call here; it only caches, it does not change results.
     static thread_local std::vector<float> pIL, q;
     pIL.resize((size_t)fr.w * fr.h); q.resize((size_t)fr.w * fr.h);
-    les_oracle_gather(o, mode, fr, plane, pIL.data());
-    les_oracle_filter_subregion(o, mode, fr, pIL.data(), q.data());                  // :171
+    if (o->kind == 1) naive_raw(o, mode, fr, plane, pIL.data());                     // LES/StereoEnergy.h:730-742
+    else les_oracle_gather(o, mode, fr, plane, pIL.data());
+    les_oracle_filter_subregion(o, mode, fr, pIL.data(), q.data());                  // :171 / LES/StereoEnergy.h:747
     int sx = tr.x - fr.x, sy = tr.y - fr.y;                                          // :169 subrect = targetRect - filterRect.tl()
     for (int y = 0; y < tr.h; y++)
         for (int x = 0; x < tr.w; x++)
@@ -738,6 +803,62 @@ extern "C" les_plane les_ransac_proposal(les_rng* r, const les_plane* labels, in
         }
     }
     return les_plane{result[0], result[1], result[2], 0.0f};                         // :239
+}
+
+// =====================================================================================================
+// One disjoint set of cells of the PatchMatch-style loop, in the REFERENCE's own order (LES/FastGCStereo.h:30-64
+// with doGC == false): OpenMP over cells; per cell: for each proposer, for each of its proposals:
+// propose -> ComputeUnaryPotential(filter, shared) -> WTA update of cost and labels over the shared region.
+// kinds[j] in {0: Expansion, 1: Random, 2: Ransac}, Ks[j] proposals each.  states: one generator per cell.
+// prop_cost: scratch H x W map (like proposalCost, :25).
+// =====================================================================================================
+extern "C" void les_oracle_pm_set(const les_oracle* o, int mode, int n, const les_rect* units, const les_rect* shared,
+                                  const les_rect* filter, uint64_t* states, int nprop, const int* kinds, const int* Ks,
+                                  les_plane* labels, float* cur_cost, float* prop_cost, int iteration, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const int W = o->W;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        les_rng r{states[i]};
+        for (int j = 0; j < nprop; j++) {
+            for (int it = 0; it < Ks[j]; it++) {
+                if (kinds[j] == 1 && !les_random_is_continued(it, Ks[j], iteration, o->MIND, o->MAXD)) break;   // LES/Proposer.h:149-152
+                les_plane label;
+                if (kinds[j] == 0) label = les_expansion_proposal(&r, labels, W, units[i]);
+                else if (kinds[j] == 1) label = les_random_proposal(&r, labels, W, units[i], iteration + it, o->MIND, o->MAXD);
+                else label = les_ransac_proposal(&r, labels, W, units[i], 500, 0.95f, 1.0f);
+                les_oracle_unary(o, mode, filter[i], shared[i], prop_cost + (size_t)filter[i].y * W + filter[i].x, W, label);   // :49
+                les_oracle_wta_update(W, shared[i], cur_cost, prop_cost, labels, label);                                        // :57-60
+            }
+        }
+        states[i] = r.state;
+    }
+}
+
+// initCurrentFast, LES/FastGCStereo.h:94-115: random label per layer-0 cell, cost of its unit region
+extern "C" void les_oracle_pm_init(const les_oracle* o, int mode, int n, const les_rect* units, uint64_t* states,
+                                   les_plane* labels, float* cur_cost, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const int W = o->W, H = o->H, R = o->windR;
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++) {
+        les_rng r{states[i]};
+        int px, py;
+        les_select_random_pixel(&r, units[i], &px, &py);                              // :107
+        les_plane label = les_create_random_label(&r, o->MIND, o->MAXD, px, py);     // :108
+        for (int y = 0; y < units[i].h; y++)
+            for (int x = 0; x < units[i].w; x++) labels[(size_t)(units[i].y + y) * W + units[i].x + x] = label;   // :109
+        les_rect f = {units[i].x - R, units[i].y - R, units[i].w + 2 * R, units[i].h + 2 * R};
+        f = rect_and(f, les_rect{0, 0, W, H});                                        // :112
+        les_oracle_unary(o, mode, f, units[i], cur_cost + (size_t)f.y * W + f.x, W, label);   // :113
+        states[i] = r.state;
+    }
 }
 
 // =====================================================================================================

@@ -70,6 +70,13 @@ les_oracle* les_oracle_create(const uint8_t* imL, const uint8_t* imR, int H, int
                               float max_disparity, float min_disparity, int use_float);
 void les_oracle_destroy(les_oracle* o);
 
+/* NaiveStereoEnergy (LES/StereoEnergy.h:629-764, MiddV2 mode / BASELINE config 1): photometric unary -- the
+ * other view warped by the plane (bilinear, replicate border), truncated L1 colour + gradient -- followed by the
+ * same guided filter.  The returned context works with every les_oracle_unary* / les_oracle_pm_* function.
+ * cv::warpAffine's exact fixed-point interpolation cannot be pinned here: tolerance-level restatement. */
+les_oracle* les_oracle_create_naive(const uint8_t* imL, const uint8_t* imR, int H, int W, int windR, double eps,
+                                    float alpha, float th_col, float th_grad, float max_disparity, float min_disparity);
+
 /* Guide statistics of view `mode` as 13 double planes of H*W:
  * order I_b,I_g,I_r (Ichannels[0..2]), mean_I[0..2], invrr,invrg,invrb,invgg,invgb,invbb, N
  * (LES/GuidedFilter.h:58-102).  "r,g,b" naming in the reference is cosmetic: channel 0 is B. */
@@ -108,6 +115,14 @@ void les_oracle_aggregate_planes(const les_oracle* o, int mode, int n, const les
  * mask = cur > prop (strict); cur <- prop, label <- plane under mask, over rect (maps are H x W). */
 void les_oracle_wta_update(int W, les_rect rect, float* cur_cost, const float* prop_cost,
                            les_plane* labels, les_plane plane);
+
+/* One disjoint set of the PatchMatch-style loop in the reference's own per-cell order (LES/FastGCStereo.h:30-64,
+ * doGC == false) and initCurrentFast (LES/FastGCStereo.h:94-115).  kinds: 0 Expansion, 1 Random, 2 Ransac. */
+void les_oracle_pm_set(const les_oracle* o, int mode, int n, const les_rect* units, const les_rect* shared,
+                       const les_rect* filter, uint64_t* states, int nprop, const int* kinds, const int* Ks,
+                       les_plane* labels, float* cur_cost, float* prop_cost, int iteration, int nthreads);
+void les_oracle_pm_init(const les_oracle* o, int mode, int n, const les_rect* units, uint64_t* states,
+                        les_plane* labels, float* cur_cost, int nthreads);
 
 /* ---------------- label generation (LES/StereoEnergy.h:120-129, LES/Utilities.hpp:254-261,
  *                  LES/Proposer.h, LES/FastGCStereo.h:231-238) ---------------- */

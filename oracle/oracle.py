@@ -83,6 +83,10 @@ def lib():
         "les_oracle_create": (vp, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double,
                                    C.c_float, C.c_float, C.c_float, C.c_int]),
         "les_oracle_destroy": (None, [vp]),
+        "les_oracle_create_naive": (vp, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_float]),
+        "les_oracle_pm_set": (None, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int]),
+        "les_oracle_pm_init": (None, [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int]),
         "les_oracle_get_stats": (None, [vp, C.c_int, vp]),
         "les_oracle_gather": (None, [vp, C.c_int, Rect, Plane, vp]),
         "les_oracle_filter_subregion": (None, [vp, C.c_int, Rect, vp, vp]),
@@ -153,7 +157,32 @@ class Layer:
 
 
 class Oracle:
-    """CostVolumeEnergy restatement (double guided filter by default)."""
+    """CostVolumeEnergy restatement (double guided filter by default); Oracle.naive(...) builds the
+    NaiveStereoEnergy restatement (MiddV2 mode) behind the same methods."""
+
+    @classmethod
+    def naive(cls, imL, imR, max_disp, windR=20, eps=1e-4, alpha=0.9, th_col=10.0, th_grad=2.0, min_disp=0.0):
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.imL, self.imR = np.ascontiguousarray(imL, np.uint8), np.ascontiguousarray(imR, np.uint8)
+        self.H, self.W = self.imL.shape[:2]
+        self.D = int(max_disp) + 1
+        self.max_disp, self.min_disp = float(max_disp), float(min_disp)
+        self.h = self.L.les_oracle_create_naive(_ptr(self.imL), _ptr(self.imR), self.H, self.W, windR, eps, alpha, th_col, th_grad,
+                                                self.max_disp, self.min_disp)
+        return self
+
+    def pm_init(self, units, states, labels, cur, mode=0, nthreads=0):
+        units = as_rects(units)
+        self.L.les_oracle_pm_init(self.h, mode, len(units), _ptr(units), _ptr(states), _ptr(labels), _ptr(cur), nthreads)
+
+    def pm_set(self, units, shared, filt, states, table, labels, cur, prop, iteration, mode=0, nthreads=0):
+        """table: list of (kind, K) with kind 0 Expansion / 1 Random / 2 Ransac."""
+        units, shared, filt = as_rects(units), as_rects(shared), as_rects(filt)
+        kinds = np.array([k for k, _ in table], np.int32)
+        Ks = np.array([K for _, K in table], np.int32)
+        self.L.les_oracle_pm_set(self.h, mode, len(units), _ptr(units), _ptr(shared), _ptr(filt), _ptr(states), len(table),
+                                 _ptr(kinds), _ptr(Ks), _ptr(labels), _ptr(cur), _ptr(prop), iteration, nthreads)
 
     def __init__(self, imL, imR, volL, volR, windR=20, eps=1e-4, th_col=0.5, max_disp=None, min_disp=0.0,
                  use_float=False):
