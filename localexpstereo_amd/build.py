@@ -59,6 +59,21 @@ def build_host(force=False):
     return exe
 
 
+def build_host_selfcheck(force=False):
+    """tests/cpp/gc_selfcheck: graph-cut host logic on a CPU-only test energy (test infrastructure)."""
+    src = os.path.join(ROOT, "tests", "cpp", "gc_selfcheck.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "gc_selfcheck")
+    if not os.path.exists(src):
+        return None
+    deps = [src] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    if not force and _newer(exe, deps + [HIP_SO]):
+        return exe
+    cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", exe,
+           "-L", CSRC, "-llocalexp_hip", "-Wl,-rpath," + CSRC]
+    subprocess.check_call(cmd, cwd=ROOT)
+    return exe
+
+
 def build_oracle(force=False):
     d = os.path.join(ROOT, "oracle")
     args = ["make", "-C", d] + (["-B"] if force else []) + ["libles_oracle.so"]

@@ -1,0 +1,92 @@
+// ExpansionMove.h -- one local alpha-expansion (graph-cut fusion of the current labelling with one proposal) over a
+// shared region: FastGCStereo::expansionMoveBK, LES/FastGCStereo.h:411-597 ("next" row N2), on top of MaxFlow.h.
+//
+// Nodes = pixels of `region`.  t-links: source capacity = current unary cost, sink capacity = proposal unary cost
+// (:433), plus for region-border pixels the pairwise terms towards their fixed neighbours outside the region
+// (:455-475).  n-links for the four forward neighbour directions with B = cost10, C = cost01, D = cost00:
+// add_edge(i, j, max(0, B + C - D), 0), add_tweights(i, C, 0), add_tweights(j, D - C, 0) (:485-551).
+// A pixel takes the proposal iff it ends on the SOURCE side (:555-559).
+#pragma once
+
+#include "MaxFlow.h"
+#include "StereoEnergy.h"
+
+namespace les_host {
+
+// updateMask: region.height x region.width (255 = take the proposal).  proposalCost / currentCost: H x W maps.
+// Returns the flow (= the energy of the fused labelling restricted to the terms that touch the region).
+inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeling, const CostMap& currentCost,
+                            const CostMap& proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
+                            int mode = 0)
+{
+    std::array<std::vector<float>, 8> cost00, cost01, cost10;
+    E.computeSmoothnessTermsExpansion(currentLabeling, label1, region, cost00, cost01, cost10, mode);
+    const int w = region.width, h = region.height, N = w * h;
+    const int W = E.getWidth(), H = E.getHeight();
+    MaxFlowGraph graph(N, 4 * N);
+    graph.add_node(N);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int s = y * w + x;
+            const Point ps{region.x + x, region.y + y};
+            graph.add_tweights(s, currentCost.at(ps.y, ps.x), proposalCost.at(ps.y, ps.x));
+            if (x == 0 || x == w - 1 || y == 0 || y == h - 1) {
+                for (int k = 0; k < 8; k++) {
+                    const Point pt{ps.x + E.neighbors[k].x, ps.y + E.neighbors[k].y};
+                    const bool in_region = pt.x >= region.x && pt.x < region.x + w && pt.y >= region.y && pt.y < region.y + h;
+                    if (in_region || pt.x < 0 || pt.x >= W || pt.y < 0 || pt.y >= H) continue;
+                    // pt keeps its current label
+                    const float c00 = E.computeSmoothnessTerm(currentLabeling.at(ps.y, ps.x), currentLabeling.at(pt.y, pt.x), ps, k, mode);
+                    const float c10 = E.computeSmoothnessTerm(label1, currentLabeling.at(pt.y, pt.x), ps, k, mode);
+                    graph.add_tweights(s, c00, c10);
+                }
+            }
+        }
+    auto link = [&](int k, int x0, int x1, int y1, int dx) {
+        for (int y = 0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int i = y * w + x, j = (y + (k == StereoEnergy::NB_GE ? 0 : 1)) * w + x + dx;
+                const float B = cost10[k][i], C = cost01[k][i], D = cost00[k][i];
+                graph.add_edge(i, j, std::max(0.f, B + C - D), 0);     // B+C-D can be slightly negative numerically
+                graph.add_tweights(i, C, 0);
+                graph.add_tweights(j, D - C, 0);
+            }
+    };
+    link(StereoEnergy::NB_GE, 0, w - 1, h, +1);          // ee <-> ge
+    link(StereoEnergy::NB_EG, 0, w, h - 1, 0);           // ee <-> eg
+    link(StereoEnergy::NB_LG, 1, w, h - 1, -1);          // ee <-> lg
+    link(StereoEnergy::NB_GG, 0, w - 1, h - 1, +1);      // ee <-> gg
+    const double flow = graph.maxflow();
+    updateMask.resize((size_t)N);
+    for (int s = 0; s < N; s++) updateMask[s] = graph.what_segment(s) == MaxFlowGraph::SOURCE ? 255 : 0;
+    return flow;
+}
+
+// The reference's (disabled) self-check of the graph construction, LES/FastGCStereo.h:561-594: the flow equals the
+// unary cost of the fused labelling over the region plus every forward pairwise term with an endpoint in the region.
+inline double fusedEnergy(const StereoEnergy& E, const LabelMap& currentLabeling, const CostMap& currentCost, const CostMap& proposalCost,
+                          const Plane& label1, const Rect& region, const std::vector<uint8_t>& updateMask, int mode = 0)
+{
+    const int W = E.getWidth(), H = E.getHeight();
+    auto in_region = [&](int x, int y) { return x >= region.x && x < region.x + region.width && y >= region.y && y < region.y + region.height; };
+    auto label_at = [&](int x, int y) -> Plane {
+        if (in_region(x, y) && updateMask[(size_t)(y - region.y) * region.width + (x - region.x)]) return label1;
+        return currentLabeling.at(y, x);
+    };
+    double e = 0;
+    for (int y = region.y; y < region.y + region.height; y++)
+        for (int x = region.x; x < region.x + region.width; x++)
+            e += updateMask[(size_t)(y - region.y) * region.width + (x - region.x)] ? proposalCost.at(y, x) : currentCost.at(y, x);
+    const Rect m = Rect(region.x - 1, region.y - 1, region.width + 2, region.height + 2) & Rect(0, 0, W, H);
+    for (int y = m.y; y < m.y + m.height; y++)
+        for (int x = m.x; x < m.x + m.width; x++)
+            for (int k : {(int)StereoEnergy::NB_GE, (int)StereoEnergy::NB_EG, (int)StereoEnergy::NB_LG, (int)StereoEnergy::NB_GG}) {
+                const int xn = x + E.neighbors[k].x, yn = y + E.neighbors[k].y;
+                if (xn < 0 || xn >= W || yn < 0 || yn >= H) continue;
+                if (!in_region(x, y) && !in_region(xn, yn)) continue;
+                e += E.computeSmoothnessTerm(label_at(x, y), label_at(xn, yn), Point{x, y}, k, mode);
+            }
+    return e;
+}
+
+}  // namespace les_host

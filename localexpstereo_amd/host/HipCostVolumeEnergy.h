@@ -35,6 +35,7 @@ public:
         hp.device = device; hp.volumes_on_device = 0;
         if (les_hip_create(&ctx_, &hp, imL, imR, volL, volR) != LES_HIP_OK)
             throw std::runtime_error(std::string("les_hip_create: ") + les_hip_last_error());
+        setImages(imL, imR);           // pairwise weights for the host graph cut
     }
     ~HipCostVolumeEnergy() override { les_hip_destroy(ctx_); }
     HipCostVolumeEnergy(const HipCostVolumeEnergy&) = delete;

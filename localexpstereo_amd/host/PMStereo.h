@@ -8,13 +8,16 @@
 //   runDevice()  the same iteration with label map, cost maps, generator states and proposers resident on
 //                the GPU: per proposal index one lock-step  propose -> unary -> winner-take-all  for all
 //                cells of the set, no host synchronisation inside an iteration.
-// The graph-cut fusion (doGC == true) needs a max-flow solver that the reference does not ship; it stays
-// outside this path ("next" row N2).
+// With doGC == true (the reference's main iterations) the winner-take-all update is replaced by a local
+// alpha-expansion per cell (ExpansionMove.h over MaxFlow.h; "next" rows N1/N2).  In runDevice() the proposals and
+// the unary costs still come from the GPU; the graph cuts of the cells of a set run on the host cores (OpenMP) and
+// the updated label map goes back to the device after every lock-step.
 #pragma once
 
 #include <chrono>
 #include <memory>
 
+#include "ExpansionMove.h"
 #include "HipCostVolumeEnergy.h"
 #include "LayerManager.h"
 #include "Proposer.h"
@@ -79,7 +82,38 @@ public:
         }
     }
 
-    void localExpansionMovesForLayer(int li, int mode, int iteration)
+    // fuse `label` into the current solution over `sharedRegion` given its unary costs in proposalCost
+    // (LES/FastGCStereo.h:52-63)
+    void fuseProposal(const Plane& label, const Rect& sharedRegion, const CostMap& proposalCost, int mode, bool doGC)
+    {
+        CostMap& currentCost = currentCost_[mode];
+        LabelMap& currentLabeling = currentLabeling_[mode];
+        if (!doGC) {
+            for (int y = sharedRegion.y; y < sharedRegion.y + sharedRegion.height; y++)
+                for (int x = sharedRegion.x; x < sharedRegion.x + sharedRegion.width; x++)
+                    if (currentCost.at(y, x) > proposalCost.at(y, x)) {
+                        currentCost.at(y, x) = proposalCost.at(y, x);
+                        currentLabeling.at(y, x) = label;
+                    }
+            return;
+        }
+        std::vector<uint8_t> mask;
+        const double flow = expansionMove(*stereoEnergy, currentLabeling, currentCost, proposalCost, label, sharedRegion, mask, mode);
+        if (checkFlowEnergy) {
+            const double e = fusedEnergy(*stereoEnergy, currentLabeling, currentCost, proposalCost, label, sharedRegion, mask, mode);
+            const double gap = std::fabs(flow - e) / std::max(1.0, std::fabs(e));
+#pragma omp critical(les_gap)
+            { maxFlowEnergyGap = std::max(maxFlowEnergyGap, gap); numMoves++; }
+        }
+        for (int y = 0; y < sharedRegion.height; y++)
+            for (int x = 0; x < sharedRegion.width; x++)
+                if (mask[(size_t)y * sharedRegion.width + x]) {
+                    currentCost.at(sharedRegion.y + y, sharedRegion.x + x) = proposalCost.at(sharedRegion.y + y, sharedRegion.x + x);
+                    currentLabeling.at(sharedRegion.y + y, sharedRegion.x + x) = label;
+                }
+    }
+
+    void localExpansionMovesForLayer(int li, int mode, int iteration, bool doGC = false)
     {
         const auto& layer = layermng.layers[li];
         CostMap& currentCost = currentCost_[mode];
@@ -101,12 +135,7 @@ public:
                         const Plane label = prop->getNextProposal();
                         stereoEnergy->ComputeUnaryPotential(layer.filterRegions[r], sharedRegion, proposalCost.view(layer.filterRegions[r]),
                                                             width, label, reusable, mode);
-                        for (int y = sharedRegion.y; y < sharedRegion.y + sharedRegion.height; y++)       // LES/FastGCStereo.h:57-60
-                            for (int x = sharedRegion.x; x < sharedRegion.x + sharedRegion.width; x++)
-                                if (currentCost.at(y, x) > proposalCost.at(y, x)) {
-                                    currentCost.at(y, x) = proposalCost.at(y, x);
-                                    currentLabeling.at(y, x) = label;
-                                }
+                        fuseProposal(label, sharedRegion, proposalCost, mode, doGC);
                     }
                 }
                 rngStates[li][r] = rng.state;
@@ -114,18 +143,23 @@ public:
         }
     }
 
-    void run(int pmInit, const std::vector<int>& viewModes = {0})
+    // FastGCStereo::run (LES/FastGCStereo.h:133-199): pmInit winner-take-all iterations, then maxIteration
+    // graph-cut iterations (the iteration counter restarts, so the random search widths do too)
+    void run(int pmInit, const std::vector<int>& viewModes = {0}, int maxIteration = 0)
     {
         for (int mode : viewModes) initCurrentFast(mode);
         for (int iteration = 0; iteration < pmInit; iteration++)
             for (int mode : viewModes)
-                for (int li = 0; li < (int)layermng.layers.size(); li++) localExpansionMovesForLayer(li, mode, iteration);
+                for (int li = 0; li < (int)layermng.layers.size(); li++) localExpansionMovesForLayer(li, mode, iteration, false);
+        for (int iteration = 0; iteration < maxIteration; iteration++)
+            for (int mode : viewModes)
+                for (int li = 0; li < (int)layermng.layers.size(); li++) localExpansionMovesForLayer(li, mode, iteration, true);
     }
 
     // ---------------------------------------------------------------------------------------------
     // Device-resident driver (needs a HipCostVolumeEnergy)
     // ---------------------------------------------------------------------------------------------
-    bool runDevice(int pmInit, const std::vector<int>& viewModes = {0}, double* seconds = nullptr)
+    bool runDevice(int pmInit, const std::vector<int>& viewModes = {0}, double* seconds = nullptr, int maxIteration = 0)
     {
         auto* hip = dynamic_cast<HipCostVolumeEnergy*>(stereoEnergy.get());
         if (!hip) return false;
@@ -194,6 +228,31 @@ public:
                 chk(les_hip_memcpy_d2h(ctx, currentLabeling_[mode].data.data(), d_labels, P * sizeof(les_hip_plane)));
                 chk(les_hip_memcpy_d2h(ctx, currentCost_[mode].data.data(), d_cur, P * sizeof(float)));
             }
+            // graph-cut iterations: GPU proposes and evaluates the unary costs of all cells of a set, the host cores
+            // cut the cells' graphs, the fused label map returns to the device for the next proposals
+            CostMap proposalCost(height, width);
+            std::vector<les_hip_plane> hplanes;
+            for (int iteration = 0; iteration < maxIteration && ok; iteration++)
+                for (size_t li = 0; li < batches.size(); li++)
+                    for (SetBatch& sb : batches[li])
+                        for (const ProposerSpec& spec : layerProposers[li])
+                            for (int it = 0; it < spec.K && ok; it++) {
+                                const int m = iteration + it;
+                                if (spec.kind == LES_HIP_PROPOSE_RANDOM && randomWidth(m) < 0.1) break;
+                                chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
+                                chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
+                                hplanes.resize(sb.n);
+                                chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
+                                chk(les_hip_memcpy_d2h(ctx, proposalCost.data.data(), d_prop, P * sizeof(float)));
+                                if (!ok) break;
+                                const auto& L = layermng.layers[li];
+#pragma omp parallel for schedule(dynamic, 1)
+                                for (int n = 0; n < sb.n; n++) {
+                                    const les_hip_plane& hp = hplanes[n];
+                                    fuseProposal(Plane(hp.a, hp.b, hp.c, hp.v), L.sharedRegions[sb.cells[n]], proposalCost, mode, true);
+                                }
+                                chk(les_hip_memcpy_h2d(ctx, d_labels, currentLabeling_[mode].data.data(), P * sizeof(les_hip_plane)));
+                            }
         }
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (auto& lb : batches)
@@ -218,9 +277,15 @@ public:
         return s;
     }
 
+    // data + smoothness energy of the current solution (what the graph-cut iterations minimise)
+    double totalEnergy(int mode) const { return totalCost(mode) + stereoEnergy->computeSmoothnessCost(currentLabeling_[mode], mode); }
+
     LabelMap currentLabeling_[2];
     CostMap currentCost_[2];
     LayerManager& layers() { return layermng; }
+    bool checkFlowEnergy = false;       // the reference's disabled self-check (LES/FastGCStereo.h:561-594)
+    double maxFlowEnergyGap = 0;        // max |flow - energy| / max(1, |energy|) over the checked moves
+    long numMoves = 0;
 
 private:
     static uint64_t splitmix(uint64_t x)

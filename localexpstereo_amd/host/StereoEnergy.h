@@ -2,9 +2,12 @@
 // class StereoEnergy (LES/StereoEnergy.h:42-627) for the members this path uses:
 //   virtual ComputeUnaryPotential / ComputeUnaryPotentialWithoutCheck  (:625-626)
 //   IsValiLabel (:560-610), createRandomLabel (:120-129), Reusable (:616-623), COST_FOR_INVALID (:45), params.
-// The pairwise (smoothness) members of the reference base class belong to the graph-cut side ("next" row
-// N1 of SURVEY.md section 8(f)) and are not part of this path.
+// The pairwise (smoothness) members used by the graph-cut fusion ("next" rows N1/N2 of SURVEY.md section 8(f)) are
+// provided on the host: neighbors (:58), initSmoothnessCoeff (:131-163), computeSmoothnessTerm (:225-230),
+// computeSmoothnessTermsExpansion (:398-453).
 #pragma once
+
+#include <array>
 
 #include "les_types.h"
 
@@ -21,11 +24,98 @@ public:
         Rect filterRect;
     };
 
+    enum { NB_LE = 0, NB_GE = 1, NB_EL = 2, NB_EG = 3, NB_LL = 4, NB_GL = 5, NB_LG = 6, NB_GG = 7 };   // LES/StereoEnergy.h:47-56
+    std::array<Point, 8> neighbors{{{-1, 0}, {+1, 0}, {0, -1}, {0, +1}, {-1, -1}, {+1, -1}, {-1, +1}, {+1, +1}}};   // :99-110
+
     Parameters params;
 
     StereoEnergy(int width, int height, Parameters p, float MAX_DISPARITY, float MIN_DISPARITY = 0)
         : params(std::move(p)), width(width), height(height), MAX_DISPARITY(MAX_DISPARITY), MIN_DISPARITY(MIN_DISPARITY) {}
     virtual ~StereoEnergy() {}
+
+    // ---- pairwise terms (host side of the graph cut) ------------------------------------------------------
+    // images: H x W x 3 uint8 BGR of the two views (the reference keeps them as CV_32FC3, LES/StereoEnergy.h:96-97)
+    void setImages(const uint8_t* imL, const uint8_t* imR)
+    {
+        const uint8_t* im[2] = {imL, imR};
+        const size_t P = (size_t)width * height;
+        for (int m = 0; m < 2; m++) {
+            if (!im[m]) continue;
+            I[m].assign(im[m], im[m] + P * 3);
+            // initSmoothnessCoeff, LES/StereoEnergy.h:131-163: w = max(epsilon, exp(-|dI|_1 / omega)), 0 for pairs that
+            // leave the image
+            for (int k = 0; k < 8; k++) {
+                smoothnessCoeff[m][k].assign(P, 0.f);
+                for (int y = 0; y < height; y++)
+                    for (int x = 0; x < width; x++) {
+                        const int xn = x + neighbors[k].x, yn = y + neighbors[k].y;
+                        if (xn < 0 || xn >= width || yn < 0 || yn >= height) continue;
+                        const float* a = &I[m][((size_t)y * width + x) * 3];
+                        const float* b = &I[m][((size_t)yn * width + xn) * 3];
+                        const float ad = std::fabs(b[0] - a[0]) + std::fabs(b[1] - a[1]) + std::fabs(b[2] - a[2]);
+                        smoothnessCoeff[m][k][(size_t)y * width + x] = std::max(params.epsilon, std::exp(-ad / params.omega));
+                    }
+            }
+        }
+    }
+    bool hasImages(int mode) const { return !I[mode].empty(); }
+
+    // LES/StereoEnergy.h:225-230
+    float computeSmoothnessTerm(const Plane& ls, const Plane& lt, Point ps, int neighborId, int mode = 0) const
+    {
+        const Point pt{ps.x + neighbors[neighborId].x, ps.y + neighbors[neighborId].y};
+        return smoothnessCoeff[mode][neighborId][(size_t)ps.y * width + ps.x]
+               * std::min(std::fabs(ls.GetZ((float)ps.x, (float)ps.y) - lt.GetZ((float)ps.x, (float)ps.y))
+                          + std::fabs(ls.GetZ((float)pt.x, (float)pt.y) - lt.GetZ((float)pt.x, (float)pt.y)), params.th_smooth)
+               * params.lambda;
+    }
+
+    // LES/StereoEnergy.h:398-453 for the forward neighbours GE, EG, LG, GG (onlyForward = true): per pixel `ee` of
+    // region and neighbour `le` = ee + n:  cost00 (both keep their labels), cost01 (le takes label1), cost10 (ee takes
+    // label1).  Outputs are region.height x region.width row-major arrays indexed by the 8-neighbour id; label0 outside
+    // the image is the zero plane (the reference's label map has a 1-pixel zero margin) and its weight is 0 anyway.
+    void computeSmoothnessTermsExpansion(const LabelMap& labeling0, const Plane& label1, const Rect& region,
+                                         std::array<std::vector<float>, 8>& cost00, std::array<std::vector<float>, 8>& cost01,
+                                         std::array<std::vector<float>, 8>& cost10, int mode = 0) const
+    {
+        const size_t n = (size_t)region.width * region.height;
+        auto dot = [](const Plane& l, float x, float y) { return ((l.a * x + l.b * y) + l.c * 1.0f) + l.v * 0.0f; };   // channelDot / channelSum order
+        for (int k : {(int)NB_GE, (int)NB_EG, (int)NB_LG, (int)NB_GG}) {
+            cost00[k].assign(n, 0.f); cost01[k].assign(n, 0.f); cost10[k].assign(n, 0.f);
+            for (int y = 0; y < region.height; y++)
+                for (int x = 0; x < region.width; x++) {
+                    const int ex = region.x + x, ey = region.y + y;
+                    const int lx = ex + neighbors[k].x, ly = ey + neighbors[k].y;
+                    const bool inside = lx >= 0 && lx < width && ly >= 0 && ly < height;
+                    const Plane l0_ee = labeling0.at(ey, ex);
+                    const Plane l0_le = inside ? labeling0.at(ly, lx) : Plane();
+                    const float fx = (float)ex, fy = (float)ey, gx = (float)lx, gy = (float)ly;
+                    const float d0_ee_at_ee = dot(l0_ee, fx, fy), d0_le_at_ee = dot(l0_le, fx, fy);
+                    const float d0_ee_at_le = dot(l0_ee, gx, gy), d0_le_at_le = dot(l0_le, gx, gy);
+                    const float d1_at_ee = dot(label1, fx, fy), d1_at_le = dot(label1, gx, gy);
+                    const float w = smoothnessCoeff[mode][k][(size_t)ey * width + ex];
+                    const size_t i = (size_t)y * region.width + x;
+                    const float th = params.th_smooth;
+                    cost00[k][i] = std::min(std::fabs(d0_ee_at_ee - d0_le_at_ee) + std::fabs(d0_ee_at_le - d0_le_at_le), th) * w * params.lambda;
+                    cost01[k][i] = std::min(std::fabs(d0_ee_at_ee - d1_at_ee) + std::fabs(d0_ee_at_le - d1_at_le), th) * w * params.lambda;
+                    cost10[k][i] = std::min(std::fabs(d1_at_ee - d0_le_at_ee) + std::fabs(d1_at_le - d0_le_at_le), th) * w * params.lambda;
+                }
+        }
+    }
+
+    // total smoothness energy of a labelling over forward pairs (StereoEnergy::computeSmoothnessCost, :165-203)
+    double computeSmoothnessCost(const LabelMap& labeling, int mode = 0) const
+    {
+        double sum = 0;
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++)
+                for (int k : {(int)NB_GE, (int)NB_EG, (int)NB_LG, (int)NB_GG}) {
+                    const int xn = x + neighbors[k].x, yn = y + neighbors[k].y;
+                    if (xn < 0 || xn >= width || yn < 0 || yn >= height) continue;
+                    sum += computeSmoothnessTerm(labeling.at(y, x), labeling.at(yn, xn), Point{x, y}, k, mode);
+                }
+        return sum;
+    }
 
     // costs: pointer to element (filterRect.y, filterRect.x) of a row-major float map with row_stride floats
     // per row, i.e. the view proposalCost(filterRect) of LES/FastGCStereo.h:49.  Only the sub-rect
@@ -66,6 +156,8 @@ public:
 protected:
     const int width, height;
     const float MAX_DISPARITY, MIN_DISPARITY;
+    std::vector<float> I[2];                                   // BGR as float, H x W x 3
+    std::vector<float> smoothnessCoeff[2][8];                  // H x W each
 };
 
 }  // namespace les_host

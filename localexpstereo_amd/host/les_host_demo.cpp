@@ -12,7 +12,9 @@
 #include <cstring>
 #include <memory>
 
+#include "MaxFlow.h"
 #include "PMStereo.h"
+#include "DemoScene.h"
 
 using namespace les_host;
 
@@ -35,42 +37,32 @@ static int cmd_layers(int argc, char** argv)
     return 0;
 }
 
-struct Scene {
-    int W, H, D;
-    std::vector<uint8_t> im;       // BGR
-    std::vector<float> vol, gt;
-};
-
-static Scene make_scene(int W, int H, int D)
+// maxflow <file>: n m / n lines "cap_source cap_sink" / m lines "i j cap rev_cap" -> prints flow and the segments
+static int cmd_maxflow(int argc, char** argv)
 {
-    Scene s{W, H, D, std::vector<uint8_t>((size_t)W * H * 3), std::vector<float>((size_t)W * H * D), std::vector<float>((size_t)W * H)};
-    RNG rng(4242);
-    // three slanted surfaces separated by vertical / diagonal boundaries; guide colour follows the surface
-    const Plane surf[3] = {Plane(0.02f, 0.01f, 0.25f * D), Plane(-0.03f, 0.0f, 0.6f * D), Plane(0.0f, -0.02f, 0.45f * D)};
-    const int col[3][3] = {{200, 60, 40}, {40, 180, 70}, {60, 70, 210}};
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const int k = x < W / 3 ? 0 : (x + y / 2 < (2 * W) / 3 ? 1 : 2);
-            float d = surf[k].GetZ((float)x, (float)y);
-            d = std::min(std::max(d, 1.0f), (float)D - 2.0f);
-            s.gt[(size_t)y * W + x] = d;
-            for (int c = 0; c < 3; c++) {
-                int v = col[k][c] + (int)(rng.uniform(-12.0f, 12.0f)) + (int)(10.0 * std::sin(0.15 * x + 0.1 * y));
-                s.im[((size_t)y * W + x) * 3 + c] = (uint8_t)std::min(255, std::max(0, v));
-            }
-            for (int dd = 0; dd < D; dd++) {
-                const float e = std::fabs((float)dd - d);
-                s.vol[((size_t)dd * H + y) * W + x] = std::min(1.0f, 0.12f * e) * 0.8f + rng.uniform(0.0f, 0.2f);
-            }
-        }
-    return s;
-}
-
-static double bad_pixels(const std::vector<float>& disp, const Scene& s, float thr)
-{
-    size_t bad = 0;
-    for (size_t i = 0; i < disp.size(); i++) bad += std::fabs(disp[i] - s.gt[i]) > thr;
-    return 100.0 * bad / disp.size();
+    if (argc < 3) return 2;
+    FILE* f = fopen(argv[2], "r");
+    if (!f) return 2;
+    int n, m;
+    if (fscanf(f, "%d %d", &n, &m) != 2) return 2;
+    MaxFlowGraph g(n, m);
+    g.add_node(n);
+    for (int i = 0; i < n; i++) {
+        float a, b;
+        if (fscanf(f, "%f %f", &a, &b) != 2) return 2;
+        g.add_tweights(i, a, b);
+    }
+    for (int k = 0; k < m; k++) {
+        int i, j;
+        float c, r;
+        if (fscanf(f, "%d %d %f %f", &i, &j, &c, &r) != 4) return 2;
+        g.add_edge(i, j, c, r);
+    }
+    fclose(f);
+    printf("%.9g\n", g.maxflow());
+    for (int i = 0; i < n; i++) printf("%d", g.what_segment(i) == MaxFlowGraph::SOURCE ? 0 : 1);
+    printf("\n");
+    return 0;
 }
 
 static int cmd_run(int argc, char** argv)
@@ -118,6 +110,28 @@ static int cmd_run(int argc, char** argv)
         printf("device    iter %d  E=%.1f  bad1.0=%.2f%%  (%.3f s)\n", iters, st->totalCost(0), bad, sec);
         if (bad > 15.0) { printf("FAIL: device run did not converge\n"); fail = 1; }
     }
+    // (c) local expansion moves proper: 1 winner-take-all iteration, then graph-cut iterations whose unary costs come
+    //     from the GPU and whose cuts run on the host cores; the reference's flow == energy self-check is on
+    {
+        auto st = build(7);
+        st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        st->checkFlowEnergy = true;
+        double sec = 0;
+        if (!st->runDevice(1, {0}, &sec, 0)) { printf("FAIL: runDevice\n"); return 1; }
+        const double e_pm = st->totalEnergy(0), bad_pm = bad_pixels(st->computeDisparities(0), s, 1.0f);
+        auto st2 = build(7);
+        st2->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st2->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        st2->checkFlowEnergy = true;
+        if (!st2->runDevice(1, {0}, &sec, iters)) { printf("FAIL: runDevice (graph cut)\n"); return 1; }
+        const double e_gc = st2->totalEnergy(0), bad_gc = bad_pixels(st2->computeDisparities(0), s, 1.0f);
+        printf("graph-cut pm 1: E(data+smooth)=%.1f bad1.0=%.2f%%  ->  + %d gc iters: E=%.1f bad1.0=%.2f%%  moves=%ld  max|flow-E|/E=%.2e  (%.3f s)\n",
+               e_pm, bad_pm, iters, e_gc, bad_gc, st2->numMoves, st2->maxFlowEnergyGap, sec);
+        if (e_gc > e_pm) { printf("FAIL: graph-cut iterations increased the energy\n"); fail = 1; }
+        if (st2->maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
+        if (bad_gc > 10.0) { printf("FAIL: graph-cut run did not converge\n"); fail = 1; }
+    }
     printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
     return fail;
 }
@@ -125,6 +139,7 @@ static int cmd_run(int argc, char** argv)
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "layers")) return cmd_layers(argc, argv);
+    if (argc >= 2 && !strcmp(argv[1], "maxflow")) return cmd_maxflow(argc, argv);
     if (argc >= 2 && !strcmp(argv[1], "run")) {
         try {
             return cmd_run(argc, argv);

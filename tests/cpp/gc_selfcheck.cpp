@@ -1,0 +1,126 @@
+// gc_selfcheck.cpp -- TEST INFRASTRUCTURE: exercises the host graph-cut side (ExpansionMove.h / MaxFlow.h / the doGC
+// loop of PMStereo.h) without a GPU.  The unary operator used here is NOT the product path and not a fallback for it:
+// it is a deliberately different, un-aggregated per-pixel cost (truncated volume lookup) that only exists so that the
+// local expansion moves have something to fuse on a CPU-only box.
+//
+// Checks (exit code != 0 on failure):
+//   1. the reference's own disabled self-check (LES/FastGCStereo.h:561-594): for every move, max-flow value ==
+//      energy of the fused labelling over the terms touching the region, within 1e-5 relative
+//   2. every expansion move is optimal against brute force on tiny regions (all 2^N masks)
+//   3. the total energy (data + smoothness) never increases over graph-cut iterations and the scene converges
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "PMStereo.h"
+#include "DemoScene.h"
+
+using namespace les_host;
+
+class PointwiseTestEnergy : public StereoEnergy {
+public:
+    PointwiseTestEnergy(const Scene& s, Parameters p, float maxd) : StereoEnergy(s.W, s.H, std::move(p), maxd, 0), s_(s)
+    {
+        setImages(s.im.data(), s.im.data());
+    }
+    void ComputeUnaryPotentialWithoutCheck(const Rect& fr, const Rect& tr, float* costs, int row_stride, const Plane& plane, Reusable&,
+                                           int = 0) const override
+    {
+        for (int y = tr.y; y < tr.y + tr.height; y++)
+            for (int x = tr.x; x < tr.x + tr.width; x++) {
+                float d = plane.GetZ((float)x, (float)y);
+                d = std::min(std::max(d, 0.0f), (float)(s_.D - 1));
+                const int d0 = std::min((int)d, s_.D - 2);
+                const float f = d - (float)d0;
+                const float c = s_.vol[((size_t)d0 * s_.H + y) * s_.W + x] * (1 - f) + s_.vol[((size_t)(d0 + 1) * s_.H + y) * s_.W + x] * f;
+                costs[(size_t)(y - fr.y) * row_stride + (x - fr.x)] = std::min(c, params.th_col);
+            }
+    }
+    void ComputeUnaryPotential(const Rect& fr, const Rect& tr, float* costs, int row_stride, const Plane& plane, Reusable& r, int mode = 0) const override
+    {
+        ComputeUnaryPotentialWithoutCheck(fr, tr, costs, row_stride, plane, r, mode);
+        for (int y = tr.y; y < tr.y + tr.height; y++)
+            for (int x = tr.x; x < tr.x + tr.width; x++)
+                if (!IsValiLabel(plane, Point{x, y})) costs[(size_t)(y - fr.y) * row_stride + (x - fr.x)] = (float)COST_FOR_INVALID;
+    }
+
+private:
+    const Scene& s_;
+};
+
+static int brute_force(const Scene& s, const Parameters& param, float maxd)
+{
+    PointwiseTestEnergy E(s, param, maxd);
+    RNG rng(99);
+    LabelMap lab(s.H, s.W);
+    CostMap cur(s.H, s.W, 0.f), prop(s.H, s.W, 0.f);
+    StereoEnergy::Reusable tmp;
+    int fail = 0;
+    for (int trial = 0; trial < 60; trial++) {
+        // random piecewise labelling and costs, random small region (<= 12 pixels), random proposal
+        for (int y = 0; y < s.H; y++)
+            for (int x = 0; x < s.W; x++) {
+                if ((x % 3 == 0 && y % 2 == 0) || (x == 0 && y == 0)) lab.at(y, x) = E.createRandomLabel(Point{x, y}, rng);
+                else lab.at(y, x) = x % 3 ? lab.at(y, x - 1) : lab.at(y - 1, x);
+                cur.at(y, x) = rng.uniform(0.0f, 1.0f);
+                prop.at(y, x) = rng.uniform(0.0f, 1.0f);
+            }
+        const int w = rng.uniform(1, 5), h = rng.uniform(1, 4);
+        const Rect region(rng.uniform(0, s.W - w + 1), rng.uniform(0, s.H - h + 1), w, h);
+        const Plane label = E.createRandomLabel(Point{region.x, region.y}, rng);
+        std::vector<uint8_t> mask;
+        const double flow = expansionMove(E, lab, cur, prop, label, region, mask);
+        const double e_cut = fusedEnergy(E, lab, cur, prop, label, region, mask);
+        double best = 1e300;
+        const int N = w * h;
+        std::vector<uint8_t> m(N);
+        for (int bits = 0; bits < (1 << N); bits++) {
+            for (int i = 0; i < N; i++) m[i] = (bits >> i) & 1 ? 255 : 0;
+            best = std::min(best, fusedEnergy(E, lab, cur, prop, label, region, m));
+        }
+        const double tol = 1e-5 * std::max(1.0, std::fabs(best));
+        if (std::fabs(flow - e_cut) > tol || e_cut > best + tol) {
+            printf("FAIL brute force trial %d: region %dx%d flow=%.7f cut energy=%.7f optimum=%.7f\n", trial, w, h, flow, e_cut, best);
+            fail = 1;
+        }
+    }
+    printf("brute force: 60 random moves %s\n", fail ? "FAILED" : "optimal");
+    return fail;
+}
+
+int main(int argc, char** argv)
+{
+    const int W = argc > 1 ? atoi(argv[1]) : 120, H = argc > 2 ? atoi(argv[2]) : 80, D = argc > 3 ? atoi(argv[3]) : 24;
+    const int iters = argc > 4 ? atoi(argv[4]) : 2;
+    Scene s = make_scene(W, H, D);
+    Parameters param(1.0f, 20, "GF", 1e-4f);
+    param.th_col = 0.5f;
+    const float maxd = (float)D - 1;
+    int fail = 0;
+    {
+        Scene tiny = make_scene(16, 12, 8);
+        fail |= brute_force(tiny, param, 7.0f);
+    }
+    PMStereo st(W, H, param, maxd);
+    st.setSeed(11);
+    st.setStereoEnergy(std::make_unique<PointwiseTestEnergy>(s, param, maxd));
+    st.addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+    st.addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}});
+    st.checkFlowEnergy = true;
+    st.initCurrentFast(0);
+    double e_prev = st.totalEnergy(0);
+    printf("init      E=%.2f  bad1.0=%.2f%%\n", e_prev, bad_pixels(st.computeDisparities(0), s, 1.0f));
+    for (int it = 0; it < iters; it++) {
+        for (size_t li = 0; li < st.layers().layers.size(); li++) st.localExpansionMovesForLayer((int)li, 0, it, true);
+        const double e = st.totalEnergy(0);
+        printf("gc iter %d E=%.2f  bad1.0=%.2f%%  moves=%ld  max |flow-E|/E = %.2e\n", it + 1, e, bad_pixels(st.computeDisparities(0), s, 1.0f),
+               st.numMoves, st.maxFlowEnergyGap);
+        if (e > e_prev * (1 + 1e-6)) { printf("FAIL: energy increased\n"); fail = 1; }
+        e_prev = e;
+    }
+    if (st.maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
+    if (bad_pixels(st.computeDisparities(0), s, 1.0f) > 20.0) { printf("FAIL: did not converge\n"); fail = 1; }
+    printf(fail ? "gc_selfcheck: FAILED\n" : "gc_selfcheck: OK\n");
+    return fail;
+}

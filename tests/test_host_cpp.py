@@ -43,3 +43,87 @@ def test_host_demo_runs_on_gpu(demo):
     r = subprocess.run([demo, "run", "240", "160", "32", "2"], capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
+
+
+def test_host_graph_cut_selfcheck(demo):
+    """Local expansion moves on the host (ExpansionMove.h over MaxFlow.h): brute-force optimality on tiny regions, the
+    reference's flow == energy self-check (LES/FastGCStereo.h:561-594) on every move, monotone energy, convergence."""
+    from localexpstereo_amd import build
+    exe = build.build_host_selfcheck()
+    r = subprocess.run([exe, "120", "80", "24", "2"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "gc_selfcheck: OK" in r.stdout
+
+
+def _maxflow_case(demo, tmp_path, n, tw, edges):
+    path = tmp_path / "g.txt"
+    with open(path, "w") as f:
+        f.write(f"{n} {len(edges)}\n")
+        for a, b in tw:
+            f.write(f"{a:.9g} {b:.9g}\n")
+        for i, j, c, r in edges:
+            f.write(f"{i} {j} {c:.9g} {r:.9g}\n")
+    out = subprocess.run([demo, "maxflow", str(path)], capture_output=True, text=True, check=True).stdout.split()
+    return float(out[0]), [int(ch) for ch in out[1]]
+
+
+def test_host_maxflow_matches_networkx(demo, tmp_path):
+    """N2: the host min-cut (host/MaxFlow.h) against networkx on random grid-like graphs with float capacities:
+    same flow value, the reported segments form a cut of that value, and the sink side is the set of nodes that can
+    still reach the sink (so ties go to SOURCE like the library the reference links, LES/FastGCStereo.h:557)."""
+    import networkx as nx
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        h, w = int(rng.integers(3, 9)), int(rng.integers(3, 9))
+        n = h * w
+        tw = np.round(rng.uniform(0, 4, (n, 2)), 3).astype(np.float32)
+        if trial % 3 == 0:
+            tw[rng.random(n) < 0.3] = 0            # nodes attached to no terminal
+        edges = []
+        for y in range(h):
+            for x in range(w):
+                for dy, dx in ((0, 1), (1, 0), (1, 1), (1, -1)):
+                    yy, xx = y + dy, x + dx
+                    if 0 <= yy < h and 0 <= xx < w:
+                        c = float(np.float32(round(rng.uniform(0, 2), 3))) if rng.random() > 0.15 else 0.0
+                        edges.append((y * w + x, yy * w + xx, c, 0.0 if trial % 2 else c))
+        flow, seg = _maxflow_case(demo, tmp_path, n, tw, edges)
+        G = nx.DiGraph()
+        G.add_nodes_from(["s", "t"])
+        base = 0.0
+        for i, (a, b) in enumerate(tw):
+            m = min(a, b)
+            base += m
+            if a - m > 0:
+                G.add_edge("s", i, capacity=float(a - m))
+            if b - m > 0:
+                G.add_edge(i, "t", capacity=float(b - m))
+        for i, j, c, r in edges:
+            for u, v, cap in ((i, j, c), (j, i, r)):
+                if cap > 0:
+                    G.add_edge(u, v, capacity=G[u][v]["capacity"] + cap if G.has_edge(u, v) else cap)
+        ref, (S, T) = nx.minimum_cut(G, "s", "t")
+        assert abs(flow - (ref + base)) <= 1e-4 * max(1.0, ref + base)
+        # capacity of the cut our segments define == the flow
+        cut = base
+        for i, (a, b) in enumerate(tw):
+            m = min(a, b)
+            cut += (b - m) if seg[i] == 0 else (a - m)
+        for i, j, c, r in edges:
+            if seg[i] == 0 and seg[j] == 1:
+                cut += c
+            if seg[j] == 0 and seg[i] == 1:
+                cut += r
+        assert abs(cut - flow) <= 1e-4 * max(1.0, flow)
+        # sink side == nodes that can reach t in the residual graph of a maximum flow (unique minimal sink set)
+        R = nx.algorithms.flow.preflow_push(G, "s", "t")
+        reach = {"t"}
+        stack = ["t"]
+        while stack:
+            v = stack.pop()
+            for u in R.predecessors(v):
+                if u not in reach and R[u][v]["capacity"] - R[u][v]["flow"] > 1e-9:
+                    reach.add(u)
+                    stack.append(u)
+        for i in range(n):
+            assert (seg[i] == 1) == (i in reach), (trial, i)
