@@ -14,6 +14,8 @@
 // the updated label map goes back to the device after every lock-step.
 #pragma once
 
+#include <omp.h>
+
 #include <chrono>
 #include <memory>
 
@@ -239,19 +241,30 @@ public:
                             for (int it = 0; it < spec.K && ok; it++) {
                                 const int m = iteration + it;
                                 if (spec.kind == LES_HIP_PROPOSE_RANDOM && randomWidth(m) < 0.1) break;
+                                const auto tA = std::chrono::steady_clock::now();
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
                                 hplanes.resize(sb.n);
                                 chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
                                 chk(les_hip_memcpy_d2h(ctx, proposalCost.data.data(), d_prop, P * sizeof(float)));
                                 if (!ok) break;
+                                const auto tB = std::chrono::steady_clock::now();
                                 const auto& L = layermng.layers[li];
-#pragma omp parallel for schedule(dynamic, 1)
+                                // no more threads than cells: a team of every core for a handful of cells costs far more in
+                                // fork/join than the cuts themselves
+                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : omp_get_max_threads() / 2));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
                                 for (int n = 0; n < sb.n; n++) {
                                     const les_hip_plane& hp = hplanes[n];
                                     fuseProposal(Plane(hp.a, hp.b, hp.c, hp.v), L.sharedRegions[sb.cells[n]], proposalCost, mode, true);
                                 }
+                                const auto tC = std::chrono::steady_clock::now();
                                 chk(les_hip_memcpy_h2d(ctx, d_labels, currentLabeling_[mode].data.data(), P * sizeof(les_hip_plane)));
+                                const auto tD = std::chrono::steady_clock::now();
+                                gcSeconds[0] += std::chrono::duration<double>(tB - tA).count();
+                                gcSeconds[1] += std::chrono::duration<double>(tC - tB).count();
+                                gcSeconds[2] += std::chrono::duration<double>(tD - tC).count();
+                                gcLockSteps++;
                             }
         }
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -286,6 +299,9 @@ public:
     bool checkFlowEnergy = false;       // the reference's disabled self-check (LES/FastGCStereo.h:561-594)
     double maxFlowEnergyGap = 0;        // max |flow - energy| / max(1, |energy|) over the checked moves
     long numMoves = 0;
+    double gcSeconds[3] = {0, 0, 0};    // runDevice graph-cut lock-steps: GPU propose+unary+D2H / host cuts / H2D labels
+    long gcLockSteps = 0;
+    int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: half the cores, at most one per cell)
 
 private:
     static uint64_t splitmix(uint64_t x)

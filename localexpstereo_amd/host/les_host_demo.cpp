@@ -128,6 +128,8 @@ static int cmd_run(int argc, char** argv)
         const double e_gc = st2->totalEnergy(0), bad_gc = bad_pixels(st2->computeDisparities(0), s, 1.0f);
         printf("graph-cut pm 1: E(data+smooth)=%.1f bad1.0=%.2f%%  ->  + %d gc iters: E=%.1f bad1.0=%.2f%%  moves=%ld  max|flow-E|/E=%.2e  (%.3f s)\n",
                e_pm, bad_pm, iters, e_gc, bad_gc, st2->numMoves, st2->maxFlowEnergyGap, sec);
+        printf("graph-cut lock-steps: %ld   GPU propose+unary+D2H %.3f s   host cuts %.3f s   H2D labels %.3f s\n", st2->gcLockSteps,
+               st2->gcSeconds[0], st2->gcSeconds[1], st2->gcSeconds[2]);
         if (e_gc > e_pm) { printf("FAIL: graph-cut iterations increased the energy\n"); fail = 1; }
         if (st2->maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
         if (bad_gc > 10.0) { printf("FAIL: graph-cut run did not converge\n"); fail = 1; }
