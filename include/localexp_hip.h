@@ -58,6 +58,15 @@ typedef struct {
  * or device when volumes_on_device).  Either view may be NULL if its mode is never used. */
 int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
                    const float* volL, const float* volR);
+
+/* replaces: NaiveStereoEnergy::NaiveStereoEnergy (LES/StereoEnergy.h:638-689) -- the image-based matching cost of the
+ * MiddV2 configuration (LES/main.cpp:86-121, PMStereoBase.h:37): no cost volume; the raw cost of a plane is the truncated
+ * colour + x-gradient difference between this view and the other view warped by the plane (StereoEnergy.h:702-742), then
+ * the same guided-filter aggregation and validity rule.  params->D and the volume fields are ignored, th_col is
+ * Parameters::th_col (10 for MiddV2), alpha / th_grad are Parameters::alpha / th_grad.  Both images are required.
+ * Every other entry point (unary_one / unary_batch / batch_* / wta) works on the returned context unchanged. */
+int les_hip_create_naive(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
+                         float alpha, float th_grad);
 void les_hip_destroy(les_hip_ctx* ctx);                 /* replaces: ~CostVolumeEnergy (:50-52)          */
 const char* les_hip_last_error(void);                   /* thread-local description of the last failure  */
 

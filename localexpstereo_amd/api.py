@@ -17,7 +17,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 
 # every symbol include/localexp_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "les_hip_create", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
+    "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
     "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
@@ -64,6 +64,7 @@ def load(path=None):
     vp, ci = C.c_void_p, C.c_int
     sig = {
         "les_hip_create": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, vp, vp]),
+        "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),
         "les_hip_destroy": (None, [vp]),
         "les_hip_last_error": (C.c_char_p, []),
         "les_hip_set_stream": (ci, [vp, vp]),
@@ -236,6 +237,25 @@ class HipCostVolumeEnergy:
         self._chk(self.L.les_hip_create(C.byref(h), C.byref(self.params), _ptr(self.imL), _ptr(self.imR), vl, vr))
         self.h = h
         self._keep = None     # host volumes were copied to HBM
+
+    @classmethod
+    def naive(cls, imL, imR, windR=20, eps=1e-4, alpha=0.9, th_col=10.0, th_grad=2.0, max_disp=63.0, min_disp=0.0, device=0, lib=None):
+        """Python mirror of NaiveStereoEnergy (LES/StereoEnergy.h:629-764; MiddV2 parameters LES/main.cpp:86-121):
+        image-based matching cost, no volume.  Every method of the volume-based operator works on it."""
+        self = cls.__new__(cls)
+        self.L = load(lib)
+        self.imL = np.ascontiguousarray(imL, np.uint8)
+        self.imR = np.ascontiguousarray(imR, np.uint8)
+        self.H, self.W = self.imL.shape[:2]
+        self.D = 1
+        self.max_disp = float(max_disp)
+        self.params = Params(self.H, self.W, 1, windR, eps, th_col, self.max_disp, float(min_disp), device, 0)
+        self._keep = None
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.L.les_hip_create_naive(C.byref(h), C.byref(self.params), _ptr(self.imL), _ptr(self.imR), C.c_float(alpha), C.c_float(th_grad)))
+        self.h = h
+        return self
 
     def _chk(self, rc):
         if rc != 0:

@@ -58,6 +58,20 @@ const StripEntry kStrips[] = {
     LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
     LES_STRIP_ENTRY(10, 4, 96, 21, 4, 3), LES_STRIP_ENTRY(10, 5, 80, 21, 3, 3),
 };
+// image-based matching cost (les_hip_create_naive): one conservative configuration per radius
+#define LES_NAIVE_ENTRY(R_, WA_, BY_, SEG_, MW_) \
+    { R_, 0, les::StripCfg<R_, WA_, BY_, SEG_>::TW, les::StripCfg<R_, WA_, BY_, SEG_>::NT, les::les_strip_kernel<R_, WA_, BY_, SEG_, MW_, 1> }
+const StripEntry kNaiveStrips[] = {
+    LES_NAIVE_ENTRY(1, 64, 16, 4, 2), LES_NAIVE_ENTRY(2, 64, 16, 4, 2), LES_NAIVE_ENTRY(3, 64, 16, 4, 2), LES_NAIVE_ENTRY(4, 64, 16, 4, 2),
+    LES_NAIVE_ENTRY(5, 64, 16, 4, 2), LES_NAIVE_ENTRY(6, 64, 16, 4, 2), LES_NAIVE_ENTRY(7, 64, 16, 4, 2), LES_NAIVE_ENTRY(8, 64, 16, 4, 2),
+    LES_NAIVE_ENTRY(9, 64, 16, 4, 2), LES_NAIVE_ENTRY(10, 64, 16, 4, 2), LES_NAIVE_ENTRY(12, 64, 16, 4, 2), LES_NAIVE_ENTRY(15, 96, 16, 6, 2),
+};
+const StripEntry* find_naive_strip(int R)
+{
+    for (const auto& e : kNaiveStrips)
+        if (e.R == R) return &e;
+    return nullptr;
+}
 const StripEntry* find_strip(int R)
 {
     int variant = 0;
@@ -78,6 +92,7 @@ struct ViewData {
     bool own_vol = false;
     float4* stats = nullptr;
     uint32_t* ipk = nullptr;
+    float4* feat = nullptr;              // NaiveStereoEnergy feature image (image-based matching cost)
 };
 
 }  // namespace
@@ -89,6 +104,9 @@ struct les_hip_ctx {
     hipStream_t stream;
     les::Geom geom;
     ViewData v[2];
+    float naive_alpha = 0;
+    int naive = 0;                       // 1: raw cost from the feature images (les_hip_create_naive), no volume
+    float th_color = 0, th_grad = 0;
     // scratch reused by the non-prepared entry points and by batch_run
     float4* d_planes = nullptr; size_t planes_cap = 0;
     float* d_map = nullptr;                         // H*W floats
@@ -178,12 +196,16 @@ int ensure_planes(les_hip_ctx* c, size_t n)
 int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, const float4* d_planes, float* d_out, int check)
 {
     if (njobs <= 0) return LES_HIP_OK;
-    if (mode < 0 || mode > 1 || !c->v[mode].vol || !c->v[mode].stats) return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
-    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk};
+    if (mode < 0 || mode > 1 || !c->v[mode].stats || (c->naive ? !c->v[1 - mode].feat : !c->v[mode].vol))
+        return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
+    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
+    if (c->naive) { view.feat_self = c->v[mode].feat; view.feat_other = c->v[1 - mode].feat; }
     hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, c->stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
+
+float naive_alpha(const les_hip_ctx* c);
 
 int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
 {
@@ -206,6 +228,10 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     HIPCHECK(hipMalloc((void**)&v.stats, P * 3 * sizeof(float4)));
     HIPCHECK(hipMalloc((void**)&d_hs, P * 9 * sizeof(double)));
     const int W = c->p.W, H = c->p.H;
+    if (c->naive) {
+        HIPCHECK(hipMalloc((void**)&v.feat, P * sizeof(float4)));
+        hipLaunchKernelGGL(les::les_naive_features_kernel, dim3((c->p.W + 255) / 256, c->p.H), dim3(256), 0, c->stream, d_img, v.feat, c->p.H, c->p.W, naive_alpha(c));
+    }
     hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, c->stream, d_img, v.ipk, (int)P);
     hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, v.ipk, d_hs, H, W, c->R);
     hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.stats, H, W, c->R, c->p.eps);
@@ -215,6 +241,8 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     HIPCHECK(hipFree(d_hs));
     return LES_HIP_OK;
 }
+
+float naive_alpha(const les_hip_ctx* c) { return c->naive_alpha; }
 
 }  // namespace
 
@@ -228,15 +256,17 @@ int les_hip_strip_width(int R)
     return e ? e->TW : 0;
 }
 
-int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
-                   const float* volL, const float* volR)
+static int create_common(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
+                         const float* volL, const float* volR, int naive, float alpha, float th_grad)
 {
     if (!out || !params) return fail(LES_HIP_ERR_ARG, "null argument");
     *out = nullptr;
-    const les_hip_params& p = *params;
+    les_hip_params p = *params;
+    if (naive) { p.D = 1; p.volumes_on_device = 0; }
     if (p.H <= 0 || p.W <= 0 || p.D <= 0 || p.windR < 2) return fail(LES_HIP_ERR_ARG, "bad dimensions");
+    if (naive && (!imL || !imR)) return fail(LES_HIP_ERR_ARG, "the image-based matching cost needs both views");
     if ((unsigned long long)p.H * p.W * p.D >= (1ull << 32)) return fail(LES_HIP_ERR_UNSUPPORTED, "volumes of 2^32 or more floats are not supported (32-bit element offsets)");
-    const StripEntry* strip = find_strip(p.windR / 2);
+    const StripEntry* strip = naive ? find_naive_strip(p.windR / 2) : find_strip(p.windR / 2);
     if (!strip) return fail(LES_HIP_ERR_UNSUPPORTED, "no kernel instantiated for guided-filter radius %d (windR %d)", p.windR / 2, p.windR);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LES_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -251,6 +281,12 @@ int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_
     c->geom.D0 = (int)(-p.min_disparity);                       // LES/CostVolumeEnergy.h:67
     c->geom.th_col = p.th_col; c->geom.pad_ = 0.0f;
     c->geom.maxd = p.max_disparity; c->geom.mind = p.min_disparity;
+    c->naive = naive;
+    if (naive) {
+        c->th_color = p.th_col * (1.0f - alpha);                 // LES/StereoEnergy.h:662
+        c->th_grad = th_grad * alpha;                            // LES/StereoEnergy.h:663
+        c->naive_alpha = alpha;
+    }
     const uint8_t* ims[2] = {imL, imR};
     const float* vols[2] = {volL, volR};
     for (int m = 0; m < 2; m++) {
@@ -265,6 +301,17 @@ int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_
     return LES_HIP_OK;
 }
 
+int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
+                   const float* volL, const float* volR)
+{
+    return create_common(out, params, imL, imR, volL, volR, 0, 0.0f, 0.0f);
+}
+
+int les_hip_create_naive(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR, float alpha, float th_grad)
+{
+    return create_common(out, params, imL, imR, nullptr, nullptr, 1, alpha, th_grad);
+}
+
 void les_hip_destroy(les_hip_ctx* c)
 {
     if (!c) return;
@@ -273,6 +320,7 @@ void les_hip_destroy(les_hip_ctx* c)
         if (c->v[m].own_vol && c->v[m].vol) (void)hipFree(c->v[m].vol);
         if (c->v[m].stats) (void)hipFree(c->v[m].stats);
         if (c->v[m].ipk) (void)hipFree(c->v[m].ipk);
+        if (c->v[m].feat) (void)hipFree(c->v[m].feat);
     }
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_map) (void)hipFree(c->d_map);

@@ -43,9 +43,15 @@ struct Geom {
 };
 
 struct View {
-    const float* vol;          // [D][H][W]
+    const float* vol;          // [D][H][W]   (null for the image-based "naive" matching cost)
     const float4* stats;       // [H*W][3] : {mean_I'_k, inv[k][0], inv[k][1], inv[k][2]}, k = 0..2
     const uint32_t* ipk;       // [H*W] guide pixel packed B | G<<8 | R<<16
+    // NaiveStereoEnergy (LES/StereoEnergy.h:629-764): 4-channel feature images {(1-alpha) B, G, R, alpha Gx} of this
+    // view and of the other one; the raw cost is computed from them instead of a volume when feat_self != null
+    const float4* feat_self;
+    const float4* feat_other;
+    float sign;                // +1 for the left view, -1 for the right one (x_src = x - sign * d)
+    float th_color, th_grad;   // (1-alpha) th_col, alpha th_grad   (LES/StereoEnergy.h:662-663)
 };
 
 struct Job {
@@ -122,6 +128,36 @@ __device__ __forceinline__ float gather_finish(const Geom& g, const GatherPrep& 
     C = r.mode == 2 ? LES_COST_INVALID : C;
     const float p = (g.th_col < C) ? g.th_col : C;
     return r.mode == 3 ? 0.0f : p;
+}
+
+// NaiveStereoEnergy raw cost, LES/StereoEnergy.h:702-742: the other view is sampled at x - sign * d on the same row with
+// the bilinear interpolation of cv::warpAffine (source coordinate rounded to 1/32 pixel, replicated border).
+struct NaivePrep {
+    uint32_t ia, ib;    // element offsets of the two feature taps in the other view
+    float w1;
+};
+__device__ __forceinline__ NaivePrep naive_prepare(const Geom& g, float sign, float a, float b, float c, int gx, int gy)
+{
+    NaivePrep r;
+    const float z = (a * (float)gx + b * (float)gy) + c;
+    const double sx = (double)gx - (double)sign * (double)z;
+    const double q = floor(sx * 32.0 + 0.5) / 32.0;
+    const double fl = floor(q);
+    r.w1 = (float)(q - fl);
+    const double flc = fmin(fmax(fl, -2.0), (double)g.W + 1.0);       // NaN -> -2: defined conversion, weights stay NaN
+    const int x0 = (int)flc;
+    const int xa = min(max(x0, 0), g.W - 1), xb = min(max(x0 + 1, 0), g.W - 1);
+    r.ia = (uint32_t)gy * (uint32_t)g.W + (uint32_t)xa;
+    r.ib = (uint32_t)gy * (uint32_t)g.W + (uint32_t)xb;
+    return r;
+}
+__device__ __forceinline__ float naive_finish(const View& v, const NaivePrep& r, float4 own, float4 fa, float4 fb)
+{
+    const float w0 = 1.0f - r.w1;
+    const float v0 = w0 * fa.x + r.w1 * fb.x, v1 = w0 * fa.y + r.w1 * fb.y, v2 = w0 * fa.z + r.w1 * fb.z, v3 = w0 * fa.w + r.w1 * fb.w;
+    const float col = (fabsf(own.x - v0) + fabsf(own.y - v1)) + fabsf(own.z - v2);
+    const float grad = fabsf(own.w - v3);
+    return ((col < v.th_color) ? col : v.th_color) + ((grad < v.th_grad) ? grad : v.th_grad);      // std::min(th, x)
 }
 
 // LES/StereoEnergy.h:560-610
@@ -256,7 +292,7 @@ struct StripCfg {
     static_assert(TW > 0, "strip too narrow for this radius");
 };
 
-template <int R, int WA, int BY, int SEG, int MW>
+template <int R, int WA, int BY, int SEG, int MW, int SRC = 0>       // SRC 0: cost volume, 1: image-based matching cost
 __global__ void __launch_bounds__(4 * WA, MW)
 les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
                  float* __restrict__ out, int njobs, int check)
@@ -337,36 +373,56 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
         // up to GB rows per lane are issued before any is consumed (memory-level parallelism, bounded so
         // that the register footprint stays small).
         {
-            constexpr int GB = 4;
-            static_for<(GPASS + GB - 1) / GB>([&](auto btag) {
-                constexpr int J0 = decltype(btag)::value * GB;
-                constexpr int JN = (GPASS - J0) < GB ? (GPASS - J0) : GB;
-                GatherPrep gp[JN];
-                float v0[JN], v1[JN];
-                uint32_t ipa[JN];
-#pragma unroll
-                for (int j = 0; j < JN; j++) {
-                    const int i = (J0 + j) * GRP + g_ri;
+            if constexpr (SRC == 1) {
+                // image-based matching cost (one row per lane in flight keeps the register footprint below the volume path's)
+#pragma unroll 1
+                for (int jp = 0; jp < GPASS; jp++) {
+                    const int i = jp * GRP + g_ri;
                     const int t = t0 + i;
                     const int gy = job.ty0 - 2 * R + t;
                     const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
                     const int sy = min(max(gy, job.cy0), job.cy1 - 1);
                     const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
-                    const float d_base = plane.y * (float)sy + plane.z;
-                    gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
-                    v0[j] = view.vol[gp[j].i0];
-                    v1[j] = view.vol[gp[j].i1];
-                    ipa[j] = view.ipk[px];
-                }
-#pragma unroll
-                for (int j = 0; j < JN; j++) {
-                    const int i = (J0 + j) * GRP + g_ri;
+                    const NaivePrep np = naive_prepare(g, view.sign, plane.x, plane.y, plane.z, g_sx, sy);
+                    const float4 own = view.feat_self[px], fa = view.feat_other[np.ia], fb = view.feat_other[np.ib];
+                    const uint32_t ip = view.ipk[px];
                     if (g_lane && i < BY) {
-                        s_p[i][g_xi] = gather_finish(g, gp[j], v0[j], v1[j]);
-                        s_ipk[i][g_xi] = ipa[j];
+                        s_p[i][g_xi] = inside ? naive_finish(view, np, own, fa, fb) : 0.0f;
+                        s_ipk[i][g_xi] = ip;
                     }
                 }
-            });
+            } else {
+                constexpr int GB = 4;
+                static_for<(GPASS + GB - 1) / GB>([&](auto btag) {
+                    constexpr int J0 = decltype(btag)::value * GB;
+                    constexpr int JN = (GPASS - J0) < GB ? (GPASS - J0) : GB;
+                    GatherPrep gp[JN];
+                    float v0[JN], v1[JN];
+                    uint32_t ipa[JN];
+#pragma unroll
+                    for (int j = 0; j < JN; j++) {
+                        const int i = (J0 + j) * GRP + g_ri;
+                        const int t = t0 + i;
+                        const int gy = job.ty0 - 2 * R + t;
+                        const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
+                        const int sy = min(max(gy, job.cy0), job.cy1 - 1);
+                        const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
+                        const float d_base = plane.y * (float)sy + plane.z;
+                        gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
+                        v0[j] = view.vol[gp[j].i0];
+                        v1[j] = view.vol[gp[j].i1];
+                        ipa[j] = view.ipk[px];
+                    }
+#pragma unroll
+                    for (int j = 0; j < JN; j++) {
+                        const int i = (J0 + j) * GRP + g_ri;
+                        if (g_lane && i < BY) {
+                            s_p[i][g_xi] = gather_finish(g, gp[j], v0[j], v1[j]);
+                            s_ipk[i][g_xi] = ipa[j];
+                        }
+                    }
+                });
+            }
             uint32_t ipo[OPASS];
 #pragma unroll
             for (int j = 0; j < OPASS; j++) {
@@ -531,6 +587,25 @@ __global__ void les_stats_finish_kernel(const double* __restrict__ hs, float4* _
     stats[px * 3 + 0] = make_float4((float)(m0 - 0.5), (float)irr, (float)irg, (float)irb);
     stats[px * 3 + 1] = make_float4((float)(m1 - 0.5), (float)irg, (float)igg, (float)igb);
     stats[px * 3 + 2] = make_float4((float)(m2 - 0.5), (float)irb, (float)igb, (float)ibb);
+}
+
+// NaiveStereoEnergy constructor, LES/StereoEnergy.h:644-664: feature image {(1-alpha) B, (1-alpha) G, (1-alpha) R,
+// alpha Gx}, Gx = 0.5 * (gray(x+1) - gray(x-1)) with replicated border, gray = 0.114 B + 0.587 G + 0.299 R.
+__global__ void les_naive_features_kernel(const uint8_t* __restrict__ img, float4* __restrict__ feat, int H, int W, float alpha)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    auto gray = [&](int xx) {
+        const uint8_t* p = img + ((size_t)y * W + xx) * 3;
+        return ((float)p[0] * 0.114f + (float)p[1] * 0.587f) + (float)p[2] * 0.299f;
+    };
+    const float gx = 0.5f * (gray(min(x + 1, W - 1)) - gray(max(x - 1, 0)));
+    const uint8_t* p = img + ((size_t)y * W + x) * 3;
+    const double k = 1.0 - (double)alpha;
+    float4 f;
+    f.x = (float)((double)p[0] * k); f.y = (float)((double)p[1] * k); f.z = (float)((double)p[2] * k);
+    f.w = gx * alpha;
+    feat[(size_t)y * W + x] = f;
 }
 
 // ---------------------------------------------------------------------------------------------------

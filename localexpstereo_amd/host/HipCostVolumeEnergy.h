@@ -38,6 +38,26 @@ public:
         setImages(imL, imR);           // pairwise weights for the host graph cut
     }
     ~HipCostVolumeEnergy() override { les_hip_destroy(ctx_); }
+
+protected:
+    // image-based matching cost (HipNaiveStereoEnergy below)
+    struct NaiveTag {};
+    HipCostVolumeEnergy(NaiveTag, const uint8_t* imL, const uint8_t* imR, int width, int height, Parameters p, float MAX_DISPARITY,
+                        float MIN_DISPARITY, int device)
+        : StereoEnergy(width, height, std::move(p), MAX_DISPARITY, MIN_DISPARITY), ctx_(nullptr)
+    {
+        if (params.filterName != "GF") throw std::runtime_error("HipNaiveStereoEnergy implements the default \"GF\" joint filter");
+        les_hip_params hp;
+        hp.H = height; hp.W = width; hp.D = 1;
+        hp.windR = params.windR; hp.eps = params.filter_param1; hp.th_col = params.th_col;
+        hp.max_disparity = MAX_DISPARITY; hp.min_disparity = MIN_DISPARITY;
+        hp.device = device; hp.volumes_on_device = 0;
+        if (les_hip_create_naive(&ctx_, &hp, imL, imR, params.alpha, params.th_grad) != LES_HIP_OK)
+            throw std::runtime_error(std::string("les_hip_create_naive: ") + les_hip_last_error());
+        setImages(imL, imR);
+    }
+
+public:
     HipCostVolumeEnergy(const HipCostVolumeEnergy&) = delete;
     HipCostVolumeEnergy& operator=(const HipCostVolumeEnergy&) = delete;
 
@@ -88,6 +108,15 @@ private:
 
     les_hip_ctx* ctx_;
     mutable std::mutex mu_;
+};
+
+// Drop-in for NaiveStereoEnergy (LES/StereoEnergy.h:629-764), the energy of the MiddV2 configuration
+// (LES/PMStereoBase.h:37, parameters LES/main.cpp:86-121): same operator, raw cost from the two images.
+class HipNaiveStereoEnergy : public HipCostVolumeEnergy {
+public:
+    HipNaiveStereoEnergy(const uint8_t* imL, const uint8_t* imR, int width, int height, Parameters p, float MAX_DISPARITY,
+                         float MIN_DISPARITY = 0, int device = 0)
+        : HipCostVolumeEnergy(NaiveTag{}, imL, imR, width, height, std::move(p), MAX_DISPARITY, MIN_DISPARITY, device) {}
 };
 
 }  // namespace les_host

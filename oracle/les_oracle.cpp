@@ -409,15 +409,16 @@ static void naive_raw(const les_oracle* o, int mode, les_rect fr, les_plane plan
             const float z = plane.a * (float)X + plane.b * (float)Y + plane.c;
             const double sx = (double)X - (double)sign * z;
             const double q = std::floor(sx * 32.0 + 0.5) / 32.0;                     // INTER_BITS = 5
-            const int x0 = (int)std::floor(q);
-            const float w1 = (float)(q - x0), w0 = 1.0f - w1;
+            const double fl = std::floor(q);
+            const float w1 = (float)(q - fl), w0 = 1.0f - w1;
+            const int x0 = (int)std::fmin(std::fmax(fl, -2.0), (double)W + 1.0);     // defined conversion for NaN / huge planes
             const int xa = std::min(std::max(x0, 0), W - 1), xb = std::min(std::max(x0 + 1, 0), W - 1);
             const float* a = &I1[((size_t)Y * W + xa) * 4];
             const float* b = &I1[((size_t)Y * W + xb) * 4];
             const float* p0 = &I0[((size_t)Y * W + X) * 4];
             float v[4];
             for (int c = 0; c < 4; c++) v[c] = w0 * a[c] + w1 * b[c];
-            const float col = std::fabs(p0[0] - v[0]) + std::fabs(p0[1] - v[1]) + std::fabs(p0[2] - v[2]);
+            const float col = (std::fabs(p0[0] - v[0]) + std::fabs(p0[1] - v[1])) + std::fabs(p0[2] - v[2]);
             raw[(size_t)y * fr.w + x] = std::min(o->thresh_color, col) + std::min(o->thresh_gradient, std::fabs(p0[3] - v[3]));   // :738-740
         }
 }

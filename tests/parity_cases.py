@@ -8,11 +8,13 @@ Tolerance (BASELINE.json north_star): aggregated costs within 1e-4 relative; wri
 |got - ref| <= RTOL*|ref| + ATOL with ATOL = 1e-6 (costs live in [0, th_col=0.5]; the float32 ulp at
 0.5 is 6e-8).  Invalid-label sentinels (1e6) and the set of written pixels must match exactly.
 """
+import os
+
 import numpy as np
 
 from localexpstereo_amd import api, synth
 from oracle import oracle as om
-from tests.util import load_cones_crop
+from tests.util import GOLDEN, load_cones_crop
 
 RTOL = 1e-4
 ATOL = 1e-6
@@ -45,6 +47,56 @@ class Pair:
 
     def close(self):
         self.e.close()
+
+
+class NaivePair:
+    """Oracle and library contexts of the image-based matching cost (NaiveStereoEnergy, LES/StereoEnergy.h:629-764)."""
+
+    def __init__(self, lib, imL, imR, max_disp, windR=20, eps=1e-4, alpha=0.9, th_col=10.0, th_grad=2.0):
+        self.o = om.Oracle.naive(imL, imR, max_disp, windR=windR, eps=eps, alpha=alpha, th_col=th_col, th_grad=th_grad)
+        self.e = api.HipCostVolumeEnergy.naive(imL, imR, windR=windR, eps=eps, alpha=alpha, th_col=th_col, th_grad=th_grad,
+                                               max_disp=max_disp, lib=lib)
+        self.H, self.W, self.D = self.o.H, self.o.W, int(max_disp) + 1
+
+    def close(self):
+        self.e.close()
+
+
+def case_naive(lib, windR=20, pm=True):
+    """Config 1's energy (MiddV2 parameters, LES/main.cpp:86-121) on the cones crop: single calls in both views with
+    valid / partly invalid / out-of-image / NaN planes, a lock-step of cells, and one PatchMatch set update."""
+    imL, imR = load_cones_crop()
+    pr = NaivePair(lib, imL, imR, 31.0, windR=windR)
+    H, W = pr.H, pr.W
+    R2 = windR
+    worst = 0.0
+    calls = [
+        (0, (0, 0, 62, 62), (0, 0, 42, 42), (0.0, 0.0, 12.0, 0.0)),
+        (0, (19, 22, 82, 74), (39, 42, 42, 34), (0.05, -0.03, 14.25, 0.0)),
+        (1, (W - 62, H - 62, 62, 62), (W - 42, H - 42, 42, 42), (-0.11, 0.07, 9.5, 0.0)),
+        (0, (0, 0, W, H), (0, 0, W, H), (0.01, 0.02, 10.125, 0.0)),
+        (1, (0, 0, W, H), (0, 0, W, H), (-0.02, 0.01, 17.3, 0.0)),
+        (1, (30, 0, 90, 60), (50, 0, 50, 40), (0.3, 0.2, -20.0, 0.0)),                 # warps far outside the other view
+        (0, (0, 36, 70, 60), (0, 56, 50, 40), (0.0, 0.0, 31.0, 0.0)),
+        (0, (40, 40, 41, 41), (60, 60, 1, 1), (0.02, 0.01, 5.0, 0.0)),
+        (0, (10, 8, 80, 70), (30, 28, 40, 30), (float("nan"), 0.0, 1.0, 0.0)),
+        (0, (10, 8, 80, 70), (30, 28, 40, 30), (0.0, 0.0, float("inf"), 0.0)),
+        (1, (10, 8, 80, 70), (30, 28, 40, 30), (0.0, 0.0, 1e9, 0.0)),
+    ]
+    for mode, fr, tr, pl in calls:
+        for check in (True, False):
+            ref = pr.o.unary(fr, tr, pl, mode=mode, check=check)
+            got = pr.e.ComputeUnaryPotential(fr, tr, np.full((H, W), np.nan, np.float32), pl, mode=mode, check=check)
+            worst = max(worst, compare_maps(got, ref, tight=False))
+    layer = om.Layer(W, H, windR, 9)
+    for s, mode in ((0, 0), (7, 1)):
+        cells = layer.sets[s]
+        planes = random_planes(len(cells), 32, H, W, 17 + s, slant=0.2)
+        ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
+        got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
+        worst = max(worst, compare_maps(got, ref, tight=False))
+    pr.close()
+    return worst
 
 
 def cones_pair(lib, D=16, **kw):
@@ -541,4 +593,39 @@ def case_quality_cones(lib, device, iters=3):
     assert hist[0][0] > 80.0                                     # random initial labels
     assert all(b[1] <= a[1] + 1e-3 for a, b in zip(hist, hist[1:])), hist      # WTA never increases the energy
     assert hist[-1][0] < 20.0, hist                              # converged to the surface almost everywhere
+    return hist
+
+
+def case_quality_cones_naive(lib, device, iters=2):
+    """Config 1's own energy (NaiveStereoEnergy, MiddV2 parameters LES/main.cpp:86-121, layers :300-306) driven by the
+    device-resident PatchMatch iterations on the cones crop.  The left crop is padded by 64 columns so that both
+    views have the width of the stored wide right crop; bad pixels are counted on the original columns only."""
+    from localexpstereo_amd import pm
+    z = np.load(os.path.join(GOLDEN, "cones_crop.npz"))
+    imL, imRw, gt = z["imL"], z["imR_wide"], z["gt"]
+    H, W = imL.shape[:2]
+    imLw = np.concatenate([np.repeat(imL[:, :1], 64, axis=1), imL], axis=1)
+    e = api.HipCostVolumeEnergy.naive(imLw, np.ascontiguousarray(imRw), windR=20, eps=1e-4, alpha=0.9, th_col=10.0, th_grad=2.0,
+                                      max_disp=63.0, lib=lib)
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)],
+             [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]]
+    r = pm.PMRunner(e, (5, 15, 25), table, seed=11, device=device)
+    known = gt > 0
+
+    def bad(thr):
+        d = r.disparities().cpu().numpy()[:, 64:]
+        return float((np.abs(d - gt)[known] > thr).mean() * 100)
+
+    r.init_labels()
+    e.synchronize()
+    hist = [(bad(1.0), float(r.cur.sum()))]
+    for it in range(iters):
+        r.iteration(it)
+        e.synchronize()
+        hist.append((bad(1.0), float(r.cur.sum())))
+    r.close()
+    e.close()
+    assert hist[0][0] > 80.0
+    assert all(b[1] <= a[1] + 1e-3 for a, b in zip(hist, hist[1:])), hist
+    assert hist[-1][0] < 20.0, hist
     return hist

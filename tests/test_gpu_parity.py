@@ -183,6 +183,19 @@ def test_gpu_volume_preparation(cones):
     pc.case_volume_preparation(cones, None)
 
 
+def test_gpu_naive_energy(oracle_mod):
+    """Image-based matching cost of config 1 (NaiveStereoEnergy, LES/StereoEnergy.h:629-764) vs the oracle."""
+    worst = pc.case_naive(None)
+    print("naive energy max abs err", worst)
+    worst = pc.case_naive(None, windR=8)
+    print("naive energy (windR 8) max abs err", worst)
+
+
+def test_gpu_quality_on_cones_crop_naive_energy():
+    hist = pc.case_quality_cones_naive(None, "cuda", iters=2)
+    print("cones crop, config-1 energy: (bad1.0 %, energy) per iteration:", hist)
+
+
 def test_gpu_quality_on_cones_crop():
     hist = pc.case_quality_cones(None, "cuda", iters=3)
     print("bad1.0 %, energy per iteration:", hist)

@@ -135,6 +135,12 @@ def test_sim_volume_preparation(cones, sim_lib):
     pc.case_volume_preparation(cones, sim_lib)
 
 
+def test_sim_naive_energy(sim_lib, oracle_mod):
+    """Image-based matching cost of config 1 (NaiveStereoEnergy) through the same kernels."""
+    worst = pc.case_naive(sim_lib)
+    print("naive energy max abs err", worst)
+
+
 def test_sim_quality_on_cones_crop(sim_lib):
     """The same end-to-end check through the simulator build (1 iteration: the simulator is slow)."""
     imL, vol, gt = pc.cones_ad_volume()
