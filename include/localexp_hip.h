@@ -131,6 +131,19 @@ int les_hip_wta_update(les_hip_ctx* ctx, int n, const les_hip_rect* rects, const
 int les_hip_fill_out_of_view(float* vol_dev, int D, int H, int W, int mode, int device, void* hip_stream);
 int les_hip_convert_volume_l2r(const float* src_dev, float* dst_dev, int D, int H, int W, int device, void* hip_stream);
 
+/* replaces: PMStereoBase::doConsistencyCheck (LES/PMStereoBase.h:111-144) -- left-right check of the disparities of two
+ * device label maps (H x W planes each): fail = 255 where |d_other(x -/+ d) - d| > threshold, 128 where the pixel maps
+ * outside the other view, 0 otherwise.  d_failL / d_failR: H x W bytes on the device. */
+int les_hip_consistency_check(les_hip_ctx* ctx, const les_hip_plane* d_labelsL, const les_hip_plane* d_labelsR, float threshold,
+                              unsigned char* d_failL, unsigned char* d_failR);
+
+/* replaces: PMStereoBase::postProcess (LES/PMStereoBase.h:146-256), called by FastGCStereo::run for two-view runs
+ * (LES/FastGCStereo.h:199-203, threshold 1.5): consistency check, horizontal fill of the failed pixels from the nearest
+ * consistent neighbours (smaller disparity wins), then the colour-weighted median of the labels over the
+ * (2 windR + 1)^2 window with weights exp(-|dI|_1 / omega) (StereoEnergy::computePatchWeight, LES/StereoEnergy.h:251-257).
+ * Both device label maps are updated in place.  Needs both views' images in the context; windR <= 31. */
+int les_hip_post_process(les_hip_ctx* ctx, les_hip_plane* d_labelsL, les_hip_plane* d_labelsR, float threshold, float omega);
+
 /* Device memory helpers for callers without a HIP toolchain (host C++ adapter, ctypes). */
 int les_hip_malloc(les_hip_ctx* ctx, void** dev_ptr, size_t bytes);
 int les_hip_free(les_hip_ctx* ctx, void* dev_ptr);

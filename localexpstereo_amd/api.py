@@ -22,7 +22,7 @@ SYMBOLS = [
     "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
-    "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r",
+    "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
 ]
 
 
@@ -64,6 +64,8 @@ def load(path=None):
     vp, ci = C.c_void_p, C.c_int
     sig = {
         "les_hip_create": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, vp, vp]),
+        "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
+        "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
         "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),
         "les_hip_destroy": (None, [vp]),
         "les_hip_last_error": (C.c_char_p, []),
@@ -307,6 +309,29 @@ class HipCostVolumeEnergy:
         assert len(frs) == len(trs) == len(pls)
         self._chk(self.L.les_hip_unary_batch(self.h, mode, len(frs), _ptr(frs), _ptr(trs), _ptr(pls), _ptr(costs_map), int(check)))
         return costs_map
+
+    # -- dual-view post-processing (LES/PMStereoBase.h:111-256) on device label maps -----------------
+    def consistency_check(self, labelsL_dev, labelsR_dev, failL_dev, failR_dev, threshold=1.5):
+        self._chk(self.L.les_hip_consistency_check(self.h, C.c_void_p(int(labelsL_dev)), C.c_void_p(int(labelsR_dev)), C.c_float(threshold),
+                                                   C.c_void_p(int(failL_dev)), C.c_void_p(int(failR_dev))))
+
+    def post_process(self, labelsL_dev, labelsR_dev, threshold=1.5, omega=10.0):
+        """PMStereoBase::postProcess in place on two device label maps (FastGCStereo::run calls it with 1.5)."""
+        self._chk(self.L.les_hip_post_process(self.h, C.c_void_p(int(labelsL_dev)), C.c_void_p(int(labelsR_dev)), C.c_float(threshold), C.c_float(omega)))
+
+    def post_process_host(self, labelsL, labelsR, threshold=1.5, omega=10.0):
+        """Convenience form for host label maps (H x W planes): upload, post-process on the device, download."""
+        out = []
+        bufs = [DeviceBuffer(self, self.H * self.W * 16) for _ in range(2)]
+        try:
+            for b, l in zip(bufs, (labelsL, labelsR)):
+                b.upload(np.ascontiguousarray(l).view(np.float32).reshape(self.H, self.W, 4))
+            self.post_process(bufs[0].ptr, bufs[1].ptr, threshold, omega)
+            out = [b.download((self.H, self.W, 4), np.float32) for b in bufs]
+        finally:
+            for b in bufs:
+                b.free()
+        return out
 
     def wta_update(self, rects, planes, cur_cost_dev, prop_cost_dev, labels_dev, planes_on_device=False):
         rects = _rects(rects)

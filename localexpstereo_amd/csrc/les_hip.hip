@@ -7,6 +7,7 @@
 #include "../../include/localexp_hip.h"
 #include "les_kernels.h"
 #include "les_propose.h"
+#include "les_post.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -579,6 +580,123 @@ int les_hip_convert_volume_l2r(const float* src, float* dst, int D, int H, int W
     HIPCHECK(hipSetDevice(device));
     hipLaunchKernelGGL(les::les_convert_l2r_kernel, dim3((W + 255) / 256, H, D), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W);
     HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+// ---- dual-view post-processing (LES/PMStereoBase.h:111-256)
+namespace {
+struct PostScratch {
+    float* disp[2] = {nullptr, nullptr};
+    uint8_t *fail = nullptr, *failb = nullptr, *fail2 = nullptr;
+    float4* copy = nullptr;
+    float* wtab = nullptr;
+    PostScratch() = default;
+    PostScratch(const PostScratch&) = delete;              // launches must capture the raw pointers, not this owner
+    PostScratch& operator=(const PostScratch&) = delete;
+    ~PostScratch()
+    {
+        for (float* d : disp) if (d) (void)hipFree(d);
+        if (fail) (void)hipFree(fail);
+        if (failb) (void)hipFree(failb);
+        if (fail2) (void)hipFree(fail2);
+        if (copy) (void)hipFree(copy);
+        if (wtab) (void)hipFree(wtab);
+    }
+};
+int post_disparities(les_hip_ctx* c, PostScratch& ps, const les_hip_plane* const labels[2])
+{
+    const int H = c->p.H, W = c->p.W;
+    const size_t P = (size_t)H * W;
+    for (int m = 0; m < 2; m++) {
+        if (!ps.disp[m]) HIPCHECK(hipMalloc((void**)&ps.disp[m], P * sizeof(float)));
+        const float4* lab = (const float4*)labels[m];
+        float* disp = ps.disp[m];
+        hipLaunchKernelGGL(les::les_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, lab, disp, H, W);
+    }
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+}  // namespace
+
+int les_hip_consistency_check(les_hip_ctx* c, const les_hip_plane* d_labelsL, const les_hip_plane* d_labelsR, float threshold,
+                              unsigned char* d_failL, unsigned char* d_failR)
+{
+    if (!c || !d_labelsL || !d_labelsR || !d_failL || !d_failR) return fail(LES_HIP_ERR_ARG, "null argument");
+    HIPCHECK(hipSetDevice(c->p.device));
+    const int H = c->p.H, W = c->p.W;
+    PostScratch ps;
+    const les_hip_plane* labels[2] = {d_labelsL, d_labelsR};
+    int rc = post_disparities(c, ps, labels);
+    if (rc) return rc;
+    unsigned char* out[2] = {d_failL, d_failR};
+    for (int m = 0; m < 2; m++) {
+        const float *d_self = ps.disp[m], *d_other = ps.disp[1 - m];
+        unsigned char* o = out[m];
+        const float sign = m ? -1.0f : 1.0f;
+        hipLaunchKernelGGL(les::les_lr_check_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_self, d_other, o, H, W, sign, threshold);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return LES_HIP_OK;
+}
+
+int les_hip_post_process(les_hip_ctx* c, les_hip_plane* d_labelsL, les_hip_plane* d_labelsR, float threshold, float omega)
+{
+    if (!c || !d_labelsL || !d_labelsR) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (!c->v[0].ipk || !c->v[1].ipk) return fail(LES_HIP_ERR_ARG, "post-processing needs both views' images");
+    const int windR = c->p.windR;
+    if (windR > 31) return fail(LES_HIP_ERR_UNSUPPORTED, "weighted median window radius %d > 31", windR);
+    HIPCHECK(hipSetDevice(c->p.device));
+    const int H = c->p.H, W = c->p.W;
+    const size_t P = (size_t)H * W;
+    PostScratch ps;
+    les_hip_plane* labels[2] = {d_labelsL, d_labelsR};
+    int rc = post_disparities(c, ps, labels);
+    if (rc) return rc;
+    HIPCHECK(hipMalloc((void**)&ps.fail, P));
+    HIPCHECK(hipMalloc((void**)&ps.failb, 2 * P));
+    HIPCHECK(hipMalloc((void**)&ps.fail2, P));
+    HIPCHECK(hipMalloc((void**)&ps.copy, P * sizeof(float4)));
+    {
+        // computePatchWeight (LES/StereoEnergy.h:251-257): exp(-|dI|_1 / omega) in float; |dI|_1 of 8-bit colours is an integer
+        std::vector<float> tab(766);
+        for (int k = 0; k < 766; k++) tab[k] = std::exp(-(float)k / omega);
+        HIPCHECK(hipMalloc((void**)&ps.wtab, tab.size() * sizeof(float)));
+        HIPCHECK(hipMemcpyAsync(ps.wtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+    }
+    const dim3 g((W + 255) / 256, H), b(256);
+    // both fail masks come from the labels before any of them is modified (LES/PMStereoBase.h:158-164)
+    uint8_t *failm = ps.fail, *fail2 = ps.fail2;
+    const float* wtab = ps.wtab;
+    float4* copy = ps.copy;
+    for (int m = 0; m < 2; m++) {
+        const float *d_self = ps.disp[m], *d_other = ps.disp[1 - m];
+        uint8_t* failb = ps.failb + m * P;
+        float4* lab = (float4*)labels[m];
+        const float sign = m ? -1.0f : 1.0f;
+        hipLaunchKernelGGL(les::les_lr_check_kernel, g, b, 0, c->stream, d_self, d_other, failm, H, W, sign, threshold);
+        hipLaunchKernelGGL(les::les_fail_dilate_kernel, g, b, 0, c->stream, failm, failb, fail2, H, W);
+        hipLaunchKernelGGL(les::les_nn_fill_kernel, g, b, 0, c->stream, failb, fail2, lab, H, W);
+    }
+    for (int m = 0; m < 2; m++) {
+        HIPCHECK(hipMemcpyAsync(ps.copy, labels[m], P * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        const dim3 gp(W, H);
+        const int area = (2 * windR + 1) * (2 * windR + 1);
+        const uint8_t* failb = ps.failb + m * P;
+        float4* lab = (float4*)labels[m];
+        const uint32_t* ipk = c->v[m].ipk;
+        if (area <= 256)
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<256, 64>), gp, dim3(64), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+        else if (area <= 1024)
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<1024, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+        else if (area <= 2048)
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<2048, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+        else
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<4096, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
     return LES_HIP_OK;
 }
 

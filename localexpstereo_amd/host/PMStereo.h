@@ -267,6 +267,8 @@ public:
                                 gcLockSteps++;
                             }
         }
+        // two-view runs end with the left-right post-processing (LES/FastGCStereo.h:199-203)
+        if (ok && viewModes.size() == 2) ok = postProcess(1.5f);
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (auto& lb : batches)
             for (SetBatch& sb : lb) { les_hip_batch_destroy(sb.b); les_hip_free(ctx, sb.rng); les_hip_free(ctx, sb.planes); }
@@ -274,6 +276,27 @@ public:
         les_hip_free(ctx, d_labels); les_hip_free(ctx, d_cur); les_hip_free(ctx, d_prop);
         return ok;
     }
+
+    // PMStereoBase::postProcess (LES/PMStereoBase.h:146-256) on the device: consistency check, fill, weighted median of both
+    // views' label maps.  rawLabeling0 keeps the left labelling before it (the reference's `rawlabeling`).
+    bool postProcess(float threshold = 1.5f)
+    {
+        auto* hip = dynamic_cast<HipCostVolumeEnergy*>(stereoEnergy.get());
+        if (!hip) return false;
+        les_hip_ctx* ctx = hip->handle();
+        const size_t bytes = (size_t)width * height * sizeof(les_hip_plane);
+        rawLabeling0 = currentLabeling_[0];
+        les_hip_plane* d[2] = {nullptr, nullptr};
+        bool ok = true;
+        for (int m = 0; m < 2 && ok; m++)
+            ok = les_hip_malloc(ctx, (void**)&d[m], bytes) == LES_HIP_OK && les_hip_memcpy_h2d(ctx, d[m], currentLabeling_[m].data.data(), bytes) == LES_HIP_OK;
+        if (ok) ok = les_hip_post_process(ctx, d[0], d[1], threshold, params.omega) == LES_HIP_OK;
+        for (int m = 0; m < 2 && ok; m++) ok = les_hip_memcpy_d2h(ctx, currentLabeling_[m].data.data(), d[m], bytes) == LES_HIP_OK;
+        if (!ok) fprintf(stderr, "PMStereo::postProcess: %s\n", les_hip_last_error());
+        for (int m = 0; m < 2; m++) les_hip_free(ctx, d[m]);
+        return ok;
+    }
+    LabelMap rawLabeling0;
 
     // disparity of the current labelling (StereoEnergy::computeDisparities, LES/StereoEnergy.h:269-272)
     std::vector<float> computeDisparities(int mode) const

@@ -134,6 +134,25 @@ static int cmd_run(int argc, char** argv)
         if (st2->maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
         if (bad_gc > 10.0) { printf("FAIL: graph-cut run did not converge\n"); fail = 1; }
     }
+    // (d) two-view run with the left-right post-processing.  The synthetic scene has one image and one volume, so the
+    //     "right" view here is the same data seen with the opposite warp sign: the consistency check must flag pixels, the
+    //     fill + weighted median must leave every label equal to some label of its window, and the left result must stay good.
+    {
+        auto st = build(7);
+        st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        double sec = 0;
+        if (!st->runDevice(iters, {0, 1}, &sec, 0)) { printf("FAIL: runDevice (two views)\n"); return 1; }
+        size_t changed = 0;
+        for (size_t i = 0; i < st->rawLabeling0.data.size(); i++) {
+            const Plane &a = st->rawLabeling0.data[i], &b = st->currentLabeling_[0].data[i];
+            changed += !(a.a == b.a && a.b == b.b && a.c == b.c);
+        }
+        const double bad = bad_pixels(st->computeDisparities(0), s, 1.0f);
+        printf("two views iter %d + post-processing: %.2f%% of the left labels replaced, bad1.0=%.2f%%  (%.3f s)\n", iters,
+               100.0 * changed / st->rawLabeling0.data.size(), bad, sec);
+        if (changed == 0) { printf("FAIL: post-processing changed nothing\n"); fail = 1; }
+    }
     printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
     return fail;
 }

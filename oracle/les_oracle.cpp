@@ -895,3 +895,115 @@ extern "C" void les_convert_volume_l2r(const float* src, float* dst, int D, int 
             for (int x = W - 1 - d; x < W; x++) s1[x] = edge1;                       // :193-194
         }
 }
+
+// =====================================================================================================
+// Dual-view post-processing  (LES/PMStereoBase.h:111-256)
+// =====================================================================================================
+extern "C" void les_consistency_check(const float* dispL, const float* dispR, int H, int W, float dispThreshold, uint8_t* failL, uint8_t* failR)
+{   // doConsistencyCheck, LES/PMStereoBase.h:111-144 (isValid is constant true, :80-83)
+    const float* disp[2] = {dispL, dispR};
+    uint8_t* fail[2] = {failL, failR};
+    for (int i = 0; i < 2; i++) {
+        const float sign = (i ? -1.0f : 1.0f);                                       // :121
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float ds = disp[i][(size_t)y * W + x];                         // :126
+                const float v = (float)x - ds * sign + 0.5f;                         // :127
+                uint8_t f = 128;                                                     // :135-138
+                if (v > -1.0e9f && v < 1.0e9f) {                                     // int(v) is undefined otherwise; such pixels are "outside"
+                    const int rx = int(v);
+                    if (rx >= 0 && rx < W) {                                         // :130 imageDomain.contains(q)
+                        const float dsr = disp[1 - i][(size_t)y * W + rx];
+                        f = (std::fabs(dsr - ds) > dispThreshold) ? 255 : 0;         // :131-133
+                    }
+                }
+                fail[i][(size_t)y * W + x] = f;
+            }
+    }
+}
+
+extern "C" void les_post_process(les_plane* labelsL, les_plane* labelsR, const uint8_t* imL, const uint8_t* imR, int H, int W, int windR,
+                                 float threshold, float omega)
+{   // postProcess, LES/PMStereoBase.h:146-256
+    les_plane* LR[2] = {labelsL, labelsR};
+    const uint8_t* im[2] = {imL, imR};
+    const size_t P = (size_t)H * W;
+    std::vector<float> disp[2];
+    for (int i = 0; i < 2; i++) {
+        disp[i].resize(P);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const les_plane& l = LR[i][(size_t)y * W + x];
+                disp[i][(size_t)y * W + x] = l.a * (float)x + l.b * (float)y + l.c;   // computeDisparities, LES/StereoEnergy.h:269-272
+            }
+    }
+    std::vector<uint8_t> fail[2], fail2[2];
+    for (int i = 0; i < 2; i++) { fail[i].assign(P, 0); fail2[i].assign(P, 0); }
+    les_consistency_check(disp[0].data(), disp[1].data(), H, W, threshold, fail[0].data(), fail[1].data());   // :160
+    for (int i = 0; i < 2; i++) {
+        for (auto& f : fail[i]) f = f > 0 ? 255 : 0;                                  // :161-162
+        for (int y = 0; y < H; y++)                                                   // :164-165 cv::dilate, 3x3
+            for (int x = 0; x < W; x++) {
+                uint8_t m = 0;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int xx = x + dx, yy = y + dy;
+                        if (xx >= 0 && xx < W && yy >= 0 && yy < H) m = std::max(m, fail[i][(size_t)yy * W + xx]);
+                    }
+                fail2[i][(size_t)y * W + x] = m;
+            }
+    }
+    auto getz = [](const les_plane& l, int x, int y) { return l.a * (float)x + l.b * (float)y + l.c; };
+    // horizontal NN-interpolation, :167-201
+    for (int i = 0; i < 2; i++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const size_t row = (size_t)y * W;
+                if (fail[i][row + x] == 0) continue;
+                const les_plane *pl = nullptr, *pr = nullptr;
+                int xx;
+                for (xx = x; xx >= 0 && fail2[i][row + xx] == 255; xx--);
+                if (xx >= 0) pl = &LR[i][row + xx];
+                for (xx = x; xx < W && fail2[i][row + xx] == 255; xx++);
+                if (xx < W) pr = &LR[i][row + xx];
+                if (pl == nullptr && pr == nullptr) continue;
+                else if (pl == nullptr) LR[i][row + x] = *pr;
+                else if (pr == nullptr) LR[i][row + x] = *pl;
+                else if (getz(*pl, x, y) < getz(*pr, x, y)) LR[i][row + x] = *pl;
+                else LR[i][row + x] = *pr;
+            }
+    // weighted median filter, :207-250.  std::sort is not stable; equal disparities are ordered here by window scan
+    // position (the stable order), which is what the device kernel implements as well.
+    struct Cand { les_plane l; float w; float z; };
+    for (int i = 0; i < 2; i++) {
+        std::vector<les_plane> copy(LR[i], LR[i] + P);                                // :209
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < H; y++) {
+            std::vector<Cand> median;
+            for (int x = 0; x < W; x++) {
+                if (fail[i][(size_t)y * W + x] == 0) continue;
+                median.clear();
+                double sumw = 0;
+                const int x0 = std::max(x - windR, 0), y0 = std::max(y - windR, 0), x1 = std::min(x + windR + 1, W), y1 = std::min(y + windR + 1, H);
+                const uint8_t* ip = im[i] + ((size_t)y * W + x) * 3;
+                for (int yy = y0; yy < y1; yy++)
+                    for (int xx = x0; xx < x1; xx++) {
+                        const uint8_t* iq = im[i] + ((size_t)yy * W + xx) * 3;
+                        // computePatchWeight, LES/StereoEnergy.h:251-257
+                        const float absdiff = std::fabs((float)ip[0] - (float)iq[0]) + std::fabs((float)ip[1] - (float)iq[1]) + std::fabs((float)ip[2] - (float)iq[2]);
+                        const float w = std::exp(-absdiff / omega);
+                        sumw += w;
+                        const les_plane& l = copy[(size_t)yy * W + xx];
+                        median.push_back(Cand{l, w, getz(l, x, y)});
+                    }
+                std::stable_sort(median.begin(), median.end(), [](const Cand& a, const Cand& b) { return a.z < b.z; });
+                const double center = sumw / 2.0;
+                sumw = 0;
+                for (size_t j = 0; j < median.size(); j++) {
+                    sumw += median[j].w;
+                    if (sumw > center) { LR[i][(size_t)y * W + x] = median[j].l; break; }
+                }
+            }
+        }
+    }
+}

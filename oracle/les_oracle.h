@@ -146,6 +146,11 @@ int       les_ransac_sample_count(int ni, int ptNum, int pf, double conf); /* :2
 void les_fill_out_of_view(float* vol, int D, int H, int W, int mode);
 void les_convert_volume_l2r(const float* src, float* dst, int D, int H, int W);
 
+/* PMStereoBase::doConsistencyCheck / postProcess (LES/PMStereoBase.h:111-256) */
+void les_consistency_check(const float* dispL, const float* dispR, int H, int W, float dispThreshold, uint8_t* failL, uint8_t* failR);
+void les_post_process(les_plane* labelsL, les_plane* labelsR, const uint8_t* imL, const uint8_t* imR, int H, int W, int windR,
+                      float threshold, float omega);
+
 #ifdef __cplusplus
 }
 #endif

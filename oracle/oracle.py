@@ -107,6 +107,8 @@ def lib():
         "les_ransac_sample_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double]),
         "les_fill_out_of_view": (None, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "les_convert_volume_l2r": (None, [vp, vp, C.c_int, C.c_int, C.c_int]),
+        "les_consistency_check": (None, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
+        "les_post_process": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -254,3 +256,25 @@ class Oracle:
         self.L.les_oracle_unary_batch(self.h, mode, len(frs), _ptr(frs), _ptr(trs), _ptr(planes), _ptr(cost_map),
                                       int(check), nthreads)
         return cost_map
+
+
+def consistency_check(dispL, dispR, threshold=1.5):
+    """PMStereoBase::doConsistencyCheck (LES/PMStereoBase.h:111-144)."""
+    L = lib()
+    dl, dr = np.ascontiguousarray(dispL, np.float32), np.ascontiguousarray(dispR, np.float32)
+    H, W = dl.shape
+    fl, fr = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
+    L.les_consistency_check(_ptr(dl), _ptr(dr), H, W, threshold, _ptr(fl), _ptr(fr))
+    return fl, fr
+
+
+def post_process(labelsL, labelsR, imL, imR, windR=20, threshold=1.5, omega=10.0):
+    """PMStereoBase::postProcess (LES/PMStereoBase.h:146-256) on two H x W x 4 float label maps; returns new maps."""
+    L = lib()
+    a = np.ascontiguousarray(labelsL, np.float32).copy()
+    b = np.ascontiguousarray(labelsR, np.float32).copy()
+    il, ir = np.ascontiguousarray(imL, np.uint8), np.ascontiguousarray(imR, np.uint8)
+    H, W = il.shape[:2]
+    assert a.shape == (H, W, 4) and b.shape == (H, W, 4)
+    L.les_post_process(_ptr(a), _ptr(b), _ptr(il), _ptr(ir), H, W, windR, threshold, omega)
+    return a, b

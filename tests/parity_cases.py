@@ -629,3 +629,55 @@ def case_quality_cones_naive(lib, device, iters=2):
     assert all(b[1] <= a[1] + 1e-3 for a, b in zip(hist, hist[1:])), hist
     assert hist[-1][0] < 20.0, hist
     return hist
+
+
+def case_post_process(pr, seed=31, windR=None):
+    """Dual-view post-processing (LES/PMStereoBase.h:111-256): consistency masks and the post-processed label maps must
+    be bit-identical to the oracle.  Label maps: piecewise-planar scene seen from both views (so that most pixels are
+    consistent), plus blocks of wrong labels, an occlusion band and image-border cases."""
+    H, W = pr.H, pr.W
+    windR = pr.e.params.windR if windR is None else windR
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+
+    def scene(sign):
+        lab = np.zeros((H, W, 4), np.float32)
+        # three surfaces with disparities ~ 4, 9, 14; the right view sees them shifted by their disparity
+        for k, (a, b, c) in enumerate([(0.01, 0.0, 4.0), (0.0, 0.02, 8.0), (-0.01, 0.01, 14.0)]):
+            m = (xs + (0 if sign > 0 else c)) // (W / 3.0) == k if k < 2 else (xs + (0 if sign > 0 else c)) // (W / 3.0) >= 2
+            # plane in this view's coordinates: d(x) for the right view is the left plane evaluated at x + d ~ x + c
+            cc = c + (a * c if sign < 0 else 0.0)
+            lab[m] = (a, b, cc, 0.0)
+        return lab
+
+    LL, LR = scene(+1.0), scene(-1.0)
+    for lab in (LL, LR):
+        for _ in range(6):                                     # blocks of outliers
+            x0, y0 = int(rng.integers(0, W - 8)), int(rng.integers(0, H - 8))
+            w, h = int(rng.integers(2, 14)), int(rng.integers(2, 10))
+            lab[y0:y0 + h, x0:x0 + w] = (rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0, pr.D), 0.0)
+        noisy = rng.random((H, W)) < 0.02                      # isolated outliers
+        lab[noisy, 2] += rng.uniform(3, 9, int(noisy.sum())).astype(np.float32)
+    LL[:, :3] = (0.0, 0.0, 1e12, 0.0)                          # huge disparity: maps far outside
+    LL[5, 7] = (np.nan, 0.0, 1.0, 0.0)
+    dl = LL[..., 0] * xs + LL[..., 1] * ys + LL[..., 2]
+    dr = LR[..., 0] * xs + LR[..., 1] * ys + LR[..., 2]
+    fl, fr = om.consistency_check(dl, dr, 1.5)
+    bufs = [api.DeviceBuffer(pr.e, H * W * 16) for _ in range(2)] + [api.DeviceBuffer(pr.e, H * W) for _ in range(2)]
+    bufs[0].upload(LL); bufs[1].upload(LR)
+    pr.e.consistency_check(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, 1.5)
+    gl, gr = bufs[2].download((H, W), np.uint8), bufs[3].download((H, W), np.uint8)
+    assert np.array_equal(gl, fl) and np.array_equal(gr, fr)
+    assert 0.02 < (fl > 0).mean() < 0.6 and (fl == 128).any() and (fl == 255).any()
+    imL, imR = pr.e.imL, pr.e.imR
+    for thr in (1.5, 1.0):
+        ref = om.post_process(LL, LR, imL, imR, windR=windR, threshold=thr, omega=10.0)
+        got = pr.e.post_process_host(LL, LR, threshold=thr, omega=10.0)
+        for g, r, name in zip(got, ref, "LR"):
+            same = (g.view(np.uint32) == r.view(np.uint32)).all(axis=2)
+            assert same.all(), f"post-processed labels differ in view {name}: {int((~same).sum())} pixels (threshold {thr})"
+        changed = (ref[0].view(np.uint32) != LL.view(np.uint32)).any(axis=2).mean()
+        assert changed > 0.01
+    for b in bufs:
+        b.free()
+    return float(changed)

@@ -183,6 +183,12 @@ def test_gpu_volume_preparation(cones):
     pc.case_volume_preparation(cones, None)
 
 
+def test_gpu_post_process(cones, mid):
+    """Dual-view post-processing (LES/PMStereoBase.h:111-256): masks and labels bit-identical to the oracle."""
+    assert pc.case_post_process(cones) > 0.01
+    assert pc.case_post_process(mid, seed=77) > 0.005
+
+
 def test_gpu_naive_energy(oracle_mod):
     """Image-based matching cost of config 1 (NaiveStereoEnergy, LES/StereoEnergy.h:629-764) vs the oracle."""
     worst = pc.case_naive(None)

@@ -135,6 +135,11 @@ def test_sim_volume_preparation(cones, sim_lib):
     pc.case_volume_preparation(cones, sim_lib)
 
 
+def test_sim_post_process(cones):
+    """Dual-view post-processing (LR check, fill, weighted median): bit-identical labels."""
+    assert pc.case_post_process(cones) > 0.01
+
+
 def test_sim_naive_energy(sim_lib, oracle_mod):
     """Image-based matching cost of config 1 (NaiveStereoEnergy) through the same kernels."""
     worst = pc.case_naive(sim_lib)

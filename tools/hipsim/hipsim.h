@@ -59,6 +59,7 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 
 using std::max;
 using std::min;
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
