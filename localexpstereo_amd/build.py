@@ -59,6 +59,20 @@ def build_host(force=False):
     return exe
 
 
+HOST_SO = os.path.join(HOST, "liblocalexp_host.so")
+
+
+def build_host_lib(force=False):
+    """g++ -> localexpstereo_amd/host/liblocalexp_host.so: C ABI of the host graph-cut fusion (include/localexp_host.h)."""
+    src = os.path.join(HOST, "les_gc.cpp")
+    deps = [src, os.path.join(ROOT, "include", "localexp_host.h")] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    if not force and _newer(HOST_SO, deps):
+        return HOST_SO
+    cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_SO]
+    subprocess.check_call(cmd, cwd=HOST)
+    return HOST_SO
+
+
 def build_host_selfcheck(force=False):
     """tests/cpp/gc_selfcheck: graph-cut host logic on a CPU-only test energy (test infrastructure)."""
     src = os.path.join(ROOT, "tests", "cpp", "gc_selfcheck.cpp")

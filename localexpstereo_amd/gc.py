@@ -1,0 +1,91 @@
+"""ctypes binding of the host graph-cut fusion library (include/localexp_host.h, localexpstereo_amd/host/les_gc.cpp).
+
+Replaces for Python drivers: FastGCStereo::expansionMoveBK + the BK max-flow library + the pairwise terms of
+StereoEnergy (LES/FastGCStereo.h:411-597, LES/StereoEnergy.h:131-230,398-453).  Host code only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import api
+
+DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "liblocalexp_host.so")
+SYMBOLS = ["les_gc_create", "les_gc_destroy", "les_gc_last_error", "les_gc_labels", "les_gc_costs", "les_gc_expansion_moves",
+           "les_gc_smoothness_cost", "les_gc_data_cost"]
+_lib = None
+
+
+def load(path=None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not built (python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(path)
+    vp, ci = C.c_void_p, C.c_int
+    sig = {
+        "les_gc_create": (ci, [C.POINTER(vp), ci, ci, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+        "les_gc_destroy": (None, [vp]),
+        "les_gc_last_error": (C.c_char_p, []),
+        "les_gc_labels": (C.POINTER(C.c_float), [vp, ci]),
+        "les_gc_costs": (C.POINTER(C.c_float), [vp, ci]),
+        "les_gc_expansion_moves": (ci, [vp, ci, ci, vp, vp, vp, ci, ci, C.POINTER(C.c_double)]),
+        "les_gc_smoothness_cost": (C.c_double, [vp, ci]),
+        "les_gc_data_cost": (C.c_double, [vp, ci]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+class GraphCut:
+    """Current solution (labels + unary costs per view) and the local expansion moves on it."""
+
+    def __init__(self, imL, imR, lambda_=20.0, th_smooth=1.0, omega=10.0, epsilon=0.01, lib=None):
+        self.L = load(lib)
+        self.imL = np.ascontiguousarray(imL, np.uint8) if imL is not None else None
+        self.imR = np.ascontiguousarray(imR, np.uint8) if imR is not None else None
+        im = self.imL if self.imL is not None else self.imR
+        self.H, self.W = im.shape[:2]
+        h = C.c_void_p()
+        if self.L.les_gc_create(C.byref(h), self.H, self.W, api._ptr(self.imL), api._ptr(self.imR), lambda_, th_smooth, omega, epsilon):
+            raise RuntimeError(self.L.les_gc_last_error().decode())
+        self.h = h
+        # zero-copy numpy views of the context's own maps
+        self.labels = [np.ctypeslib.as_array(self.L.les_gc_labels(h, m), (self.H, self.W, 4)) for m in (0, 1)]
+        self.costs = [np.ctypeslib.as_array(self.L.les_gc_costs(h, m), (self.H, self.W)) for m in (0, 1)]
+
+    def expansion_moves(self, regions, planes, proposal_cost, mode=0, nthreads=0, check=False):
+        """One lock-step of a disjoint set: fuse planes[i] over regions[i] (LES/FastGCStereo.h:30-63, doGC == true).
+        Returns the largest flow-vs-energy gap when check is set (LES/FastGCStereo.h:561-594), else 0."""
+        regions, planes = api._rects(regions), api._planes(planes)
+        pc = np.ascontiguousarray(proposal_cost, np.float32)
+        assert pc.shape == (self.H, self.W) and len(regions) == len(planes)
+        gap = C.c_double(0)
+        if self.L.les_gc_expansion_moves(self.h, mode, len(regions), api._ptr(regions), api._ptr(planes), api._ptr(pc), nthreads, int(check), C.byref(gap)):
+            raise RuntimeError(self.L.les_gc_last_error().decode())
+        return gap.value
+
+    def smoothness_cost(self, mode=0):
+        return self.L.les_gc_smoothness_cost(self.h, mode)
+
+    def data_cost(self, mode=0):
+        return self.L.les_gc_data_cost(self.h, mode)
+
+    def energy(self, mode=0):
+        return self.data_cost(mode) + self.smoothness_cost(mode)
+
+    def close(self):
+        if self.h:
+            self.labels = self.costs = None
+            self.L.les_gc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

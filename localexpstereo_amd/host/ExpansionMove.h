@@ -15,8 +15,16 @@ namespace les_host {
 
 // updateMask: region.height x region.width (255 = take the proposal).  proposalCost / currentCost: H x W maps.
 // Returns the flow (= the energy of the fused labelling restricted to the terms that touch the region).
-inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeling, const CostMap& currentCost,
-                            const CostMap& proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
+// cost maps as raw row-major H x W arrays (row stride = image width)
+struct CostView {
+    const float* p; int stride;
+    CostView(const float* p_, int stride_) : p(p_), stride(stride_) {}
+    CostView(const CostMap& m) : p(m.data.data()), stride(m.cols) {}
+    float at(int y, int x) const { return p[(size_t)y * stride + x]; }
+};
+
+inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeling, CostView currentCost,
+                            CostView proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
                             int mode = 0)
 {
     std::array<std::vector<float>, 8> cost00, cost01, cost10;
@@ -64,7 +72,7 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
 
 // The reference's (disabled) self-check of the graph construction, LES/FastGCStereo.h:561-594: the flow equals the
 // unary cost of the fused labelling over the region plus every forward pairwise term with an endpoint in the region.
-inline double fusedEnergy(const StereoEnergy& E, const LabelMap& currentLabeling, const CostMap& currentCost, const CostMap& proposalCost,
+inline double fusedEnergy(const StereoEnergy& E, const LabelMap& currentLabeling, CostView currentCost, CostView proposalCost,
                           const Plane& label1, const Rect& region, const std::vector<uint8_t>& updateMask, int mode = 0)
 {
     const int W = E.getWidth(), H = E.getHeight();

@@ -86,7 +86,7 @@ public:
 
     // fuse `label` into the current solution over `sharedRegion` given its unary costs in proposalCost
     // (LES/FastGCStereo.h:52-63)
-    void fuseProposal(const Plane& label, const Rect& sharedRegion, const CostMap& proposalCost, int mode, bool doGC)
+    void fuseProposal(const Plane& label, const Rect& sharedRegion, CostView proposalCost, int mode, bool doGC)
     {
         CostMap& currentCost = currentCost_[mode];
         LabelMap& currentLabeling = currentLabeling_[mode];

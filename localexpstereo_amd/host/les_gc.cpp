@@ -1,0 +1,117 @@
+// les_gc.cpp -- C ABI (include/localexp_host.h) over the host graph-cut fusion (ExpansionMove.h / MaxFlow.h).
+#include "../../include/localexp_host.h"
+
+#include <omp.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <string>
+
+#include "ExpansionMove.h"
+
+using namespace les_host;
+
+namespace {
+thread_local std::string g_err;
+int fail(const char* fmt, ...)
+{
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+// the pairwise half of StereoEnergy; the unary operator lives on the GPU and is never called through this object
+class PairwiseEnergy : public StereoEnergy {
+public:
+    PairwiseEnergy(int W, int H, Parameters p) : StereoEnergy(W, H, std::move(p), 0.f, 0.f) {}
+    void ComputeUnaryPotentialWithoutCheck(const Rect&, const Rect&, float*, int, const Plane&, Reusable&, int) const override {}
+    void ComputeUnaryPotential(const Rect&, const Rect&, float*, int, const Plane&, Reusable&, int) const override {}
+};
+}  // namespace
+
+struct les_gc_ctx {
+    int H, W;
+    std::unique_ptr<PairwiseEnergy> E;
+    LabelMap labels[2];
+    CostMap costs[2];
+};
+
+extern "C" {
+
+const char* les_gc_last_error(void) { return g_err.c_str(); }
+
+int les_gc_create(les_gc_ctx** out, int H, int W, const uint8_t* imL, const uint8_t* imR, float lambda, float th_smooth, float omega, float epsilon)
+{
+    if (!out || H <= 0 || W <= 0 || (!imL && !imR)) return fail("les_gc_create: bad argument");
+    Parameters p;
+    p.lambda = lambda; p.th_smooth = th_smooth; p.omega = omega; p.epsilon = epsilon;
+    les_gc_ctx* c = new les_gc_ctx();
+    c->H = H; c->W = W;
+    c->E = std::make_unique<PairwiseEnergy>(W, H, p);
+    c->E->setImages(imL, imR);
+    for (int m = 0; m < 2; m++) {
+        c->labels[m] = LabelMap(H, W);
+        c->costs[m] = CostMap(H, W, 0.f);
+    }
+    *out = c;
+    return 0;
+}
+
+void les_gc_destroy(les_gc_ctx* c) { delete c; }
+
+float* les_gc_labels(les_gc_ctx* c, int mode) { return (c && mode >= 0 && mode < 2) ? reinterpret_cast<float*>(c->labels[mode].data.data()) : nullptr; }
+float* les_gc_costs(les_gc_ctx* c, int mode) { return (c && mode >= 0 && mode < 2) ? c->costs[mode].data.data() : nullptr; }
+
+int les_gc_expansion_moves(les_gc_ctx* c, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes, const float* proposal_cost,
+                           int nthreads, int check, double* max_gap)
+{
+    if (!c || mode < 0 || mode > 1 || n < 0 || (n > 0 && (!regions || !planes || !proposal_cost))) return fail("les_gc_expansion_moves: bad argument");
+    if (!c->E->hasImages(mode)) return fail("les_gc_expansion_moves: view %d has no image", mode);
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect& r = regions[i];
+        if (r.w < 0 || r.h < 0 || r.x < 0 || r.y < 0 || r.x + r.w > c->W || r.y + r.h > c->H) return fail("les_gc_expansion_moves: region %d outside the image", i);
+    }
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    nthreads = std::max(1, std::min(nthreads, n));
+    LabelMap& lab = c->labels[mode];
+    CostMap& cur = c->costs[mode];
+    const CostView prop(proposal_cost, c->W);
+    double gap = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(max : gap)
+    for (int i = 0; i < n; i++) {
+        const Rect region(regions[i].x, regions[i].y, regions[i].w, regions[i].h);
+        if (region.width == 0 || region.height == 0) continue;
+        const Plane label(planes[i].a, planes[i].b, planes[i].c, planes[i].v);
+        std::vector<uint8_t> mask;
+        const double flow = expansionMove(*c->E, lab, cur, prop, label, region, mask, mode);
+        if (check) {
+            const double e = fusedEnergy(*c->E, lab, cur, prop, label, region, mask, mode);
+            gap = std::max(gap, std::fabs(flow - e) / std::max(1.0, std::fabs(e)));
+        }
+        for (int y = 0; y < region.height; y++)                               // LES/FastGCStereo.h:61-62
+            for (int x = 0; x < region.width; x++)
+                if (mask[(size_t)y * region.width + x]) {
+                    cur.at(region.y + y, region.x + x) = prop.at(region.y + y, region.x + x);
+                    lab.at(region.y + y, region.x + x) = label;
+                }
+    }
+    if (max_gap) *max_gap = gap;
+    return 0;
+}
+
+double les_gc_smoothness_cost(les_gc_ctx* c, int mode) { return (c && mode >= 0 && mode < 2 && c->E->hasImages(mode)) ? c->E->computeSmoothnessCost(c->labels[mode], mode) : 0.0; }
+
+double les_gc_data_cost(les_gc_ctx* c, int mode)
+{
+    double s = 0;
+    if (c && mode >= 0 && mode < 2)
+        for (float v : c->costs[mode].data) s += v;
+    return s;
+}
+
+}  // extern "C"

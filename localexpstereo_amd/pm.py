@@ -74,6 +74,7 @@ class _Shard:
         self.own = cells[bounds[rank]:bounds[rank + 1]]
         tgt = units if target_is_unit else shared
         self.n = len(self.own)
+        self.regions = np.ascontiguousarray(tgt[self.own])
         self.batch = api.Batch(e, filt[self.own], tgt[self.own])
         self.batch.set_units(units[self.own])
         self.rng = torch.from_numpy(seeds[self.own].view(np.int64).copy()).to(dev)
@@ -154,10 +155,65 @@ class PMRunner:
                 self._sync()
                 self._exchange(sh)
 
-    def run(self, pm_iterations):
+    # -- graph-cut iterations (LES/FastGCStereo.h:171-185: the main loop, doGC == true) ----------------------------
+    # Proposals and unary costs come from the GPU exactly as in iteration(); the winner-take-all update is replaced by
+    # the local expansion moves of the rank's own cells on the host cores (gc.GraphCut), and the fused labels go
+    # back to the device for the next proposals.  Cross-rank coherence is the same per-set all-gather.
+    def begin_gc(self, graph_cut, mode=None):
+        self.gc = graph_cut
+        m = self.mode if mode is None else mode
+        self._sync()
+        self.gc.labels[m][...] = self.labels.cpu().numpy()
+        self.gc.costs[m][...] = self.cur.cpu().numpy()
+        self._prop_host = torch.empty((self.H, self.W), dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.empty((self.H, self.W))
+        self.gc_max_gap = 0.0
+        self.gc_seconds = {"device": 0.0, "host_cuts": 0.0, "h2d": 0.0}
+
+    def gc_iteration(self, iteration, check=False, nthreads=0):
+        import time
+        gc, m = self.gc, self.mode
+        lab_host = torch.from_numpy(gc.labels[m])
+        cur_host = torch.from_numpy(gc.costs[m])
+        for li, layer in enumerate(self.shards):
+            for sh in layer:
+                if sh.n:
+                    for kind, K in self.table[li]:
+                        for it in range(K):
+                            mm = iteration + it
+                            if kind == api.PROPOSE_RANDOM and (self.maxd - self.mind) * 0.5 ** (mm + 1) < 0.1:
+                                break
+                            t0 = time.perf_counter()
+                            sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=mm)
+                            sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=m, check=True, planes_on_device=True)
+                            self._sync()
+                            self._prop_host.copy_(self.prop)
+                            planes = sh.planes[: sh.n].cpu().numpy()
+                            t1 = time.perf_counter()
+                            gap = gc.expansion_moves(sh.regions, planes, self._prop_host.numpy(), mode=m, nthreads=nthreads, check=check)
+                            self.gc_max_gap = max(self.gc_max_gap, gap)
+                            t2 = time.perf_counter()
+                            self.labels.copy_(lab_host)
+                            t3 = time.perf_counter()
+                            self.gc_seconds["device"] += t1 - t0
+                            self.gc_seconds["host_cuts"] += t2 - t1
+                            self.gc_seconds["h2d"] += t3 - t2
+                if self.world > 1:
+                    self.cur.copy_(cur_host)
+                    self._exchange(sh)
+                    lab_host.copy_(self.labels)
+                    cur_host.copy_(self.cur)
+        self.cur.copy_(cur_host)
+
+    def run(self, pm_iterations, iterations=0, graph_cut=None):
+        """FastGCStereo::run for one view (LES/FastGCStereo.h:133-199): init, pmInit winner-take-all iterations, then
+        `iterations` graph-cut iterations (their counter restarts at 0)."""
         self.init_labels()
         for it in range(pm_iterations):
             self.iteration(it)
+        if iterations > 0:
+            self.begin_gc(graph_cut)
+            for it in range(iterations):
+                self.gc_iteration(it)
         return self.labels, self.cur
 
     def disparities(self):

@@ -278,3 +278,20 @@ def post_process(labelsL, labelsR, imL, imR, windR=20, threshold=1.5, omega=10.0
     assert a.shape == (H, W, 4) and b.shape == (H, W, 4)
     L.les_post_process(_ptr(a), _ptr(b), _ptr(il), _ptr(ir), H, W, windR, threshold, omega)
     return a, b
+
+
+def fill_out_of_view(vol, mode):
+    """fillOutOfView (LES/main.cpp:146-176), in place on a contiguous float32 [D][H][W] array."""
+    assert vol.dtype == np.float32 and vol.flags.c_contiguous and vol.flags.writeable
+    D, H, W = vol.shape
+    lib().les_fill_out_of_view(_ptr(vol), D, H, W, mode)
+    return vol
+
+
+def convert_volume_l2r(vol):
+    """convertVolumeL2R (LES/main.cpp:178-199)."""
+    src = np.ascontiguousarray(vol, np.float32)
+    dst = np.empty_like(src)
+    D, H, W = src.shape
+    lib().les_convert_volume_l2r(_ptr(src), _ptr(dst), D, H, W)
+    return dst

@@ -681,3 +681,64 @@ def case_post_process(pr, seed=31, windR=None):
     for b in bufs:
         b.free()
     return float(changed)
+
+
+def case_ingest_files(lib, device, tmp_path, D=12, H=20, W=37):
+    """MiddV3 volume ingest (LES/main.cpp:353-368) from raw .acrt files: with and without im1.acrt."""
+    from localexpstereo_amd import io as lio
+    rng = np.random.default_rng(5)
+    vl = rng.uniform(0, 1, (D, H, W)).astype(np.float32)
+    vr = rng.uniform(0, 1, (D, H, W)).astype(np.float32)
+    lio.save_cost_volume(str(tmp_path / "im0.acrt"), vl)
+    for have_right in (True, False):
+        if have_right:
+            lio.save_cost_volume(str(tmp_path / "im1.acrt"), vr)
+        elif os.path.exists(tmp_path / "im1.acrt"):
+            os.remove(tmp_path / "im1.acrt")
+        a = lio.load_cost_volume(str(tmp_path / "im0.acrt"), D, H, W)
+        b = lio.load_cost_volume(str(tmp_path / "im1.acrt"), D, H, W)
+        assert (b is not None) == have_right
+        tl, tr = lio.ingest_volumes(a, b, device=device, lib=lib)
+        rl = vl.copy()
+        om.fill_out_of_view(rl, 0)
+        rr = vr.copy() if have_right else om.convert_volume_l2r(rl)
+        om.fill_out_of_view(rr, 1)
+        assert np.array_equal(tl.cpu().numpy(), rl) and np.array_equal(tr.cpu().numpy(), rr)
+
+
+def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25), lambda_=1.0):
+    """Local expansion moves proper on the cones crop: PatchMatch iteration(s), then graph-cut iterations whose
+    proposals / unary costs come from the library under test and whose cuts run in liblocalexp_host.so.
+    Checks: the reference's flow == energy self-check on every move (LES/FastGCStereo.h:561-594, <= 1e-5 relative),
+    the total energy (data + smoothness) never increases, the error rate stays converged."""
+    from localexpstereo_amd import gc as lgc
+    from localexpstereo_amd import pm
+    imL, vol, gt = cones_ad_volume()
+    e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0, lib=lib)
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)],
+             [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]][: len(units)]
+    r = pm.PMRunner(e, units, table, seed=11, device=device)
+    g = lgc.GraphCut(imL, None, lambda_=lambda_)
+    known = gt > 0
+
+    def bad(thr):
+        d = r.disparities().cpu().numpy()
+        return float((np.abs(d - gt)[known] > thr).mean() * 100)
+
+    r.init_labels()
+    for it in range(pm_iters):
+        r.iteration(it)
+    r.begin_gc(g)
+    hist = [(bad(1.0), g.data_cost(0), g.smoothness_cost(0))]
+    for it in range(gc_iters):
+        r.gc_iteration(it, check=True)
+        hist.append((bad(1.0), g.data_cost(0), g.smoothness_cost(0)))
+        assert np.array_equal(r.labels.cpu().numpy(), g.labels[0])            # device and host solutions stay identical
+    gap = r.gc_max_gap
+    r.close(); e.close(); g.close()
+    assert gap <= 1e-5, gap
+    en = [h[1] + h[2] for h in hist]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(en, en[1:])), hist
+    assert hist[-1][2] < hist[0][2], hist                                       # the smoothness term went down
+    assert hist[-1][0] < 20.0, hist
+    return hist, gap

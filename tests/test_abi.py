@@ -32,6 +32,24 @@ def test_header_symbols_are_exported(hip_so):
     assert sorted(api.SYMBOLS) == declared
 
 
+def test_host_library_symbols_are_exported():
+    """include/localexp_host.h (host graph-cut fusion) vs liblocalexp_host.so and its Python binding."""
+    from localexpstereo_amd import build, gc
+    lib = ctypes.CDLL(build.build_host_lib())
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "localexp_host.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(les_gc_[a-z0-9_]+)\s*\(", text)))
+    assert declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/localexp_host.h but not exported"
+    assert sorted(gc.SYMBOLS) == declared
+    g = gc.GraphCut(np.zeros((4, 5, 3), np.uint8), None)
+    with pytest.raises(RuntimeError, match="outside the image"):
+        g.expansion_moves([(0, 0, 9, 9)], [(0, 0, 1, 0)], np.zeros((4, 5), np.float32))
+    with pytest.raises(RuntimeError, match="no image"):
+        g.expansion_moves([(0, 0, 2, 2)], [(0, 0, 1, 0)], np.zeros((4, 5), np.float32), mode=1)
+    g.close()
+
+
 def test_library_contains_gfx950_code_object(hip_so):
     blob = open(hip_so, "rb").read()
     assert b"gfx950" in blob

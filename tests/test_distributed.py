@@ -20,12 +20,12 @@ def test_python_layer_geometry_matches_oracle(oracle_mod):
         assert len(sets) == len(L.sets) and all(np.array_equal(a, b) for a, b in zip(sets, L.sets))
 
 
-def _run(world, out, H=64, W=88, D=10, iters=1):
+def _run(world, out, H=64, W=88, D=10, iters=1, gc_iters=0):
     from localexpstereo_amd import build
     lib = build.build_sim()
     env = dict(os.environ, OMP_NUM_THREADS="2")
     worker = os.path.join(ROOT, "tests", "dist_worker.py")
-    args = [out, lib, str(H), str(W), str(D), str(iters)]
+    args = [out, lib, str(H), str(W), str(D), str(iters), str(gc_iters)]
     if world == 1:
         cmd = [sys.executable, worker] + args
     else:
@@ -43,3 +43,16 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_mod):
     assert one["cur"].tobytes() == two["cur"].tobytes()
     # the run did something: every pixel has a finite cost below the initial sentinel for most of the image
     assert np.isfinite(one["cur"]).all() and (one["cur"] < 1e5).mean() > 0.9
+
+
+def test_two_ranks_equal_one_rank_graph_cut(tmp_path, oracle_mod):
+    """Graph-cut iterations sharded over ranks: every rank cuts its own cells on the host, the per-set
+    all-gather keeps the replicas coherent -> same labels as one rank."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    one = _run(1, str(tmp_path / "one.npz"), H=48, W=64, iters=1, gc_iters=1)
+    two = _run(2, str(tmp_path / "two.npz"), H=48, W=64, iters=1, gc_iters=1)
+    assert one["labels"].tobytes() == two["labels"].tobytes()
+    assert one["cur"].tobytes() == two["cur"].tobytes()
+    assert one["host_labels"].tobytes() == one["labels"].tobytes()
+    assert float(one["energy"]) == float(two["energy"]) and float(one["energy"]) > 0

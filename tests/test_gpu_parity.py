@@ -183,6 +183,16 @@ def test_gpu_volume_preparation(cones):
     pc.case_volume_preparation(cones, None)
 
 
+def test_gpu_graph_cut_iterations(oracle_mod):
+    """Local expansion moves end to end: GPU proposals + unary costs, host graph cuts (liblocalexp_host.so)."""
+    hist, gap = pc.case_quality_cones_gc(None, "cuda", pm_iters=1, gc_iters=2)
+    print("cones crop PM+GC (bad1.0, data, smooth):", hist, "max flow-energy gap", gap)
+
+
+def test_gpu_ingest_files(oracle_mod, tmp_path):
+    pc.case_ingest_files(None, "cuda", tmp_path, D=40, H=64, W=333)
+
+
 def test_gpu_post_process(cones, mid):
     """Dual-view post-processing (LES/PMStereoBase.h:111-256): masks and labels bit-identical to the oracle."""
     assert pc.case_post_process(cones) > 0.01

@@ -135,6 +135,18 @@ def test_sim_volume_preparation(cones, sim_lib):
     pc.case_volume_preparation(cones, sim_lib)
 
 
+def test_sim_graph_cut_iterations(sim_lib, oracle_mod):
+    """PatchMatch + graph-cut iterations through the Python driver: simulator proposals / unary costs, host cuts."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    hist, gap = pc.case_quality_cones_gc(sim_lib, "cpu", units=(12,))
+    print("cones crop PM+GC (bad1.0, data, smooth):", hist, "max flow-energy gap", gap)
+
+
+def test_sim_ingest_files(sim_lib, oracle_mod, tmp_path):
+    pc.case_ingest_files(sim_lib, "cpu", tmp_path)
+
+
 def test_sim_post_process(cones):
     """Dual-view post-processing (LR check, fill, weighted median): bit-identical labels."""
     assert pc.case_post_process(cones) > 0.01
