@@ -1,0 +1,136 @@
+"""Python driver of the whole local expansion loop around the GPU path (mirror of FastGCStereo / PMStereoBase,
+LES/FastGCStereo.h:88-227, LES/PMStereoBase.h) and of the two data-set front ends MidV2 / MidV3 (LES/main.cpp:270-420).
+
+What runs where: proposals, unary costs, winner-take-all updates, post-processing -> MI355X through the C ABI
+(liblocalexp_hip.so); graph cuts of the main iterations -> host cores (liblocalexp_host.so); file formats and the
+Evaluator -> numpy (io.py).  One process per GPU: pass rank/world to shard the cells of every disjoint set.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import api, gc, io, pm
+
+PARAMS_GF = dict(lambda_=1.0, windR=20, eps=1e-4, alpha=0.9, omega=10.0, th_grad=2.0, th_col=10.0, th_smooth=1.0, epsilon=0.01)   # paramsGF, LES/main.cpp:73
+
+
+class FastGCStereo:
+    def __init__(self, energy, imL, imR, params, device="cuda", rank=0, world=1, seed=1):
+        self.e, self.imL, self.imR, self.p = energy, imL, imR, dict(PARAMS_GF, **params)
+        self.device, self.rank, self.world, self.seed = device, rank, world, seed
+        self.units, self.table = [], []
+        self.evaluator = None
+        self.log = []
+        self.check_flow_energy = False
+        self.host_threads = 0
+
+    def addLayer(self, unit_region_size, proposers):
+        """proposers: list of (kind, K) with kind in api.PROPOSE_EXPANSION / _RANDOM / _RANSAC (LES/FastGCStereo.h:88-92)."""
+        self.units.append(int(unit_region_size))
+        self.table.append(list(proposers))
+
+    def setEvaluator(self, evaluator, precision=-1.0):
+        self.evaluator, self.precision = evaluator, precision
+
+    def _evaluate(self, index, mode, runner, g, t0):
+        if mode != 0:
+            return
+        disp = runner.disparities().cpu().numpy()
+        if g is not None and getattr(runner, "gc", None) is g:
+            dc, sc = g.data_cost(mode), g.smoothness_cost(mode)
+        else:
+            dc, sc = float(runner.cur.sum(dtype=torch.float64)), float("nan")
+        row = dict(index=index, time=time.perf_counter() - t0, energy=dc + (0.0 if sc != sc else sc), data=dc, smooth=sc)
+        if self.evaluator is not None:
+            d = disp
+            if self.precision > 0:                                         # Evaluator::quantize, LES/Evaluator.h:106-111
+                d = (np.rint(disp / np.float32(self.precision)) * np.float32(self.precision)).astype(np.float32)
+            row["all"], row["nonocc"] = self.evaluator.evaluate(d)
+        self.log.append(row)
+
+    def run(self, maxIteration, viewModes=(0,), pmInit=0):
+        """FastGCStereo::run (LES/FastGCStereo.h:133-227).  Returns (labeling, rawlabeling) of the left view as
+        H x W x 4 float arrays (the raw one is the labelling before the two-view post-processing)."""
+        t0 = time.perf_counter()
+        runners = {m: pm.PMRunner(self.e, self.units, self.table, seed=self.seed + 7919 * m, rank=self.rank, world=self.world,
+                                  device=self.device, mode=m) for m in viewModes}
+        g = gc.GraphCut(self.imL, self.imR, lambda_=self.p["lambda_"], th_smooth=self.p["th_smooth"], omega=self.p["omega"],
+                        epsilon=self.p["epsilon"]) if maxIteration > 0 else None
+        for m in viewModes:
+            runners[m].init_labels()
+            self._evaluate(0, m, runners[m], None, t0)
+        for it in range(pmInit):
+            for m in viewModes:
+                runners[m].iteration(it)
+                self._evaluate(it + 1, m, runners[m], None, t0)
+        self.gc_max_gap, self.gc_seconds = 0.0, {}
+        if maxIteration > 0:
+            for m in viewModes:
+                runners[m].begin_gc(g, mode=m)
+            for it in range(maxIteration):
+                for m in viewModes:
+                    runners[m].gc_iteration(it, check=self.check_flow_energy, nthreads=self.host_threads)
+                    self._evaluate(it + 1 + pmInit, m, runners[m], g, t0)
+            for m in viewModes:
+                self.gc_max_gap = max(self.gc_max_gap, runners[m].gc_max_gap)
+                for k, v in runners[m].gc_seconds.items():
+                    self.gc_seconds[k] = self.gc_seconds.get(k, 0.0) + v
+        raw = runners[0].labels.cpu().numpy().copy() if 0 in runners else None
+        if len(viewModes) == 2:
+            self.e.post_process(runners[0].labels.data_ptr(), runners[1].labels.data_ptr(), 1.5, self.p["omega"])     # LES/FastGCStereo.h:202
+            self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
+        lab = runners[0].labels.cpu().numpy().copy() if 0 in runners else None
+        self.seconds = time.perf_counter() - t0
+        for r in runners.values():
+            r.close()
+        if g is not None:
+            g.close()
+        return lab, raw
+
+
+def disparities(labeling):
+    H, W = labeling.shape[:2]
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    return labeling[..., 0] * xs + labeling[..., 1] * ys + labeling[..., 2]
+
+
+def _layers(st, sizes):
+    e, r, p = api.PROPOSE_EXPANSION, api.PROPOSE_RANSAC, api.PROPOSE_RANDOM
+    st.addLayer(sizes[0], [(e, 1), (r, 1), (p, 7)])                    # LES/main.cpp:300-306 / :391-397
+    st.addLayer(sizes[1], [(e, 2), (r, 1)])
+    st.addLayer(sizes[2], [(e, 2), (r, 1)])
+
+
+def MidV2(data, iterations=5, pmIterations=2, doDual=False, smooth_weight=1.0, filterRadious=20, device="cuda", seed=1, lib=None, **kw):
+    """MidV2 (LES/main.cpp:270-328) on a data dict of io.load_data: image-based matching cost, layers 5/15/25, error
+    threshold 0.5, disparities quantised to the ground-truth precision before evaluation."""
+    maxdisp = float(data["ndisp"] - 1)
+    e = api.HipCostVolumeEnergy.naive(data["imL"], data["imR"], windR=filterRadious, eps=PARAMS_GF["eps"], alpha=PARAMS_GF["alpha"],
+                                      th_col=PARAMS_GF["th_col"], th_grad=PARAMS_GF["th_grad"], max_disp=maxdisp,
+                                      device=torch.device(device).index or 0, lib=lib)
+    st = FastGCStereo(e, data["imL"], data["imR"], dict(lambda_=smooth_weight, windR=filterRadious), device=device, seed=seed, **kw)
+    st.setEvaluator(io.Evaluator(data["dispGT"], data["nonocc"], 0.5), precision=data.get("gt_prec", -1.0))
+    _layers(st, (5, 15, 25))
+    lab, raw = st.run(iterations, (0, 1) if doDual else (0,), pmIterations)
+    e.close()
+    return st, lab, raw
+
+
+def MidV3(data, volL, volR, iterations=5, pmIterations=2, doDual=False, smooth_weight=0.5, mc_threshold=0.5, filterRadious=20,
+          error_threshold=1.0, device="cuda", seed=1, lib=None, **kw):
+    """MidV3 (LES/main.cpp:330-420): cost-volume energy (volumes ingested on the device), layers 1 % / 3 % / 9 % of the
+    image width.  volL / volR: host arrays / memmaps [ndisp][H][W] (volR None: synthesised from the left one)."""
+    maxdisp = float(data["ndisp"] - 1)
+    tl, tr = io.ingest_volumes(volL, volR, device=device, lib=lib)
+    D, H, W = tl.shape
+    e = api.HipCostVolumeEnergy(data["imL"], data["imR"], tl.data_ptr(), tr.data_ptr(), windR=filterRadious, eps=PARAMS_GF["eps"],
+                                th_col=mc_threshold, max_disp=maxdisp, device=torch.device(device).index or 0, volumes_on_device=True,
+                                shape=(D, H, W), lib=lib)
+    st = FastGCStereo(e, data["imL"], data["imR"], dict(lambda_=smooth_weight, windR=filterRadious, th_col=mc_threshold), device=device, seed=seed, **kw)
+    st.setEvaluator(io.Evaluator(data["dispGT"], data["nonocc"], error_threshold), precision=-1.0)
+    _layers(st, (int(W * 0.01), int(W * 0.03), int(W * 0.09)))
+    lab, raw = st.run(iterations, (0, 1) if doDual else (0,), pmIterations)
+    e.close()
+    del tl, tr
+    return st, lab, raw

@@ -742,3 +742,33 @@ def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25)
     assert hist[-1][2] < hist[0][2], hist                                       # the smoothness term went down
     assert hist[-1][0] < 20.0, hist
     return hist, gap
+
+
+def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
+    """The Python FastGCStereo mirror end to end on the (padded) cones crop with config 1's energy, two views:
+    PatchMatch iteration(s), graph-cut iteration(s), left-right post-processing, Evaluator rows."""
+    from localexpstereo_amd import io as lio
+    from localexpstereo_amd import stereo
+    z = np.load(os.path.join(GOLDEN, "cones_crop.npz"))
+    imL, imRw, gt = z["imL"], np.ascontiguousarray(z["imR_wide"]), z["gt"]
+    imLw = np.concatenate([np.repeat(imL[:, :1], 64, axis=1), imL], axis=1)
+    gtw = np.concatenate([np.zeros((gt.shape[0], 64), np.float32), gt], axis=1)
+    e = api.HipCostVolumeEnergy.naive(imLw, imRw, max_disp=63.0, lib=lib)
+    st = stereo.FastGCStereo(e, imLw, imRw, dict(lambda_=1.0), device=device, seed=3)
+    st.setEvaluator(lio.Evaluator(gtw, gtw > 0, 1.0), precision=0.25)
+    st.check_flow_energy = True
+    ex, ra, rn = api.PROPOSE_EXPANSION, api.PROPOSE_RANSAC, api.PROPOSE_RANDOM
+    tabs = [[(ex, 1), (ra, 1), (rn, 7)], [(ex, 2), (ra, 1)], [(ex, 2), (ra, 1)]]
+    for u, t in zip(units, tabs):
+        st.addLayer(u, t)
+    lab, raw = st.run(maxIteration, (0, 1), pmInit)
+    e.close()
+    rows = st.log
+    assert [r["index"] for r in rows] == list(range(0, pmInit + maxIteration + 2))
+    assert rows[0]["all"] > 80 and rows[-1]["all"] < 25, rows
+    assert st.gc_max_gap <= 1e-5
+    gc_rows = rows[pmInit + 1: pmInit + maxIteration + 1]
+    assert all(r["smooth"] == r["smooth"] and r["energy"] == r["data"] + r["smooth"] for r in gc_rows)
+    assert lab.shape == raw.shape == imLw.shape[:2] + (4,)
+    assert (lab != raw).any()                                   # post-processing replaced some labels
+    return rows

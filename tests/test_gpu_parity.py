@@ -189,6 +189,31 @@ def test_gpu_graph_cut_iterations(oracle_mod):
     print("cones crop PM+GC (bad1.0, data, smooth):", hist, "max flow-energy gap", gap)
 
 
+def test_gpu_stereo_driver_two_views(oracle_mod):
+    rows = pc.case_stereo_driver(None, "cuda", units=(5, 15, 25), pmInit=1, maxIteration=1)
+    print("FastGCStereo mirror, cones crop, two views:", rows)
+
+
+def test_gpu_config1_cones_end_to_end():
+    """BASELINE configs[0]: MiddV2 cones 450x375, ndisp 64, NaiveStereoEnergy, pmIterations 2, then graph-cut iterations
+    (2 here instead of the default 5 to bound the host time) -- the whole loop of LES/main.cpp:270-328 with the unary
+    costs on the MI355X.  Evaluator: bad-0.5 px, disparities quantised to 1/4 px (LES/main.cpp:280-292)."""
+    pytest.importorskip("PIL")
+    import os
+    from localexpstereo_amd import io as lio
+    from localexpstereo_amd import stereo
+    data = lio.load_data(os.path.join(os.path.dirname(__file__), "golden", "cones"), ndisp=64)
+    st, lab, raw = stereo.MidV2(data, iterations=2, pmIterations=2, doDual=False)
+    for r in st.log:
+        print("%2d %6.2f s  E=%.0f data=%.0f smooth=%.0f  all=%.2f nonocc=%.2f" % (r["index"], r["time"], r["energy"], r["data"], r["smooth"], r["all"], r["nonocc"]))
+    print("graph-cut phase seconds:", st.gc_seconds)
+    assert st.log[0]["all"] > 90
+    assert st.log[2]["nonocc"] < 12.0            # PatchMatch iterations alone
+    assert st.log[-1]["nonocc"] < 8.0 and st.log[-1]["all"] < 16.0
+    en = [r["energy"] for r in st.log[3:]]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(en, en[1:]))
+
+
 def test_gpu_ingest_files(oracle_mod, tmp_path):
     pc.case_ingest_files(None, "cuda", tmp_path, D=40, H=64, W=333)
 
