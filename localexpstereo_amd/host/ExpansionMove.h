@@ -1,5 +1,6 @@
 // ExpansionMove.h -- one local alpha-expansion (graph-cut fusion of the current labelling with one proposal) over a
-// shared region: FastGCStereo::expansionMoveBK, LES/FastGCStereo.h:411-597 ("next" row N2), on top of MaxFlow.h.
+// shared region: FastGCStereo::expansionMoveBK, LES/FastGCStereo.h:411-597 ("next" row N2), on top of GridMaxFlow.h
+// (the grid-specialised form of MaxFlow.h: same cut, ~5x faster on these graphs).
 //
 // Nodes = pixels of `region`.  t-links: source capacity = current unary cost, sink capacity = proposal unary cost
 // (:433), plus for region-border pixels the pairwise terms towards their fixed neighbours outside the region
@@ -8,7 +9,7 @@
 // A pixel takes the proposal iff it ends on the SOURCE side (:555-559).
 #pragma once
 
-#include "MaxFlow.h"
+#include "GridMaxFlow.h"
 #include "StereoEnergy.h"
 
 namespace les_host {
@@ -27,17 +28,13 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
                             CostView proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
                             int mode = 0)
 {
-    std::array<std::vector<float>, 8> cost00, cost01, cost10;
-    E.computeSmoothnessTermsExpansion(currentLabeling, label1, region, cost00, cost01, cost10, mode);
     const int w = region.width, h = region.height, N = w * h;
     const int W = E.getWidth(), H = E.getHeight();
-    MaxFlowGraph graph(N, 4 * N);
-    graph.add_node(N);
+    GridMaxFlow graph(w, h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            const int s = y * w + x;
             const Point ps{region.x + x, region.y + y};
-            graph.add_tweights(s, currentCost.at(ps.y, ps.x), proposalCost.at(ps.y, ps.x));
+            graph.add_tweights(x, y, currentCost.at(ps.y, ps.x), proposalCost.at(ps.y, ps.x));
             if (x == 0 || x == w - 1 || y == 0 || y == h - 1) {
                 for (int k = 0; k < 8; k++) {
                     const Point pt{ps.x + E.neighbors[k].x, ps.y + E.neighbors[k].y};
@@ -46,27 +43,28 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
                     // pt keeps its current label
                     const float c00 = E.computeSmoothnessTerm(currentLabeling.at(ps.y, ps.x), currentLabeling.at(pt.y, pt.x), ps, k, mode);
                     const float c10 = E.computeSmoothnessTerm(label1, currentLabeling.at(pt.y, pt.x), ps, k, mode);
-                    graph.add_tweights(s, c00, c10);
+                    graph.add_tweights(x, y, c00, c10);
                 }
             }
         }
-    auto link = [&](int k, int x0, int x1, int y1, int dx) {
+    auto link = [&](int k, int dir, int x0, int x1, int y1, int dx, int dy) {
         for (int y = 0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
-                const int i = y * w + x, j = (y + (k == StereoEnergy::NB_GE ? 0 : 1)) * w + x + dx;
-                const float B = cost10[k][i], C = cost01[k][i], D = cost00[k][i];
-                graph.add_edge(i, j, std::max(0.f, B + C - D), 0);     // B+C-D can be slightly negative numerically
-                graph.add_tweights(i, C, 0);
-                graph.add_tweights(j, D - C, 0);
+                float B, C, D;                                             // cost10, cost01, cost00 (LES/StereoEnergy.h:398-453)
+                E.smoothnessTermsExpansionAt(currentLabeling, label1, region.x + x, region.y + y, k, D, C, B, mode);
+                graph.add_edge(x, y, dir, std::max(0.f, B + C - D), 0);     // B+C-D can be slightly negative numerically
+                graph.add_tweights(x, y, C, 0);
+                graph.add_tweights(x + dx, y + dy, D - C, 0);
             }
     };
-    link(StereoEnergy::NB_GE, 0, w - 1, h, +1);          // ee <-> ge
-    link(StereoEnergy::NB_EG, 0, w, h - 1, 0);           // ee <-> eg
-    link(StereoEnergy::NB_LG, 1, w, h - 1, -1);          // ee <-> lg
-    link(StereoEnergy::NB_GG, 0, w - 1, h - 1, +1);      // ee <-> gg
+    link(StereoEnergy::NB_GE, GridMaxFlow::E, 0, w - 1, h, +1, 0);           // ee <-> ge
+    link(StereoEnergy::NB_EG, GridMaxFlow::S, 0, w, h - 1, 0, +1);           // ee <-> eg
+    link(StereoEnergy::NB_LG, GridMaxFlow::SW, 1, w, h - 1, -1, +1);         // ee <-> lg
+    link(StereoEnergy::NB_GG, GridMaxFlow::SE, 0, w - 1, h - 1, +1, +1);     // ee <-> gg
     const double flow = graph.maxflow();
     updateMask.resize((size_t)N);
-    for (int s = 0; s < N; s++) updateMask[s] = graph.what_segment(s) == MaxFlowGraph::SOURCE ? 255 : 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) updateMask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
     return flow;
 }
 

@@ -1,0 +1,271 @@
+// GridMaxFlow.h -- s/t minimum cut on an 8-connected w x h pixel grid, the only graph shape the expansion moves build
+// (LES/FastGCStereo.h:485-551: forward neighbours E, S, SW, SE of every pixel of the region).
+//
+// Same algorithm and segment rule as MaxFlow.h (Boykov-Kolmogorov search trees, FIFO orphan adoption, time-stamp /
+// distance heuristic; SINK iff the node can still reach the sink in the residual graph, SOURCE otherwise), but the
+// arcs are implicit: every node keeps its 8 residual capacities inline (one cache line per node together with its
+// tree state) and neighbours are index offsets on a grid padded by one ring of capacity-less nodes, so the inner
+// loops have no arc records, no `next` chains and no bounds checks.  The minimum cut -- hence every label decision --
+// is a property of the graph, not of the augmentation order (up to float rounding of the residual capacities); it is
+// tested for equality against MaxFlow.h on random instances.  Capacities float, flow double, like the reference's
+// Graph<float,float,double>.
+#pragma once
+
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace les_host {
+
+class GridMaxFlow {
+public:
+    enum termtype { SOURCE = 0, SINK = 1 };
+    // arc directions; sister(k) == k ^ 1
+    enum { E = 0, W = 1, S = 2, N = 3, SW = 4, NE = 5, SE = 6, NW = 7 };
+
+    GridMaxFlow(int w, int h) : w_(w), h_(h), pw_(w + 2), flow_(0), nodes_((size_t)(w + 2) * (h + 2))
+    {
+        const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
+        for (int k = 0; k < 8; k++) off_[k] = o[k];
+    }
+    int id(int x, int y) const { return (y + 1) * pw_ + (x + 1); }
+
+    void add_tweights(int x, int y, float cap_source, float cap_sink)
+    {
+        Node& n = nodes_[id(x, y)];
+        const float delta = n.tr;
+        if (delta > 0) cap_source += delta;
+        else cap_sink -= delta;
+        flow_ += (cap_source < cap_sink) ? cap_source : cap_sink;
+        n.tr = cap_source - cap_sink;
+    }
+    // arc (x, y) -> neighbour in direction k with capacity cap, reverse capacity rev_cap (capacities accumulate)
+    void add_edge(int x, int y, int k, float cap, float rev_cap)
+    {
+        const int i = id(x, y);
+        nodes_[i].rc[k] += cap;
+        nodes_[i + off_[k]].rc[k ^ 1] += rev_cap;
+    }
+
+    double maxflow()
+    {
+        init_trees();
+        int current = NONE_NODE;
+        for (;;) {
+            int i = current;
+            if (i != NONE_NODE) {
+                nodes_[i].next_active = NOT_QUEUED;
+                if (nodes_[i].parent == P_NONE) i = NONE_NODE;
+            }
+            if (i == NONE_NODE) {
+                i = next_active();
+                if (i == NONE_NODE) break;
+            }
+            Node& ni = nodes_[i];
+            int mid_s = NONE_NODE, mid_k = 0;                   // connecting arc: S-tree node mid_s, direction mid_k
+            if (!ni.is_sink) {
+                for (int k = 0; k < 8; k++) {
+                    if (!(ni.rc[k] > 0)) continue;
+                    const int j = i + off_[k];
+                    Node& nj = nodes_[j];
+                    if (nj.parent == P_NONE) {
+                        nj.is_sink = 0; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
+                        set_active(j);
+                    } else if (nj.is_sink) { mid_s = i; mid_k = k; break; }
+                    else if (nj.ts <= ni.ts && nj.dist > ni.dist) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
+                }
+            } else {
+                for (int k = 0; k < 8; k++) {
+                    const int j = i + off_[k];
+                    Node& nj = nodes_[j];
+                    if (!(nj.rc[k ^ 1] > 0)) continue;          // residual capacity j -> i
+                    if (nj.parent == P_NONE) {
+                        nj.is_sink = 1; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
+                        set_active(j);
+                    } else if (!nj.is_sink) { mid_s = j; mid_k = k ^ 1; break; }
+                    else if (nj.ts <= ni.ts && nj.dist > ni.dist) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
+                }
+            }
+            time_++;
+            if (mid_s != NONE_NODE) {
+                ni.next_active = i;                              // stays active (not queued): more paths may start here
+                current = i;
+                augment(mid_s, mid_k);
+                while (orphan_head_ < orphans_.size()) {
+                    const int o = orphans_[orphan_head_++];
+                    if (nodes_[o].is_sink) adopt<true>(o);
+                    else adopt<false>(o);
+                }
+                orphans_.clear();
+                orphan_head_ = 0;
+            } else current = NONE_NODE;
+        }
+        return flow_;
+    }
+
+    termtype what_segment(int x, int y) const
+    {
+        const Node& n = nodes_[id(x, y)];
+        return (n.parent != P_NONE && n.is_sink) ? SINK : SOURCE;
+    }
+
+private:
+    static constexpr int NONE_NODE = -1, NOT_QUEUED = -2;
+    static constexpr int8_t P_TERMINAL = 8, P_ORPHAN = 9, P_NONE = 10;
+
+    struct alignas(64) Node {
+        float rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // residual capacity towards the 8 neighbours
+        float tr = 0;                              // > 0: source -> node residual, < 0: node -> sink
+        int next_active = NOT_QUEUED;
+        int ts = 0, dist = 0;
+        int8_t parent = P_NONE;                    // direction towards the tree parent, or P_TERMINAL / P_ORPHAN / P_NONE (free)
+        uint8_t is_sink = 0;
+    };
+
+    const int w_, h_, pw_;
+    int off_[8];
+    double flow_;
+    std::vector<Node> nodes_;
+    std::vector<int> orphans_;
+    size_t orphan_head_ = 0;
+    int time_ = 0;
+    int queue_first_[2] = {NONE_NODE, NONE_NODE}, queue_last_[2] = {NONE_NODE, NONE_NODE};
+
+    void set_active(int i)
+    {
+        if (nodes_[i].next_active != NOT_QUEUED) return;
+        nodes_[i].next_active = i;
+        if (queue_last_[1] != NONE_NODE) nodes_[queue_last_[1]].next_active = i;
+        else queue_first_[1] = i;
+        queue_last_[1] = i;
+    }
+    int next_active()
+    {
+        for (;;) {
+            int i = queue_first_[0];
+            if (i == NONE_NODE) {
+                queue_first_[0] = i = queue_first_[1];
+                queue_last_[0] = queue_last_[1];
+                queue_first_[1] = queue_last_[1] = NONE_NODE;
+                if (i == NONE_NODE) return NONE_NODE;
+            }
+            if (nodes_[i].next_active == i) queue_first_[0] = queue_last_[0] = NONE_NODE;
+            else queue_first_[0] = nodes_[i].next_active;
+            nodes_[i].next_active = NOT_QUEUED;
+            if (nodes_[i].parent != P_NONE) return i;
+        }
+    }
+    void init_trees()
+    {
+        for (int y = 0; y < h_; y++)
+            for (int x = 0; x < w_; x++) {
+                const int i = id(x, y);
+                Node& n = nodes_[i];
+                if (n.tr > 0) { n.is_sink = 0; n.parent = P_TERMINAL; n.dist = 1; set_active(i); }
+                else if (n.tr < 0) { n.is_sink = 1; n.parent = P_TERMINAL; n.dist = 1; set_active(i); }
+            }
+    }
+    void make_orphan(int i) { nodes_[i].parent = P_ORPHAN; orphans_.push_back(i); }
+
+    void augment(int s, int k)
+    {
+        const int t = s + off_[k];
+        float bottleneck = nodes_[s].rc[k];
+        for (int i = s;;) {                                      // up the S tree
+            const int p = nodes_[i].parent;
+            if (p == P_TERMINAL) { if (bottleneck > nodes_[i].tr) bottleneck = nodes_[i].tr; break; }
+            const int m = i + off_[p];
+            const float c = nodes_[m].rc[p ^ 1];                 // parent -> i
+            if (bottleneck > c) bottleneck = c;
+            i = m;
+        }
+        for (int i = t;;) {                                      // down to the sink
+            const int p = nodes_[i].parent;
+            if (p == P_TERMINAL) { if (bottleneck > -nodes_[i].tr) bottleneck = -nodes_[i].tr; break; }
+            const float c = nodes_[i].rc[p];
+            if (bottleneck > c) bottleneck = c;
+            i += off_[p];
+        }
+        nodes_[s].rc[k] -= bottleneck;
+        nodes_[t].rc[k ^ 1] += bottleneck;
+        for (int i = s;;) {
+            const int p = nodes_[i].parent;
+            if (p == P_TERMINAL) {
+                nodes_[i].tr -= bottleneck;
+                if (!(nodes_[i].tr > 0)) make_orphan(i);
+                break;
+            }
+            const int m = i + off_[p];
+            nodes_[i].rc[p] += bottleneck;
+            nodes_[m].rc[p ^ 1] -= bottleneck;
+            if (!(nodes_[m].rc[p ^ 1] > 0)) make_orphan(i);
+            i = m;
+        }
+        for (int i = t;;) {
+            const int p = nodes_[i].parent;
+            if (p == P_TERMINAL) {
+                nodes_[i].tr += bottleneck;
+                if (!(nodes_[i].tr < 0)) make_orphan(i);
+                break;
+            }
+            const int m = i + off_[p];
+            nodes_[m].rc[p ^ 1] += bottleneck;
+            nodes_[i].rc[p] -= bottleneck;
+            if (!(nodes_[i].rc[p] > 0)) make_orphan(i);
+            i = m;
+        }
+        flow_ += bottleneck;
+    }
+
+    int origin_distance(int j)
+    {
+        int d = 0, k = j;
+        for (;;) {
+            if (nodes_[k].ts == time_) { d += nodes_[k].dist; break; }
+            const int p = nodes_[k].parent;
+            d++;
+            if (p == P_TERMINAL) { nodes_[k].ts = time_; nodes_[k].dist = 1; break; }
+            if (p == P_ORPHAN || p == P_NONE) return -1;
+            k += off_[p];
+        }
+        int dd = d;
+        for (k = j; nodes_[k].ts != time_; k += off_[nodes_[k].parent]) {
+            nodes_[k].ts = time_;
+            nodes_[k].dist = dd--;
+        }
+        return d;
+    }
+
+    template <bool SINKTREE>
+    void adopt(int i)
+    {
+        Node& ni = nodes_[i];
+        int best = -1, best_d = std::numeric_limits<int>::max();
+        for (int k = 0; k < 8; k++) {
+            const int j = i + off_[k];
+            const Node& nj = nodes_[j];
+            // source tree: need residual j -> i; sink tree: need residual i -> j
+            if (SINKTREE ? !(ni.rc[k] > 0) : !(nj.rc[k ^ 1] > 0)) continue;
+            if ((bool)nj.is_sink != SINKTREE || nj.parent == P_NONE) continue;
+            const int d = origin_distance(j);
+            if (d >= 0 && d < best_d) { best = k; best_d = d; }
+        }
+        if (best >= 0) {
+            ni.parent = (int8_t)best; ni.ts = time_; ni.dist = best_d + 1;
+            return;
+        }
+        ni.ts = 0;
+        for (int k = 0; k < 8; k++) {
+            const int j = i + off_[k];
+            Node& nj = nodes_[j];
+            const int pa = nj.parent;
+            if ((bool)nj.is_sink == SINKTREE && pa != P_NONE) {
+                if (SINKTREE ? (ni.rc[k] > 0) : (nj.rc[k ^ 1] > 0)) set_active(j);
+                if (pa == (k ^ 1)) make_orphan(j);               // j's parent is i
+            }
+        }
+        ni.parent = P_NONE;
+    }
+};
+
+}  // namespace les_host

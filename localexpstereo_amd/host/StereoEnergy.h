@@ -103,6 +103,27 @@ public:
         }
     }
 
+    // The three terms of computeSmoothnessTermsExpansion for one pixel `ee` = (ex, ey) and one forward neighbour k
+    // (same arithmetic; used by the expansion move to build its graph without the intermediate cost arrays).
+    void smoothnessTermsExpansionAt(const LabelMap& labeling0, const Plane& label1, int ex, int ey, int k, float& c00, float& c01, float& c10,
+                                    int mode = 0) const
+    {
+        auto dot = [](const Plane& l, float x, float y) { return ((l.a * x + l.b * y) + l.c * 1.0f) + l.v * 0.0f; };
+        const int lx = ex + neighbors[k].x, ly = ey + neighbors[k].y;
+        const bool inside = lx >= 0 && lx < width && ly >= 0 && ly < height;
+        const Plane& l0_ee = labeling0.at(ey, ex);
+        const Plane l0_le = inside ? labeling0.at(ly, lx) : Plane();
+        const float fx = (float)ex, fy = (float)ey, gx = (float)lx, gy = (float)ly;
+        const float d0_ee_at_ee = dot(l0_ee, fx, fy), d0_le_at_ee = dot(l0_le, fx, fy);
+        const float d0_ee_at_le = dot(l0_ee, gx, gy), d0_le_at_le = dot(l0_le, gx, gy);
+        const float d1_at_ee = dot(label1, fx, fy), d1_at_le = dot(label1, gx, gy);
+        const float w = smoothnessCoeff[mode][k][(size_t)ey * width + ex];
+        const float th = params.th_smooth;
+        c00 = std::min(std::fabs(d0_ee_at_ee - d0_le_at_ee) + std::fabs(d0_ee_at_le - d0_le_at_le), th) * w * params.lambda;
+        c01 = std::min(std::fabs(d0_ee_at_ee - d1_at_ee) + std::fabs(d0_ee_at_le - d1_at_le), th) * w * params.lambda;
+        c10 = std::min(std::fabs(d1_at_ee - d0_le_at_ee) + std::fabs(d1_at_le - d0_le_at_le), th) * w * params.lambda;
+    }
+
     // total smoothness energy of a labelling over forward pairs (StereoEnergy::computeSmoothnessCost, :165-203)
     double computeSmoothnessCost(const LabelMap& labeling, int mode = 0) const
     {

@@ -15,6 +15,7 @@
 
 #include "PMStereo.h"
 #include "DemoScene.h"
+#include "MaxFlow.h"
 
 using namespace les_host;
 
@@ -89,10 +90,47 @@ static int brute_force(const Scene& s, const Parameters& param, float maxd)
     return fail;
 }
 
+// GridMaxFlow (implicit 8-connected grid arcs) against the generic MaxFlowGraph on random instances: same flow value, same
+// segments (the minimum cut with the largest source side is unique).  Integer-valued capacities keep the arithmetic exact.
+static int grid_vs_generic()
+{
+    RNG rng(2024);
+    int fail = 0;
+    for (int trial = 0; trial < 40; trial++) {
+        const int w = rng.uniform(1, 24), h = rng.uniform(1, 20);
+        GridMaxFlow g(w, h);
+        MaxFlowGraph m(w * h, 4 * w * h);
+        m.add_node(w * h);
+        const int range = trial % 2 ? 4 : 50;                       // small range: many ties / saturated arcs
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                for (int rep = 0; rep < 2; rep++) {                 // accumulating t-links like the expansion move does
+                    const float a = (float)rng.uniform(0, range), b = (float)rng.uniform(0, range);
+                    g.add_tweights(x, y, a, b); m.add_tweights(y * w + x, a, b);
+                }
+                const int dx[4] = {1, 0, -1, 1}, dy[4] = {0, 1, 1, 1}, dir[4] = {GridMaxFlow::E, GridMaxFlow::S, GridMaxFlow::SW, GridMaxFlow::SE};
+                for (int k = 0; k < 4; k++) {
+                    const int xx = x + dx[k], yy = y + dy[k];
+                    if (xx < 0 || xx >= w || yy >= h) continue;
+                    const float c = (float)rng.uniform(0, range), r = (float)rng.uniform(0, trial % 3 ? 1 : range);
+                    g.add_edge(x, y, dir[k], c, r); m.add_edge(y * w + x, yy * w + xx, c, r);
+                }
+            }
+        const double fg = g.maxflow(), fm = m.maxflow();
+        int diff = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) diff += (int)g.what_segment(x, y) != (int)m.what_segment(y * w + x);
+        if (fg != fm || diff) { printf("FAIL grid max-flow trial %d (%dx%d): flow %.1f vs %.1f, %d segment differences\n", trial, w, h, fg, fm, diff); fail = 1; }
+    }
+    printf("grid max-flow vs generic: 40 random grids %s\n", fail ? "FAILED" : "identical");
+    return fail;
+}
+
 int main(int argc, char** argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 120, H = argc > 2 ? atoi(argv[2]) : 80, D = argc > 3 ? atoi(argv[3]) : 24;
     const int iters = argc > 4 ? atoi(argv[4]) : 2;
+    const bool check = argc > 5 ? atoi(argv[5]) != 0 : true;          // 0: skip the per-move energy recomputation (timing runs)
     Scene s = make_scene(W, H, D);
     Parameters param(1.0f, 20, "GF", 1e-4f);
     param.th_col = 0.5f;
@@ -101,13 +139,14 @@ int main(int argc, char** argv)
     {
         Scene tiny = make_scene(16, 12, 8);
         fail |= brute_force(tiny, param, 7.0f);
+        fail |= grid_vs_generic();
     }
     PMStereo st(W, H, param, maxd);
     st.setSeed(11);
     st.setStereoEnergy(std::make_unique<PointwiseTestEnergy>(s, param, maxd));
     st.addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
     st.addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}});
-    st.checkFlowEnergy = true;
+    st.checkFlowEnergy = check;
     st.initCurrentFast(0);
     double e_prev = st.totalEnergy(0);
     printf("init      E=%.2f  bad1.0=%.2f%%\n", e_prev, bad_pixels(st.computeDisparities(0), s, 1.0f));
