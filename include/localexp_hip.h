@@ -131,6 +131,21 @@ int les_hip_wta_update(les_hip_ctx* ctx, int n, const les_hip_rect* rects, const
 int les_hip_fill_out_of_view(float* vol_dev, int D, int H, int W, int mode, int device, void* hip_stream);
 int les_hip_convert_volume_l2r(const float* src_dev, float* dst_dev, int D, int H, int W, int device, void* hip_stream);
 
+/* replaces (on the device): the pairwise side of FastGCStereo::expansionMoveBK's graph construction
+ * (LES/FastGCStereo.h:425-551) with StereoEnergy::initSmoothnessCoeff / computeSmoothnessTerm /
+ * computeSmoothnessTermsExpansion (LES/StereoEnergy.h:131-163, 225-230, 398-453): for every cell i of the batch (its
+ * target rect = the cell's shared region, proposal d_planes[i]) the ready-made capacities of the cell's 8-connected
+ * grid graph.  d_payload: 5 floats per node {source-minus-sink terminal residual, arc capacities towards E, S, SW, SE}
+ * (reverse capacities are 0), cell i at 5 * offsets[i] floats, nodes row-major over its rect; total
+ * les_hip_batch_graph_nodes() nodes.  The values are bit-identical to the host construction
+ * (localexpstereo_amd/host/ExpansionMove.h).  d_labels / d_cur / d_prop: current label map, current and proposal cost
+ * maps (H x W, device).  flow0_host (n doubles, may be NULL): flow already routed by the t-links per cell. */
+long long les_hip_batch_graph_nodes(const les_hip_batch* batch);
+int les_hip_batch_graph_offsets(const les_hip_batch* batch, long long* offsets /* n */);
+int les_hip_batch_expansion_graph(les_hip_ctx* ctx, const les_hip_batch* batch, int mode, const les_hip_plane* d_planes,
+                                  const les_hip_plane* d_labels, const float* d_cur, const float* d_prop, float lambda, float th_smooth,
+                                  float omega, float epsilon, float* d_payload, double* flow0_host);
+
 /* replaces: PMStereoBase::doConsistencyCheck (LES/PMStereoBase.h:111-144) -- left-right check of the disparities of two
  * device label maps (H x W planes each): fail = 255 where |d_other(x -/+ d) - d| > threshold, 128 where the pixel maps
  * outside the other view, 0 otherwise.  d_failL / d_failR: H x W bytes on the device. */

@@ -45,6 +45,20 @@ float* les_gc_costs(les_gc_ctx* ctx, int mode);
 int les_gc_expansion_moves(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,
                            const float* proposal_cost, int nthreads, int check, double* max_gap);
 
+/* The same lock-step on graphs whose capacities were computed on the device (include/localexp_hip.h:
+ * les_hip_batch_expansion_graph): payload = 5 floats per node {terminal residual, caps E, S, SW, SE}, cell i at
+ * 5 * offsets[i]; flow0[i] (may be NULL) = flow already routed by the t-links; flows (may be NULL) receives the flow
+ * values.  Only the max-flow, the segment readout and the mask updates (LES/FastGCStereo.h:553-559, :61-62) run on
+ * the host. */
+int les_gc_expansion_moves_prebuilt(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,
+                                    const float* proposal_cost, const float* payload, const long long* offsets, const double* flow0,
+                                    int nthreads, double* flows);
+
+/* Host construction of the same payload from the context's current solution (the code path of
+ * les_gc_expansion_moves up to the max-flow): the parity reference of the device construction. */
+int les_gc_build_graphs(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,
+                        const float* proposal_cost, const long long* offsets, float* payload, double* flow0);
+
 /* StereoEnergy::computeSmoothnessCost (LES/StereoEnergy.h:165-203) and the data term (sum of the current costs,
  * LES/Evaluator.h:119-121) of the context's current solution. */
 double les_gc_smoothness_cost(les_gc_ctx* ctx, int mode);

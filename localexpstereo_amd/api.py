@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
     "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
@@ -64,6 +64,9 @@ def load(path=None):
     vp, ci = C.c_void_p, C.c_int
     sig = {
         "les_hip_create": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, vp, vp]),
+        "les_hip_batch_graph_nodes": (C.c_longlong, [vp]),
+        "les_hip_batch_graph_offsets": (ci, [vp, vp]),
+        "les_hip_batch_expansion_graph": (ci, [vp, vp, ci, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
         "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
         "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
         "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),
@@ -205,6 +208,25 @@ class Batch:
     def wta(self, planes_dev, cur_cost_dev, prop_cost_dev, labels_dev):
         self.e._chk(self.e.L.les_hip_batch_wta(self.e.h, self.h, C.c_void_p(int(planes_dev)), C.c_void_p(int(cur_cost_dev)),
                                                C.c_void_p(int(prop_cost_dev)), C.c_void_p(int(labels_dev))))
+
+    # -- pairwise terms / graph capacities of the expansion moves on the device ("next" row N1)
+    def graph_nodes(self):
+        return int(self.e.L.les_hip_batch_graph_nodes(self.h))
+
+    def graph_offsets(self):
+        off = np.zeros(self.n, np.int64)
+        self.e._chk(self.e.L.les_hip_batch_graph_offsets(self.h, _ptr(off)))
+        return off
+
+    def expansion_graph(self, planes_dev, labels_dev, cur_dev, prop_dev, payload_dev, mode=0, lambda_=1.0, th_smooth=1.0, omega=10.0, epsilon=0.01,
+                        want_flow0=False):
+        """Graph capacities of one lock-step (LES/FastGCStereo.h:425-551 + LES/StereoEnergy.h:398-453) into payload_dev
+        (5 floats per node).  Returns the per-cell t-link flow when want_flow0."""
+        f0 = np.zeros(self.n, np.float64) if want_flow0 else None
+        self.e._chk(self.e.L.les_hip_batch_expansion_graph(self.e.h, self.h, mode, C.c_void_p(int(planes_dev)), C.c_void_p(int(labels_dev)),
+                                                           C.c_void_p(int(cur_dev)), C.c_void_p(int(prop_dev)), lambda_, th_smooth, omega, epsilon,
+                                                           C.c_void_p(int(payload_dev)), _ptr(f0)))
+        return f0
 
     def destroy(self):
         if self.h:

@@ -8,6 +8,7 @@
 #include "les_kernels.h"
 #include "les_propose.h"
 #include "les_post.h"
+#include "les_pairwise.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -58,6 +59,9 @@ const StripEntry kStrips[] = {
     // A/B variants for radius 10 (LES_HIP_VARIANT=n)
     LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
     LES_STRIP_ENTRY(10, 4, 96, 21, 4, 3), LES_STRIP_ENTRY(10, 5, 80, 21, 3, 3),
+    // measured (ms per 1500x1000x256 pass): 0: 7.14 | 11 = (64,21,3) at 2 waves/SIMD: 9.57 | (128,21,SEG 3/4/6) at 2 waves: 10.2 / 11.2 / 8.8
+    // | (96,21,SEG 3/4) at 2 waves (6-wave workgroups): 15.1 / 12.4  -- occupancy beats the lower instruction count of wide strips
+    LES_STRIP_ENTRY(10, 8, 128, 21, 6, 2), LES_STRIP_ENTRY(10, 11, 64, 21, 3, 2),
 };
 // image-based matching cost (les_hip_create_naive): one conservative configuration per radius
 #define LES_NAIVE_ENTRY(R_, WA_, BY_, SEG_, MW_) \
@@ -113,6 +117,8 @@ struct les_hip_ctx {
     float* d_map = nullptr;                         // H*W floats
     les::WtaJob* d_wta = nullptr; size_t wta_cap = 0;
     float4* d_wta_planes = nullptr; size_t wta_planes_cap = 0;
+    // smoothness-coefficient table of the pairwise terms, cached per (omega, epsilon)
+    float* d_pw_tab = nullptr; float pw_omega = -1.f, pw_epsilon = -1.f;
 };
 
 struct les_hip_batch {
@@ -125,6 +131,11 @@ struct les_hip_batch {
     les::WtaJob* d_targets = nullptr;
     les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // RANSAC proposer scratch
     int wta_chunks = 1;                  // blocks per target rect in the WTA kernel
+    // expansion-graph payload layout (les_hip_batch_expansion_graph): node offset of every target, total node count
+    std::vector<long long> graph_off;
+    long long graph_nodes = 0;
+    long long* d_graph_off = nullptr;
+    double* d_flow0 = nullptr;           // n * wta_chunks partial sums
 };
 
 namespace {
@@ -327,6 +338,7 @@ void les_hip_destroy(les_hip_ctx* c)
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_wta) (void)hipFree(c->d_wta);
     if (c->d_wta_planes) (void)hipFree(c->d_wta_planes);
+    if (c->d_pw_tab) (void)hipFree(c->d_pw_tab);
     delete c;
 }
 
@@ -359,8 +371,20 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
         for (int i = 0; i < n; i++) max_area = std::max(max_area, trs[i].w * trs[i].h);
         b->wta_chunks = std::min(32, std::max(1, (max_area + 4095) / 4096));
     }
+    b->graph_off.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        b->graph_off[i] = b->graph_nodes;
+        b->graph_nodes += (long long)std::max(0, trs[i].w) * std::max(0, trs[i].h);
+    }
     if (n > 0) {
         static_assert(sizeof(les::WtaJob) == sizeof(les_hip_rect), "rect layout");
+        static_assert(sizeof(les::GraphCell) == sizeof(les_hip_rect), "rect layout");
+        if (hipMalloc((void**)&b->d_graph_off, (size_t)n * sizeof(long long)) != hipSuccess ||
+            hipMemcpy(b->d_graph_off, b->graph_off.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMalloc((void**)&b->d_flow0, (size_t)n * b->wta_chunks * sizeof(double)) != hipSuccess) {
+            les_hip_batch_destroy(b);
+            return fail(LES_HIP_ERR_DEVICE, "upload of the graph offset table failed");
+        }
         if (hipMalloc((void**)&b->d_targets, (size_t)n * sizeof(les::WtaJob)) != hipSuccess ||
             hipMemcpy(b->d_targets, trs, (size_t)n * sizeof(les::WtaJob), hipMemcpyHostToDevice) != hipSuccess) {
             les_hip_batch_destroy(b);
@@ -383,6 +407,8 @@ void les_hip_batch_destroy(les_hip_batch* b)
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_units) (void)hipFree(b->d_units);
     if (b->d_targets) (void)hipFree(b->d_targets);
+    if (b->d_graph_off) (void)hipFree(b->d_graph_off);
+    if (b->d_flow0) (void)hipFree(b->d_flow0);
     if (b->rs.disp) (void)hipFree(b->rs.disp);
     if (b->rs.idx) (void)hipFree(b->rs.idx);
     if (b->rs.state) (void)hipFree(b->rs.state);
@@ -468,6 +494,54 @@ int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plan
 }
 
 int les_hip_batch_num_jobs(const les_hip_batch* b) { return b ? b->njobs : 0; }
+
+long long les_hip_batch_graph_nodes(const les_hip_batch* b) { return b ? b->graph_nodes : 0; }
+
+int les_hip_batch_graph_offsets(const les_hip_batch* b, long long* offsets)
+{
+    if (!b || !offsets) return fail(LES_HIP_ERR_ARG, "null argument");
+    std::copy(b->graph_off.begin(), b->graph_off.end(), offsets);
+    return LES_HIP_OK;
+}
+
+int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mode, const les_hip_plane* d_planes, const les_hip_plane* d_labels,
+                                  const float* d_cur, const float* d_prop, float lambda, float th_smooth, float omega, float epsilon,
+                                  float* d_payload, double* flow0_host)
+{
+    if (!c || !b || !d_planes || !d_labels || !d_cur || !d_prop || !d_payload) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (mode < 0 || mode > 1 || !c->v[mode].ipk) return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
+    if (b->n == 0) return LES_HIP_OK;
+    if (c->pw_omega != omega || c->pw_epsilon != epsilon || !c->d_pw_tab) {
+        // initSmoothnessCoeff (LES/StereoEnergy.h:131-163): max(epsilon, exp(-|dI|_1 / omega)) in float
+        std::vector<float> tab(766);
+        for (int k = 0; k < 766; k++) tab[k] = std::max(epsilon, std::exp(-(float)k / omega));
+        if (!c->d_pw_tab) HIPCHECK(hipMalloc((void**)&c->d_pw_tab, tab.size() * sizeof(float)));
+        HIPCHECK(hipMemcpyAsync(c->d_pw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        c->pw_omega = omega; c->pw_epsilon = epsilon;
+    }
+    const les::PairwiseParams pp{c->p.H, c->p.W, lambda, th_smooth};
+    const les::GraphCell* cells = reinterpret_cast<const les::GraphCell*>(b->d_targets);
+    const long long* offs = b->d_graph_off;
+    const float4 *pl = reinterpret_cast<const float4*>(d_planes), *lab = reinterpret_cast<const float4*>(d_labels);
+    const uint32_t* ipk = c->v[mode].ipk;
+    const float* wtab = c->d_pw_tab;
+    double* flow0 = b->d_flow0;
+    hipLaunchKernelGGL(les::les_expansion_graph_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, cells, offs, pl, lab, d_cur, d_prop, ipk, wtab,
+                       pp, d_payload, flow0);
+    HIPCHECK(hipGetLastError());
+    if (flow0_host) {
+        std::vector<double> part((size_t)b->n * b->wta_chunks);
+        HIPCHECK(hipMemcpyAsync(part.data(), b->d_flow0, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < b->n; i++) {
+            double s = 0;
+            for (int k = 0; k < b->wta_chunks; k++) s += part[(size_t)i * b->wta_chunks + k];
+            flow0_host[i] = s;
+        }
+    }
+    return LES_HIP_OK;
+}
 
 int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const les_hip_plane* planes, int planes_on_device,
                       float* out_dev, int check)

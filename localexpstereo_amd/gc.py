@@ -11,7 +11,7 @@ from . import api
 
 DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "liblocalexp_host.so")
 SYMBOLS = ["les_gc_create", "les_gc_destroy", "les_gc_last_error", "les_gc_labels", "les_gc_costs", "les_gc_expansion_moves",
-           "les_gc_smoothness_cost", "les_gc_data_cost"]
+           "les_gc_expansion_moves_prebuilt", "les_gc_build_graphs", "les_gc_smoothness_cost", "les_gc_data_cost"]
 _lib = None
 
 
@@ -31,6 +31,8 @@ def load(path=None):
         "les_gc_labels": (C.POINTER(C.c_float), [vp, ci]),
         "les_gc_costs": (C.POINTER(C.c_float), [vp, ci]),
         "les_gc_expansion_moves": (ci, [vp, ci, ci, vp, vp, vp, ci, ci, C.POINTER(C.c_double)]),
+        "les_gc_expansion_moves_prebuilt": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+        "les_gc_build_graphs": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp]),
         "les_gc_smoothness_cost": (C.c_double, [vp, ci]),
         "les_gc_data_cost": (C.c_double, [vp, ci]),
     }
@@ -46,6 +48,7 @@ class GraphCut:
 
     def __init__(self, imL, imR, lambda_=20.0, th_smooth=1.0, omega=10.0, epsilon=0.01, lib=None):
         self.L = load(lib)
+        self.params = dict(lambda_=float(lambda_), th_smooth=float(th_smooth), omega=float(omega), epsilon=float(epsilon))
         self.imL = np.ascontiguousarray(imL, np.uint8) if imL is not None else None
         self.imR = np.ascontiguousarray(imR, np.uint8) if imR is not None else None
         im = self.imL if self.imL is not None else self.imR
@@ -68,6 +71,32 @@ class GraphCut:
         if self.L.les_gc_expansion_moves(self.h, mode, len(regions), api._ptr(regions), api._ptr(planes), api._ptr(pc), nthreads, int(check), C.byref(gap)):
             raise RuntimeError(self.L.les_gc_last_error().decode())
         return gap.value
+
+    def expansion_moves_prebuilt(self, regions, planes, proposal_cost, payload, offsets, flow0=None, mode=0, nthreads=0):
+        """The same lock-step on device-built graphs (api.Batch.expansion_graph): only max-flow + mask updates on the host."""
+        regions, planes = api._rects(regions), api._planes(planes)
+        pc = np.ascontiguousarray(proposal_cost, np.float32)
+        payload = np.ascontiguousarray(payload, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        f0 = np.ascontiguousarray(flow0, np.float64) if flow0 is not None else None
+        flows = np.zeros(len(regions), np.float64)
+        if self.L.les_gc_expansion_moves_prebuilt(self.h, mode, len(regions), api._ptr(regions), api._ptr(planes), api._ptr(pc), api._ptr(payload),
+                                                  api._ptr(offsets), api._ptr(f0), nthreads, api._ptr(flows)):
+            raise RuntimeError(self.L.les_gc_last_error().decode())
+        return flows
+
+    def build_graphs(self, regions, planes, proposal_cost, offsets, mode=0):
+        """Host construction of the graph payload (parity reference of the device construction)."""
+        regions, planes = api._rects(regions), api._planes(planes)
+        pc = np.ascontiguousarray(proposal_cost, np.float32)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        total = int(offsets[-1] + regions[-1]["w"] * regions[-1]["h"]) if len(regions) else 0
+        payload = np.zeros(total * 5, np.float32)
+        flow0 = np.zeros(len(regions), np.float64)
+        if self.L.les_gc_build_graphs(self.h, mode, len(regions), api._ptr(regions), api._ptr(planes), api._ptr(pc), api._ptr(offsets), api._ptr(payload),
+                                      api._ptr(flow0)):
+            raise RuntimeError(self.L.les_gc_last_error().decode())
+        return payload, flow0
 
     def smoothness_cost(self, mode=0):
         return self.L.les_gc_smoothness_cost(self.h, mode)

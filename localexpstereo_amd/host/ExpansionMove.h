@@ -24,13 +24,12 @@ struct CostView {
     float at(int y, int x) const { return p[(size_t)y * stride + x]; }
 };
 
-inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeling, CostView currentCost,
-                            CostView proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
-                            int mode = 0)
+// graph construction of expansionMoveBK (LES/FastGCStereo.h:425-551)
+inline void buildExpansionGraph(GridMaxFlow& graph, const StereoEnergy& E, const LabelMap& currentLabeling, CostView currentCost,
+                                CostView proposalCost, const Plane& label1, const Rect& region, int mode = 0)
 {
-    const int w = region.width, h = region.height, N = w * h;
+    const int w = region.width, h = region.height;
     const int W = E.getWidth(), H = E.getHeight();
-    GridMaxFlow graph(w, h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const Point ps{region.x + x, region.y + y};
@@ -61,11 +60,37 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
     link(StereoEnergy::NB_EG, GridMaxFlow::S, 0, w, h - 1, 0, +1);           // ee <-> eg
     link(StereoEnergy::NB_LG, GridMaxFlow::SW, 1, w, h - 1, -1, +1);         // ee <-> lg
     link(StereoEnergy::NB_GG, GridMaxFlow::SE, 0, w - 1, h - 1, +1, +1);     // ee <-> gg
+}
+
+// max-flow + segment readout (LES/FastGCStereo.h:553-559)
+inline double solveExpansionGraph(GridMaxFlow& graph, const Rect& region, std::vector<uint8_t>& updateMask)
+{
+    const int w = region.width, h = region.height;
     const double flow = graph.maxflow();
-    updateMask.resize((size_t)N);
+    updateMask.resize((size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) updateMask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
     return flow;
+}
+
+inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeling, CostView currentCost,
+                            CostView proposalCost, const Plane& label1, const Rect& region, std::vector<uint8_t>& updateMask,
+                            int mode = 0)
+{
+    GridMaxFlow graph(region.width, region.height);
+    buildExpansionGraph(graph, E, currentLabeling, currentCost, proposalCost, label1, region, mode);
+    return solveExpansionGraph(graph, region, updateMask);
+}
+
+// The same move on a graph whose capacities were computed on the device (5 floats per node, row-major over the region;
+// include/localexp_hip.h: les_hip_batch_expansion_graph).
+inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, std::vector<uint8_t>& updateMask)
+{
+    GridMaxFlow graph(region.width, region.height);
+    for (int y = 0; y < region.height; y++)
+        for (int x = 0; x < region.width; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * region.width + x));
+    graph.set_base_flow(base_flow);
+    return solveExpansionGraph(graph, region, updateMask);
 }
 
 // The reference's (disabled) self-check of the graph construction, LES/FastGCStereo.h:561-594: the flow equals the

@@ -47,6 +47,21 @@ public:
         nodes_[i + off_[k]].rc[k ^ 1] += rev_cap;
     }
 
+    // direct initialisation from / export to the 5-float node payload {terminal residual, caps E, S, SW, SE} produced by
+    // the device (include/localexp_hip.h: les_hip_batch_expansion_graph); base_flow = flow already routed by the t-links
+    void load_node(int x, int y, const float* p5)
+    {
+        Node& n = nodes_[id(x, y)];
+        n.tr = p5[0]; n.rc[E] = p5[1]; n.rc[S] = p5[2]; n.rc[SW] = p5[3]; n.rc[SE] = p5[4];
+    }
+    void store_node(int x, int y, float* p5) const
+    {
+        const Node& n = nodes_[id(x, y)];
+        p5[0] = n.tr; p5[1] = n.rc[E]; p5[2] = n.rc[S]; p5[3] = n.rc[SW]; p5[4] = n.rc[SE];
+    }
+    void set_base_flow(double f) { flow_ = f; }
+    double base_flow() const { return flow_; }
+
     double maxflow()
     {
         init_trees();

@@ -107,6 +107,13 @@ public:
 #pragma omp critical(les_gap)
             { maxFlowEnergyGap = std::max(maxFlowEnergyGap, gap); numMoves++; }
         }
+        applyMask(label, sharedRegion, proposalCost, mask, mode);
+    }
+    // subProposalCost.copyTo(subCurrentCost, updateMask); subCurrentLabeling.setTo(label, updateMask)  (LES/FastGCStereo.h:61-62)
+    void applyMask(const Plane& label, const Rect& sharedRegion, CostView proposalCost, const std::vector<uint8_t>& mask, int mode)
+    {
+        CostMap& currentCost = currentCost_[mode];
+        LabelMap& currentLabeling = currentLabeling_[mode];
         for (int y = 0; y < sharedRegion.height; y++)
             for (int x = 0; x < sharedRegion.width; x++)
                 if (mask[(size_t)y * sharedRegion.width + x]) {
@@ -234,6 +241,11 @@ public:
             // cut the cells' graphs, the fused label map returns to the device for the next proposals
             CostMap proposalCost(height, width);
             std::vector<les_hip_plane> hplanes;
+            std::vector<float> payload;
+            std::vector<long long> goff;
+            float* d_payload = nullptr;
+            long long payload_cap = 0;
+            if (maxIteration > 0 && ok) chk(les_hip_memcpy_h2d(ctx, d_cur, currentCost_[mode].data.data(), P * sizeof(float)));
             for (int iteration = 0; iteration < maxIteration && ok; iteration++)
                 for (size_t li = 0; li < batches.size(); li++)
                     for (SetBatch& sb : batches[li])
@@ -244,6 +256,23 @@ public:
                                 const auto tA = std::chrono::steady_clock::now();
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
+                                // pairwise terms / graph capacities on the device unless the self-check wants the host construction
+                                const bool devGraph = deviceGraph && !checkFlowEnergy;
+                                const long long nodes = les_hip_batch_graph_nodes(sb.b);
+                                if (devGraph) {
+                                    if (nodes * 5 > payload_cap) {
+                                        if (d_payload) les_hip_free(ctx, d_payload);
+                                        d_payload = nullptr;
+                                        payload_cap = nodes * 5;
+                                        chk(les_hip_malloc(ctx, (void**)&d_payload, (size_t)payload_cap * sizeof(float)));
+                                    }
+                                    chk(les_hip_batch_expansion_graph(ctx, sb.b, mode, sb.planes, d_labels, d_cur, d_prop, params.lambda, params.th_smooth,
+                                                                      params.omega, params.epsilon, d_payload, nullptr));
+                                    payload.resize((size_t)nodes * 5);
+                                    goff.resize((size_t)sb.n);
+                                    chk(les_hip_batch_graph_offsets(sb.b, goff.data()));
+                                    if (ok) chk(les_hip_memcpy_d2h(ctx, payload.data(), d_payload, (size_t)nodes * 5 * sizeof(float)));
+                                }
                                 hplanes.resize(sb.n);
                                 chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
                                 chk(les_hip_memcpy_d2h(ctx, proposalCost.data.data(), d_prop, P * sizeof(float)));
@@ -256,16 +285,24 @@ public:
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
                                 for (int n = 0; n < sb.n; n++) {
                                     const les_hip_plane& hp = hplanes[n];
-                                    fuseProposal(Plane(hp.a, hp.b, hp.c, hp.v), L.sharedRegions[sb.cells[n]], proposalCost, mode, true);
+                                    const Plane label(hp.a, hp.b, hp.c, hp.v);
+                                    const Rect& region = L.sharedRegions[sb.cells[n]];
+                                    if (devGraph) {
+                                        std::vector<uint8_t> mask;
+                                        expansionMovePrebuilt(payload.data() + 5 * goff[n], 0.0, region, mask);
+                                        applyMask(label, region, proposalCost, mask, mode);
+                                    } else fuseProposal(label, region, proposalCost, mode, true);
                                 }
                                 const auto tC = std::chrono::steady_clock::now();
                                 chk(les_hip_memcpy_h2d(ctx, d_labels, currentLabeling_[mode].data.data(), P * sizeof(les_hip_plane)));
+                                if (deviceGraph) chk(les_hip_memcpy_h2d(ctx, d_cur, currentCost_[mode].data.data(), P * sizeof(float)));
                                 const auto tD = std::chrono::steady_clock::now();
                                 gcSeconds[0] += std::chrono::duration<double>(tB - tA).count();
                                 gcSeconds[1] += std::chrono::duration<double>(tC - tB).count();
                                 gcSeconds[2] += std::chrono::duration<double>(tD - tC).count();
                                 gcLockSteps++;
                             }
+            if (d_payload) les_hip_free(ctx, d_payload);
         }
         // two-view runs end with the left-right post-processing (LES/FastGCStereo.h:199-203)
         if (ok && viewModes.size() == 2) ok = postProcess(1.5f);
@@ -324,6 +361,7 @@ public:
     long numMoves = 0;
     double gcSeconds[3] = {0, 0, 0};    // runDevice graph-cut lock-steps: GPU propose+unary+D2H / host cuts / H2D labels
     long gcLockSteps = 0;
+    bool deviceGraph = true;            // runDevice: pairwise terms / graph capacities of the moves computed on the GPU (N1)
     int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: half the cores, at most one per cell)
 
 private:

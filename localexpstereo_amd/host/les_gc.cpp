@@ -104,6 +104,57 @@ int les_gc_expansion_moves(les_gc_ctx* c, int mode, int n, const les_hip_rect* r
     return 0;
 }
 
+int les_gc_expansion_moves_prebuilt(les_gc_ctx* c, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes, const float* proposal_cost,
+                                    const float* payload, const long long* offsets, const double* flow0, int nthreads, double* flows)
+{
+    if (!c || mode < 0 || mode > 1 || n < 0 || (n > 0 && (!regions || !planes || !proposal_cost || !payload || !offsets)))
+        return fail("les_gc_expansion_moves_prebuilt: bad argument");
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect& r = regions[i];
+        if (r.w < 0 || r.h < 0 || r.x < 0 || r.y < 0 || r.x + r.w > c->W || r.y + r.h > c->H) return fail("les_gc_expansion_moves_prebuilt: region %d outside the image", i);
+    }
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    nthreads = std::max(1, std::min(nthreads, n));
+    LabelMap& lab = c->labels[mode];
+    CostMap& cur = c->costs[mode];
+    const CostView prop(proposal_cost, c->W);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int i = 0; i < n; i++) {
+        const Rect region(regions[i].x, regions[i].y, regions[i].w, regions[i].h);
+        if (region.width == 0 || region.height == 0) continue;
+        const Plane label(planes[i].a, planes[i].b, planes[i].c, planes[i].v);
+        std::vector<uint8_t> mask;
+        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], flow0 ? flow0[i] : 0.0, region, mask);
+        if (flows) flows[i] = flow;
+        for (int y = 0; y < region.height; y++)
+            for (int x = 0; x < region.width; x++)
+                if (mask[(size_t)y * region.width + x]) {
+                    cur.at(region.y + y, region.x + x) = prop.at(region.y + y, region.x + x);
+                    lab.at(region.y + y, region.x + x) = label;
+                }
+    }
+    return 0;
+}
+
+int les_gc_build_graphs(les_gc_ctx* c, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes, const float* proposal_cost,
+                        const long long* offsets, float* payload, double* flow0)
+{
+    if (!c || mode < 0 || mode > 1 || n < 0 || (n > 0 && (!regions || !planes || !proposal_cost || !payload || !offsets))) return fail("les_gc_build_graphs: bad argument");
+    if (!c->E->hasImages(mode)) return fail("les_gc_build_graphs: view %d has no image", mode);
+    const CostView prop(proposal_cost, c->W);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        const Rect region(regions[i].x, regions[i].y, regions[i].w, regions[i].h);
+        if (region.width <= 0 || region.height <= 0) continue;
+        GridMaxFlow graph(region.width, region.height);
+        buildExpansionGraph(graph, *c->E, c->labels[mode], c->costs[mode], prop, Plane(planes[i].a, planes[i].b, planes[i].c, planes[i].v), region, mode);
+        for (int y = 0; y < region.height; y++)
+            for (int x = 0; x < region.width; x++) graph.store_node(x, y, payload + 5 * (offsets[i] + (long long)y * region.width + x));
+        if (flow0) flow0[i] = graph.base_flow();
+    }
+    return 0;
+}
+
 double les_gc_smoothness_cost(les_gc_ctx* c, int mode) { return (c && mode >= 0 && mode < 2 && c->E->hasImages(mode)) ? c->E->computeSmoothnessCost(c->labels[mode], mode) : 0.0; }
 
 double les_gc_data_cost(les_gc_ctx* c, int mode)

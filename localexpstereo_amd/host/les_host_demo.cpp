@@ -130,6 +130,17 @@ static int cmd_run(int argc, char** argv)
                e_pm, bad_pm, iters, e_gc, bad_gc, st2->numMoves, st2->maxFlowEnergyGap, sec);
         printf("graph-cut lock-steps: %ld   GPU propose+unary+D2H %.3f s   host cuts %.3f s   H2D labels %.3f s\n", st2->gcLockSteps,
                st2->gcSeconds[0], st2->gcSeconds[1], st2->gcSeconds[2]);
+        // the same run with the pairwise terms / graph capacities computed on the GPU: identical labels
+        auto st3 = build(7);
+        st3->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st3->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        double sec3 = 0;
+        if (!st3->runDevice(1, {0}, &sec3, iters)) { printf("FAIL: runDevice (device graphs)\n"); return 1; }
+        size_t diff = 0;
+        for (size_t i = 0; i < st3->currentLabeling_[0].data.size(); i++) diff += !(st3->currentLabeling_[0].data[i] == st2->currentLabeling_[0].data[i]);
+        printf("device-built graphs: %zu label differences vs host-built  (%.3f s; GPU %.3f s, host cuts %.3f s, H2D %.3f s)\n", diff, sec3,
+               st3->gcSeconds[0], st3->gcSeconds[1], st3->gcSeconds[2]);
+        if (diff) { printf("FAIL: device-built graphs changed the result\n"); fail = 1; }
         if (e_gc > e_pm) { printf("FAIL: graph-cut iterations increased the energy\n"); fail = 1; }
         if (st2->maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
         if (bad_gc > 10.0) { printf("FAIL: graph-cut run did not converge\n"); fail = 1; }

@@ -84,7 +84,10 @@ def ingest_volumes(volL, volR=None, device="cuda", lib=None):
     def upload(v):
         # never alias the caller's (possibly read-only, memory-mapped) array: the fills work in place
         if dev.type == "cuda":
-            return torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev)
+            a = np.ascontiguousarray(v, np.float32)
+            if not a.flags.writeable:                     # read-only memmap: stage through a writable (page-cache backed) copy
+                a = np.array(a, np.float32, copy=True)
+            return torch.from_numpy(a).to(dev)
         return torch.from_numpy(np.array(v, np.float32, copy=True))
 
     tl = upload(volL)

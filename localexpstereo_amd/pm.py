@@ -79,6 +79,9 @@ class _Shard:
         self.batch.set_units(units[self.own])
         self.rng = torch.from_numpy(seeds[self.own].view(np.int64).copy()).to(dev)
         self.planes = torch.zeros((max(1, self.n), 4), dtype=torch.float32, device=dev)
+        self.graph_off = self.batch.graph_offsets()
+        self.graph_nodes = self.batch.graph_nodes()
+        self.payload = None                      # device / pinned host buffers of the graph capacities, allocated on first use
         self.idx = [torch.from_numpy(_pixel_indices(tgt[cells[bounds[r]:bounds[r + 1]]], runner.W)).to(dev) for r in range(world)]
         self.lmax = max(int(i.numel()) for i in self.idx)
 
@@ -159,8 +162,11 @@ class PMRunner:
     # Proposals and unary costs come from the GPU exactly as in iteration(); the winner-take-all update is replaced by
     # the local expansion moves of the rank's own cells on the host cores (gc.GraphCut), and the fused labels go
     # back to the device for the next proposals.  Cross-rank coherence is the same per-set all-gather.
-    def begin_gc(self, graph_cut, mode=None):
+    def begin_gc(self, graph_cut, mode=None, device_graph=True):
+        """device_graph: the pairwise terms / graph capacities of every move are computed on the GPU
+        (les_hip_batch_expansion_graph) and the host only runs the max-flows; False = host construction."""
         self.gc = graph_cut
+        self.device_graph = device_graph
         m = self.mode if mode is None else mode
         self._sync()
         self.gc.labels[m][...] = self.labels.cpu().numpy()
@@ -185,14 +191,32 @@ class PMRunner:
                             t0 = time.perf_counter()
                             sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=mm)
                             sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=m, check=True, planes_on_device=True)
+                            use_dev = self.device_graph and not check
+                            if use_dev:
+                                if sh.payload is None:
+                                    sh.payload = torch.empty(max(1, sh.graph_nodes * 5), dtype=torch.float32, device=self.device)
+                                    sh.payload_host = torch.empty(max(1, sh.graph_nodes * 5), dtype=torch.float32)
+                                    if self.device.type == "cuda":
+                                        sh.payload_host = sh.payload_host.pin_memory()
+                                sh.batch.expansion_graph(sh.planes.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(),
+                                                         sh.payload.data_ptr(), mode=m, lambda_=gc.params["lambda_"], th_smooth=gc.params["th_smooth"],
+                                                         omega=gc.params["omega"], epsilon=gc.params["epsilon"])
                             self._sync()
                             self._prop_host.copy_(self.prop)
+                            if use_dev:
+                                sh.payload_host.copy_(sh.payload)
                             planes = sh.planes[: sh.n].cpu().numpy()
                             t1 = time.perf_counter()
-                            gap = gc.expansion_moves(sh.regions, planes, self._prop_host.numpy(), mode=m, nthreads=nthreads, check=check)
-                            self.gc_max_gap = max(self.gc_max_gap, gap)
+                            if use_dev:
+                                gc.expansion_moves_prebuilt(sh.regions, planes, self._prop_host.numpy(), sh.payload_host.numpy(), sh.graph_off, mode=m,
+                                                            nthreads=nthreads)
+                            else:
+                                gap = gc.expansion_moves(sh.regions, planes, self._prop_host.numpy(), mode=m, nthreads=nthreads, check=check)
+                                self.gc_max_gap = max(self.gc_max_gap, gap)
                             t2 = time.perf_counter()
                             self.labels.copy_(lab_host)
+                            if self.device_graph:
+                                self.cur.copy_(cur_host)              # the device t-links read the current costs
                             t3 = time.perf_counter()
                             self.gc_seconds["device"] += t1 - t0
                             self.gc_seconds["host_cuts"] += t2 - t1

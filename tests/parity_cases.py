@@ -731,7 +731,7 @@ def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25)
     r.begin_gc(g)
     hist = [(bad(1.0), g.data_cost(0), g.smoothness_cost(0))]
     for it in range(gc_iters):
-        r.gc_iteration(it, check=True)
+        r.gc_iteration(it, check=(it == 0))          # later iterations: graph capacities computed on the device
         hist.append((bad(1.0), g.data_cost(0), g.smoothness_cost(0)))
         assert np.array_equal(r.labels.cpu().numpy(), g.labels[0])            # device and host solutions stay identical
     gap = r.gc_max_gap
@@ -772,3 +772,56 @@ def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     assert lab.shape == raw.shape == imLw.shape[:2] + (4,)
     assert (lab != raw).any()                                   # post-processing replaced some labels
     return rows
+
+
+def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
+    """Pairwise terms on the device (N1): the graph capacities of a lock-step computed by les_hip_batch_expansion_graph
+    must be bit-identical to the host construction (liblocalexp_host.so: les_gc_build_graphs), and the moves on the
+    device-built graphs must give the same labels as the host-built ones.  Cells at the image border included."""
+    from localexpstereo_amd import gc as lgc
+    H, W, D = pr.H, pr.W, pr.D
+    rng = np.random.default_rng(seed)
+    layer = om.Layer(W, H, 20, unit)
+    labels = _label_map(H, W, D, seed, noise=0.05)
+    lab4 = np.ascontiguousarray(labels.view(np.float32).reshape(H, W, 4))
+    cur = rng.uniform(0, 0.5, (H, W)).astype(np.float32)
+    prop = rng.uniform(0, 0.5, (H, W)).astype(np.float32)
+    g = lgc.GraphCut(pr.e.imL, pr.e.imR, lambda_=lambda_, th_smooth=1.0, omega=10.0, epsilon=0.01)
+    worst_cells = 0
+    for mode, si in ((0, set_index), (1, 0), (0, len(layer.sets) - 1)):
+        cells = layer.sets[si]
+        regions = np.ascontiguousarray(layer.shared[cells])
+        planes = random_planes(len(cells), D, H, W, seed + si, slant=0.05)
+        g.labels[mode][...] = lab4
+        g.costs[mode][...] = cur
+        batch = api.Batch(pr.e, layer.filter[cells], regions)
+        off = batch.graph_offsets()
+        nn = batch.graph_nodes()
+        assert nn == int(sum(int(r["w"]) * int(r["h"]) for r in regions))
+        ref_payload, ref_flow0 = g.build_graphs(regions, planes, prop, off, mode=mode)
+        bufs = dict(planes=api.DeviceBuffer(pr.e, max(1, len(cells)) * 16), labels=api.DeviceBuffer(pr.e, H * W * 16),
+                    cur=api.DeviceBuffer(pr.e, H * W * 4), prop=api.DeviceBuffer(pr.e, H * W * 4), payload=api.DeviceBuffer(pr.e, nn * 20))
+        bufs["planes"].upload(api._planes(planes).view(np.float32)); bufs["labels"].upload(lab4); bufs["cur"].upload(cur); bufs["prop"].upload(prop)
+        flow0 = batch.expansion_graph(bufs["planes"].ptr, bufs["labels"].ptr, bufs["cur"].ptr, bufs["prop"].ptr, bufs["payload"].ptr, mode=mode,
+                                      lambda_=lambda_, th_smooth=1.0, omega=10.0, epsilon=0.01, want_flow0=True)
+        pr.e.synchronize()
+        got = bufs["payload"].download((nn * 5,), np.float32)
+        diff = got.view(np.uint32) != ref_payload.view(np.uint32)
+        assert not diff.any(), f"graph payload differs in {int(diff.sum())} of {diff.size} values (mode {mode}, set {si})"
+        assert np.allclose(flow0, ref_flow0, rtol=1e-12, atol=1e-9)
+        assert (got.reshape(-1, 5)[:, 1:] > 0).mean() > 0.2            # the instance has real pairwise structure
+        # moves on device-built graphs == moves with the host construction
+        flows = g.expansion_moves_prebuilt(regions, planes, prop, got, off, flow0=flow0, mode=mode)
+        lab_dev, cost_dev = g.labels[mode].copy(), g.costs[mode].copy()
+        g.labels[mode][...] = lab4
+        g.costs[mode][...] = cur
+        gap = g.expansion_moves(regions, planes, prop, mode=mode, check=True)
+        assert gap <= 1e-5
+        assert np.array_equal(lab_dev.view(np.uint32), g.labels[mode].view(np.uint32)) and np.array_equal(cost_dev, g.costs[mode])
+        assert (lab_dev.view(np.uint32) != lab4.view(np.uint32)).any() and (flows > 0).all()
+        worst_cells = max(worst_cells, len(cells))
+        batch.destroy()
+        for b in bufs.values():
+            b.free()
+    g.close()
+    return worst_cells

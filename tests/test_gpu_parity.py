@@ -183,6 +183,11 @@ def test_gpu_volume_preparation(cones):
     pc.case_volume_preparation(cones, None)
 
 
+def test_gpu_expansion_graph_on_device(cones, mid):
+    pc.case_expansion_graph(cones)
+    pc.case_expansion_graph(mid, unit=25, set_index=3, seed=43)
+
+
 def test_gpu_graph_cut_iterations(oracle_mod):
     """Local expansion moves end to end: GPU proposals + unary costs, host graph cuts (liblocalexp_host.so)."""
     hist, gap = pc.case_quality_cones_gc(None, "cuda", pm_iters=1, gc_iters=2)

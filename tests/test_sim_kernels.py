@@ -135,6 +135,13 @@ def test_sim_volume_preparation(cones, sim_lib):
     pc.case_volume_preparation(cones, sim_lib)
 
 
+def test_sim_expansion_graph_on_device(cones):
+    """Pairwise terms / graph capacities on the device (N1): bit-identical to the host construction."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    pc.case_expansion_graph(cones)
+
+
 def test_sim_graph_cut_iterations(sim_lib, oracle_mod):
     """PatchMatch + graph-cut iterations through the Python driver: simulator proposals / unary costs, host cuts."""
     from localexpstereo_amd import build
