@@ -146,6 +146,12 @@ int les_hip_batch_expansion_graph(les_hip_ctx* ctx, const les_hip_batch* batch, 
                                   const les_hip_plane* d_labels, const float* d_cur, const float* d_prop, float lambda, float th_smooth,
                                   float omega, float epsilon, float* d_payload, double* flow0_host);
 
+/* replaces: the mask updates after a graph cut -- subProposalCost.copyTo(subCurrentCost, updateMask);
+ * subCurrentLabeling.setTo(label, updateMask) (LES/FastGCStereo.h:61-62) -- for all cells of the batch.  d_masks: one
+ * byte per graph node in the payload order of les_hip_batch_expansion_graph (non-zero = the node takes the proposal). */
+int les_hip_batch_apply_masks(les_hip_ctx* ctx, const les_hip_batch* batch, const les_hip_plane* d_planes, const unsigned char* d_masks,
+                              float* d_cur, const float* d_prop, les_hip_plane* d_labels);
+
 /* replaces: PMStereoBase::doConsistencyCheck (LES/PMStereoBase.h:111-144) -- left-right check of the disparities of two
  * device label maps (H x W planes each): fail = 255 where |d_other(x -/+ d) - d| > threshold, 128 where the pixel maps
  * outside the other view, 0 otherwise.  d_failL / d_failR: H x W bytes on the device. */

@@ -54,6 +54,12 @@ int les_gc_expansion_moves_prebuilt(les_gc_ctx* ctx, int mode, int n, const les_
                                     const float* proposal_cost, const float* payload, const long long* offsets, const double* flow0,
                                     int nthreads, double* flows);
 
+/* Stateless form for device-resident solutions: max-flow + segment readout only.  masks: one byte per graph node in
+ * payload order (255 = the node takes the proposal, LES/FastGCStereo.h:555-559); the caller applies them on the device
+ * (les_hip_batch_apply_masks).  flows (may be NULL): flow through the n-links and residual t-links of every cell. */
+int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* payload, const long long* offsets, int nthreads,
+                          unsigned char* masks, double* flows);
+
 /* Host construction of the same payload from the context's current solution (the code path of
  * les_gc_expansion_moves up to the max-flow): the parity reference of the device construction. */
 int les_gc_build_graphs(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,

@@ -543,6 +543,20 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
     return LES_HIP_OK;
 }
 
+int les_hip_batch_apply_masks(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plane* d_planes, const unsigned char* d_masks, float* d_cur,
+                              const float* d_prop, les_hip_plane* d_labels)
+{
+    if (!c || !b || !d_planes || !d_masks || !d_cur || !d_prop || !d_labels) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (b->n == 0) return LES_HIP_OK;
+    const les::GraphCell* cells = reinterpret_cast<const les::GraphCell*>(b->d_targets);
+    const long long* offs = b->d_graph_off;
+    const float4* pl = reinterpret_cast<const float4*>(d_planes);
+    float4* lab = reinterpret_cast<float4*>(d_labels);
+    hipLaunchKernelGGL(les::les_apply_masks_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, cells, offs, pl, d_masks, d_cur, d_prop, lab, c->p.W);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
 int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const les_hip_plane* planes, int planes_on_device,
                       float* out_dev, int check)
 {

@@ -144,4 +144,22 @@ __global__ void les_expansion_graph_kernel(const GraphCell* __restrict__ cells, 
     if (threadIdx.x == 0) flow0[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = s_red[0];
 }
 
+// subProposalCost.copyTo(subCurrentCost, updateMask); subCurrentLabeling.setTo(label, updateMask)  (LES/FastGCStereo.h:61-62)
+// with the masks of a lock-step in graph-node order (cell i at offsets[i], row-major over its region).  grid = (cells, chunks)
+__global__ void les_apply_masks_kernel(const GraphCell* __restrict__ cells, const long long* __restrict__ offsets, const float4* __restrict__ planes,
+                                       const uint8_t* __restrict__ masks, float* __restrict__ cur, const float* __restrict__ prop,
+                                       float4* __restrict__ labels, int W)
+{
+    const GraphCell c = cells[blockIdx.x];
+    const float4 pl = planes[blockIdx.x];
+    const uint8_t* m = masks + offsets[blockIdx.x];
+    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < c.w * c.h; idx += (int)(blockDim.x * gridDim.y)) {
+        if (!m[idx]) continue;
+        const int y = idx / c.w, x = idx - y * c.w;
+        const size_t px = (size_t)(c.y + y) * W + c.x + x;
+        cur[px] = prop[px];
+        labels[px] = pl;
+    }
+}
+
 }  // namespace les

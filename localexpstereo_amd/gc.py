@@ -11,7 +11,7 @@ from . import api
 
 DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "liblocalexp_host.so")
 SYMBOLS = ["les_gc_create", "les_gc_destroy", "les_gc_last_error", "les_gc_labels", "les_gc_costs", "les_gc_expansion_moves",
-           "les_gc_expansion_moves_prebuilt", "les_gc_build_graphs", "les_gc_smoothness_cost", "les_gc_data_cost"]
+           "les_gc_expansion_moves_prebuilt", "les_gc_solve_prebuilt", "les_gc_build_graphs", "les_gc_smoothness_cost", "les_gc_data_cost"]
 _lib = None
 
 
@@ -33,6 +33,7 @@ def load(path=None):
         "les_gc_expansion_moves": (ci, [vp, ci, ci, vp, vp, vp, ci, ci, C.POINTER(C.c_double)]),
         "les_gc_expansion_moves_prebuilt": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
         "les_gc_build_graphs": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp]),
+        "les_gc_solve_prebuilt": (ci, [ci, vp, vp, vp, ci, vp, vp]),
         "les_gc_smoothness_cost": (C.c_double, [vp, ci]),
         "les_gc_data_cost": (C.c_double, [vp, ci]),
     }
@@ -41,6 +42,16 @@ def load(path=None):
         f.restype, f.argtypes = res, args
     _lib = L
     return L
+
+
+def solve_prebuilt(regions, payload, offsets, masks_out, nthreads=0, lib=None):
+    """Max-flow + segment readout of one lock-step of device-built graphs (stateless): fills masks_out (uint8, node order)."""
+    L = load(lib)
+    regions = api._rects(regions)
+    assert payload.dtype == np.float32 and payload.flags.c_contiguous and masks_out.dtype == np.uint8 and masks_out.flags.c_contiguous
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    if L.les_gc_solve_prebuilt(len(regions), api._ptr(regions), api._ptr(payload), api._ptr(offsets), nthreads, api._ptr(masks_out), None):
+        raise RuntimeError(L.les_gc_last_error().decode())
 
 
 class GraphCut:

@@ -242,10 +242,14 @@ public:
             CostMap proposalCost(height, width);
             std::vector<les_hip_plane> hplanes;
             std::vector<float> payload;
+            std::vector<uint8_t> masks;
             std::vector<long long> goff;
             float* d_payload = nullptr;
+            unsigned char* d_masks = nullptr;
             long long payload_cap = 0;
-            if (maxIteration > 0 && ok) chk(les_hip_memcpy_h2d(ctx, d_cur, currentCost_[mode].data.data(), P * sizeof(float)));
+            // deviceGraph: the solution stays on the GPU; the host receives the ready-made graphs and returns one mask byte
+            // per node.  Otherwise (or with the self-check on): host-resident solution and host graph construction.
+            const bool devGraph = deviceGraph && !checkFlowEnergy;
             for (int iteration = 0; iteration < maxIteration && ok; iteration++)
                 for (size_t li = 0; li < batches.size(); li++)
                     for (SetBatch& sb : batches[li])
@@ -256,53 +260,65 @@ public:
                                 const auto tA = std::chrono::steady_clock::now();
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
-                                // pairwise terms / graph capacities on the device unless the self-check wants the host construction
-                                const bool devGraph = deviceGraph && !checkFlowEnergy;
-                                const long long nodes = les_hip_batch_graph_nodes(sb.b);
+                                const auto& L = layermng.layers[li];
+                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : omp_get_max_threads() / 2));
+                                std::chrono::steady_clock::time_point tB, tC;
                                 if (devGraph) {
-                                    if (nodes * 5 > payload_cap) {
+                                    const long long nodes = les_hip_batch_graph_nodes(sb.b);
+                                    if (nodes > payload_cap) {
                                         if (d_payload) les_hip_free(ctx, d_payload);
-                                        d_payload = nullptr;
-                                        payload_cap = nodes * 5;
-                                        chk(les_hip_malloc(ctx, (void**)&d_payload, (size_t)payload_cap * sizeof(float)));
+                                        if (d_masks) les_hip_free(ctx, d_masks);
+                                        d_payload = nullptr; d_masks = nullptr;
+                                        payload_cap = nodes;
+                                        chk(les_hip_malloc(ctx, (void**)&d_payload, (size_t)nodes * 5 * sizeof(float)));
+                                        chk(les_hip_malloc(ctx, (void**)&d_masks, (size_t)nodes));
                                     }
                                     chk(les_hip_batch_expansion_graph(ctx, sb.b, mode, sb.planes, d_labels, d_cur, d_prop, params.lambda, params.th_smooth,
                                                                       params.omega, params.epsilon, d_payload, nullptr));
                                     payload.resize((size_t)nodes * 5);
+                                    masks.resize((size_t)nodes);
                                     goff.resize((size_t)sb.n);
                                     chk(les_hip_batch_graph_offsets(sb.b, goff.data()));
                                     if (ok) chk(les_hip_memcpy_d2h(ctx, payload.data(), d_payload, (size_t)nodes * 5 * sizeof(float)));
-                                }
-                                hplanes.resize(sb.n);
-                                chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
-                                chk(les_hip_memcpy_d2h(ctx, proposalCost.data.data(), d_prop, P * sizeof(float)));
-                                if (!ok) break;
-                                const auto tB = std::chrono::steady_clock::now();
-                                const auto& L = layermng.layers[li];
-                                // no more threads than cells: a team of every core for a handful of cells costs far more in
-                                // fork/join than the cuts themselves
-                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : omp_get_max_threads() / 2));
+                                    if (!ok) break;
+                                    tB = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-                                for (int n = 0; n < sb.n; n++) {
-                                    const les_hip_plane& hp = hplanes[n];
-                                    const Plane label(hp.a, hp.b, hp.c, hp.v);
-                                    const Rect& region = L.sharedRegions[sb.cells[n]];
-                                    if (devGraph) {
+                                    for (int n = 0; n < sb.n; n++) {
+                                        const Rect& region = L.sharedRegions[sb.cells[n]];
                                         std::vector<uint8_t> mask;
                                         expansionMovePrebuilt(payload.data() + 5 * goff[n], 0.0, region, mask);
-                                        applyMask(label, region, proposalCost, mask, mode);
-                                    } else fuseProposal(label, region, proposalCost, mode, true);
+                                        std::copy(mask.begin(), mask.end(), masks.begin() + goff[n]);
+                                    }
+                                    tC = std::chrono::steady_clock::now();
+                                    chk(les_hip_memcpy_h2d(ctx, d_masks, masks.data(), (size_t)nodes));
+                                    chk(les_hip_batch_apply_masks(ctx, sb.b, sb.planes, d_masks, d_cur, d_prop, d_labels));
+                                } else {
+                                    hplanes.resize(sb.n);
+                                    chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
+                                    chk(les_hip_memcpy_d2h(ctx, proposalCost.data.data(), d_prop, P * sizeof(float)));
+                                    if (!ok) break;
+                                    tB = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+                                    for (int n = 0; n < sb.n; n++) {
+                                        const les_hip_plane& hp = hplanes[n];
+                                        fuseProposal(Plane(hp.a, hp.b, hp.c, hp.v), L.sharedRegions[sb.cells[n]], proposalCost, mode, true);
+                                    }
+                                    tC = std::chrono::steady_clock::now();
+                                    chk(les_hip_memcpy_h2d(ctx, d_labels, currentLabeling_[mode].data.data(), P * sizeof(les_hip_plane)));
                                 }
-                                const auto tC = std::chrono::steady_clock::now();
-                                chk(les_hip_memcpy_h2d(ctx, d_labels, currentLabeling_[mode].data.data(), P * sizeof(les_hip_plane)));
-                                if (deviceGraph) chk(les_hip_memcpy_h2d(ctx, d_cur, currentCost_[mode].data.data(), P * sizeof(float)));
                                 const auto tD = std::chrono::steady_clock::now();
                                 gcSeconds[0] += std::chrono::duration<double>(tB - tA).count();
                                 gcSeconds[1] += std::chrono::duration<double>(tC - tB).count();
                                 gcSeconds[2] += std::chrono::duration<double>(tD - tC).count();
                                 gcLockSteps++;
                             }
+            if (devGraph && maxIteration > 0 && ok) {
+                chk(les_hip_synchronize(ctx));
+                chk(les_hip_memcpy_d2h(ctx, currentLabeling_[mode].data.data(), d_labels, P * sizeof(les_hip_plane)));
+                chk(les_hip_memcpy_d2h(ctx, currentCost_[mode].data.data(), d_cur, P * sizeof(float)));
+            }
             if (d_payload) les_hip_free(ctx, d_payload);
+            if (d_masks) les_hip_free(ctx, d_masks);
         }
         // two-view runs end with the left-right post-processing (LES/FastGCStereo.h:199-203)
         if (ok && viewModes.size() == 2) ok = postProcess(1.5f);

@@ -136,6 +136,24 @@ int les_gc_expansion_moves_prebuilt(les_gc_ctx* c, int mode, int n, const les_hi
     return 0;
 }
 
+int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* payload, const long long* offsets, int nthreads, unsigned char* masks,
+                          double* flows)
+{
+    if (n < 0 || (n > 0 && (!regions || !payload || !offsets || !masks))) return fail("les_gc_solve_prebuilt: bad argument");
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    nthreads = std::max(1, std::min(nthreads, n));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int i = 0; i < n; i++) {
+        const Rect region(0, 0, regions[i].w, regions[i].h);
+        if (region.width <= 0 || region.height <= 0) continue;
+        std::vector<uint8_t> mask;
+        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, mask);
+        if (flows) flows[i] = flow;
+        std::copy(mask.begin(), mask.end(), masks + offsets[i]);
+    }
+    return 0;
+}
+
 int les_gc_build_graphs(les_gc_ctx* c, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes, const float* proposal_cost,
                         const long long* offsets, float* payload, double* flow0)
 {

@@ -163,23 +163,44 @@ class PMRunner:
     # the local expansion moves of the rank's own cells on the host cores (gc.GraphCut), and the fused labels go
     # back to the device for the next proposals.  Cross-rank coherence is the same per-set all-gather.
     def begin_gc(self, graph_cut, mode=None, device_graph=True):
-        """device_graph: the pairwise terms / graph capacities of every move are computed on the GPU
-        (les_hip_batch_expansion_graph) and the host only runs the max-flows; False = host construction."""
+        """device_graph (default): the solution stays on the GPU -- pairwise terms / graph capacities of every move are
+        computed there (les_hip_batch_expansion_graph), the host receives only the graphs, runs the max-flows and
+        returns one mask byte per node, which the GPU applies (les_hip_batch_apply_masks).  False (or check=True in
+        gc_iteration) = the reference's shape: host-resident solution, host graph construction."""
         self.gc = graph_cut
         self.device_graph = device_graph
-        m = self.mode if mode is None else mode
-        self._sync()
-        self.gc.labels[m][...] = self.labels.cpu().numpy()
-        self.gc.costs[m][...] = self.cur.cpu().numpy()
-        self._prop_host = torch.empty((self.H, self.W), dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.empty((self.H, self.W))
+        self._gc_mode = self.mode if mode is None else mode
+        self.sync_gc_state()
+        pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+        self._prop_host = pin(torch.empty((self.H, self.W), dtype=torch.float32))
         self.gc_max_gap = 0.0
         self.gc_seconds = {"device": 0.0, "host_cuts": 0.0, "h2d": 0.0}
 
+    def sync_gc_state(self):
+        """Copy the device solution into the host graph-cut context (for its energy queries / the host-construction path)."""
+        m = self._gc_mode
+        self._sync()
+        self.gc.labels[m][...] = self.labels.cpu().numpy()
+        self.gc.costs[m][...] = self.cur.cpu().numpy()
+
+    def _gc_buffers(self, sh):
+        if sh.payload is None:
+            pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+            n = max(1, sh.graph_nodes)
+            sh.payload = torch.empty(n * 5, dtype=torch.float32, device=self.device)
+            sh.payload_host = pin(torch.empty(n * 5, dtype=torch.float32))
+            sh.masks = torch.empty(n, dtype=torch.uint8, device=self.device)
+            sh.masks_host = pin(torch.zeros(n, dtype=torch.uint8))
+
     def gc_iteration(self, iteration, check=False, nthreads=0):
         import time
+        from . import gc as lgc
         gc, m = self.gc, self.mode
-        lab_host = torch.from_numpy(gc.labels[m])
-        cur_host = torch.from_numpy(gc.costs[m])
+        host_path = check or not self.device_graph
+        if host_path:
+            self.sync_gc_state()
+            lab_host = torch.from_numpy(gc.labels[m])
+            cur_host = torch.from_numpy(gc.costs[m])
         for li, layer in enumerate(self.shards):
             for sh in layer:
                 if sh.n:
@@ -191,42 +212,40 @@ class PMRunner:
                             t0 = time.perf_counter()
                             sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=mm)
                             sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=m, check=True, planes_on_device=True)
-                            use_dev = self.device_graph and not check
-                            if use_dev:
-                                if sh.payload is None:
-                                    sh.payload = torch.empty(max(1, sh.graph_nodes * 5), dtype=torch.float32, device=self.device)
-                                    sh.payload_host = torch.empty(max(1, sh.graph_nodes * 5), dtype=torch.float32)
-                                    if self.device.type == "cuda":
-                                        sh.payload_host = sh.payload_host.pin_memory()
-                                sh.batch.expansion_graph(sh.planes.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(),
-                                                         sh.payload.data_ptr(), mode=m, lambda_=gc.params["lambda_"], th_smooth=gc.params["th_smooth"],
-                                                         omega=gc.params["omega"], epsilon=gc.params["epsilon"])
-                            self._sync()
-                            self._prop_host.copy_(self.prop)
-                            if use_dev:
-                                sh.payload_host.copy_(sh.payload)
-                            planes = sh.planes[: sh.n].cpu().numpy()
-                            t1 = time.perf_counter()
-                            if use_dev:
-                                gc.expansion_moves_prebuilt(sh.regions, planes, self._prop_host.numpy(), sh.payload_host.numpy(), sh.graph_off, mode=m,
-                                                            nthreads=nthreads)
-                            else:
+                            if host_path:
+                                self._sync()
+                                self._prop_host.copy_(self.prop)
+                                planes = sh.planes[: sh.n].cpu().numpy()
+                                t1 = time.perf_counter()
                                 gap = gc.expansion_moves(sh.regions, planes, self._prop_host.numpy(), mode=m, nthreads=nthreads, check=check)
                                 self.gc_max_gap = max(self.gc_max_gap, gap)
-                            t2 = time.perf_counter()
-                            self.labels.copy_(lab_host)
-                            if self.device_graph:
-                                self.cur.copy_(cur_host)              # the device t-links read the current costs
+                                t2 = time.perf_counter()
+                                self.labels.copy_(lab_host)
+                                self.cur.copy_(cur_host)
+                            else:
+                                self._gc_buffers(sh)
+                                p = gc.params
+                                sh.batch.expansion_graph(sh.planes.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(),
+                                                         sh.payload.data_ptr(), mode=m, lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"],
+                                                         epsilon=p["epsilon"])
+                                self._sync()
+                                sh.payload_host.copy_(sh.payload)
+                                t1 = time.perf_counter()
+                                lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
+                                t2 = time.perf_counter()
+                                sh.masks.copy_(sh.masks_host)
+                                sh.batch.apply_masks(sh.planes.data_ptr(), sh.masks.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
                             t3 = time.perf_counter()
                             self.gc_seconds["device"] += t1 - t0
                             self.gc_seconds["host_cuts"] += t2 - t1
                             self.gc_seconds["h2d"] += t3 - t2
                 if self.world > 1:
-                    self.cur.copy_(cur_host)
+                    self._sync()
                     self._exchange(sh)
-                    lab_host.copy_(self.labels)
-                    cur_host.copy_(self.cur)
-        self.cur.copy_(cur_host)
+                    if host_path:
+                        lab_host.copy_(self.labels)
+                        cur_host.copy_(self.cur)
+        self._sync()
 
     def run(self, pm_iterations, iterations=0, graph_cut=None):
         """FastGCStereo::run for one view (LES/FastGCStereo.h:133-199): init, pmInit winner-take-all iterations, then
@@ -238,6 +257,7 @@ class PMRunner:
             self.begin_gc(graph_cut)
             for it in range(iterations):
                 self.gc_iteration(it)
+            self.sync_gc_state()
         return self.labels, self.cur
 
     def disparities(self):

@@ -16,14 +16,14 @@ PARAMS_GF = dict(lambda_=1.0, windR=20, eps=1e-4, alpha=0.9, omega=10.0, th_grad
 
 
 class FastGCStereo:
-    def __init__(self, energy, imL, imR, params, device="cuda", rank=0, world=1, seed=1):
+    def __init__(self, energy, imL, imR, params, device="cuda", rank=0, world=1, seed=1, host_threads=0):
         self.e, self.imL, self.imR, self.p = energy, imL, imR, dict(PARAMS_GF, **params)
         self.device, self.rank, self.world, self.seed = device, rank, world, seed
         self.units, self.table = [], []
         self.evaluator = None
         self.log = []
         self.check_flow_energy = False
-        self.host_threads = 0
+        self.host_threads = host_threads         # threads of the host max-flows (0: one per cell up to the core count)
 
     def addLayer(self, unit_region_size, proposers):
         """proposers: list of (kind, K) with kind in api.PROPOSE_EXPANSION / _RANDOM / _RANSAC (LES/FastGCStereo.h:88-92)."""
@@ -38,6 +38,7 @@ class FastGCStereo:
             return
         disp = runner.disparities().cpu().numpy()
         if g is not None and getattr(runner, "gc", None) is g:
+            runner.sync_gc_state()
             dc, sc = g.data_cost(mode), g.smoothness_cost(mode)
         else:
             dc, sc = float(runner.cur.sum(dtype=torch.float64)), float("nan")

@@ -732,8 +732,9 @@ def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25)
     hist = [(bad(1.0), g.data_cost(0), g.smoothness_cost(0))]
     for it in range(gc_iters):
         r.gc_iteration(it, check=(it == 0))          # later iterations: graph capacities computed on the device
+        r.sync_gc_state()
         hist.append((bad(1.0), g.data_cost(0), g.smoothness_cost(0)))
-        assert np.array_equal(r.labels.cpu().numpy(), g.labels[0])            # device and host solutions stay identical
+        assert np.array_equal(r.labels.cpu().numpy(), g.labels[0])
     gap = r.gc_max_gap
     r.close(); e.close(); g.close()
     assert gap <= 1e-5, gap
@@ -819,6 +820,16 @@ def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
         assert gap <= 1e-5
         assert np.array_equal(lab_dev.view(np.uint32), g.labels[mode].view(np.uint32)) and np.array_equal(cost_dev, g.costs[mode])
         assert (lab_dev.view(np.uint32) != lab4.view(np.uint32)).any() and (flows > 0).all()
+        # device-resident form: stateless host solve -> masks -> applied on the device
+        masks = np.zeros(nn, np.uint8)
+        lgc.solve_prebuilt(regions, got, off, masks)
+        mbuf = api.DeviceBuffer(pr.e, max(1, nn))
+        mbuf.upload(masks)
+        batch.apply_masks(bufs["planes"].ptr, mbuf.ptr, bufs["cur"].ptr, bufs["prop"].ptr, bufs["labels"].ptr)
+        pr.e.synchronize()
+        assert np.array_equal(bufs["labels"].download((H, W, 4), np.float32).view(np.uint32), lab_dev.view(np.uint32))
+        assert np.array_equal(bufs["cur"].download((H, W), np.float32), cost_dev)
+        mbuf.free()
         worst_cells = max(worst_cells, len(cells))
         batch.destroy()
         for b in bufs.values():

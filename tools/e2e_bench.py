@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""End-to-end run at the Adirondack-H shape (BASELINE configs[1]/[3] substitute, SURVEY.md 8(d) "End-to-end").
+
+The Adirondack data set (1.2 GB, MC-CNN volumes) is not in the container, so a synthetic scene of the same shape is
+used: piecewise-planar ground-truth disparity, textured left image, right image = left warped by the ground truth,
+matching-cost volumes = truncated absolute colour differences computed with torch on the GPU (float [ndisp][H][W], the
+.acrt layout).  Then the MidV3 loop of LES/main.cpp:330-420: volume ingest (fillOutOfView / convertVolumeL2R), layers
+1 % / 3 % / 9 % of the width, pmIterations PatchMatch iterations + `iterations` graph-cut iterations, optional two-view
+post-processing, Evaluator rows (bad-1.0).  Prints one JSON object with the wall-clock split.
+
+  python tools/e2e_bench.py [--width 1436 --height 992 --ndisp 256 --iterations 5 --pm-iterations 2 --dual 0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_scene(H, W, D, seed=3):
+    import torch
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    # piecewise planar disparity: background plane + a few slanted quadrilateral "objects"
+    gt = 0.08 * D + 0.00004 * D * xs + 0.00006 * D * ys
+    for _ in range(9):
+        cx, cy = rng.uniform(0.1, 0.9) * W, rng.uniform(0.1, 0.9) * H
+        rw, rh = rng.uniform(0.06, 0.2) * W, rng.uniform(0.08, 0.25) * H
+        m = (np.abs(xs - cx) < rw) & (np.abs(ys - cy) < rh)
+        a, b = rng.uniform(-0.03, 0.03), rng.uniform(-0.03, 0.03)
+        z = rng.uniform(0.25, 0.8) * D + a * (xs - cx) + b * (ys - cy)
+        gt = np.where(m & (z > gt), z, gt)
+    gt = np.clip(gt, 1, D - 2).astype(np.float32)
+    # texture: multi-scale noise, colour
+    tex = np.zeros((H, W, 3), np.float32)
+    for s in (2, 5, 13, 37):
+        n = rng.uniform(0, 1, (H // s + 2, W // s + 2, 3)).astype(np.float32)
+        tex += np.kron(n, np.ones((s, s, 1), np.float32))[:H, :W] / 4
+    imL = np.clip(tex * 255, 0, 255).astype(np.uint8)
+    # right view by forward warping (nearest, z-buffered by processing small disparities first), holes filled from the left
+    imR = np.zeros_like(imL)
+    filled = np.zeros((H, W), bool)
+    order = np.argsort(gt, axis=None)
+    yy, xx = np.unravel_index(order, gt.shape)
+    xr = np.rint(xx - gt[yy, xx]).astype(int)
+    ok = (xr >= 0) & (xr < W)
+    imR[yy[ok], xr[ok]] = imL[yy[ok], xx[ok]]
+    filled[yy[ok], xr[ok]] = True
+    for y in range(H):                                    # horizontal hole filling
+        row = filled[y]
+        if not row.all():
+            idx = np.where(row, np.arange(W), -1)
+            np.maximum.accumulate(idx, out=idx)
+            idx[idx < 0] = np.argmax(row)
+            imR[y] = imR[y, idx]
+    return imL, imR, gt
+
+
+def ad_volume(imL, imR, D, device):
+    """vol[d][y][x] = min(1, mean_c |L(y,x,c) - R(y,x-d,c)| / 64): a stand-in for the MC-CNN matching cost in [0,1]."""
+    import torch
+    L = torch.from_numpy(imL).to(device).float()
+    R = torch.from_numpy(imR).to(device).float()
+    H, W = L.shape[:2]
+    vol = torch.empty((D, H, W), device=device, dtype=torch.float32)
+    for d in range(D):
+        Rs = torch.roll(R, shifts=d, dims=1)
+        vol[d] = ((L - Rs).abs().mean(dim=2) / 64.0).clamp_(max=1.0)
+    return vol
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1436)
+    ap.add_argument("--height", type=int, default=992)
+    ap.add_argument("--ndisp", type=int, default=256)
+    ap.add_argument("--iterations", type=int, default=5)
+    ap.add_argument("--pm-iterations", type=int, default=2)
+    ap.add_argument("--dual", type=int, default=0)
+    ap.add_argument("--smooth-weight", type=float, default=0.5)
+    ap.add_argument("--host-threads", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    from localexpstereo_amd import io as lio
+    from localexpstereo_amd import stereo
+    dev = "cuda"
+    H, W, D = args.height, args.width, args.ndisp
+    t0 = time.perf_counter()
+    imL, imR, gt = make_scene(H, W, D)
+    volL = ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
+    t_scene = time.perf_counter() - t0
+    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    t1 = time.perf_counter()
+    st, lab, raw = stereo.MidV3(data, volL, None, iterations=args.iterations, pmIterations=args.pm_iterations, doDual=bool(args.dual),
+                                smooth_weight=args.smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=args.host_threads)
+    t_total = time.perf_counter() - t1
+    rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
+    out = dict(shape=[W, H, D], iterations=args.iterations, pm_iterations=args.pm_iterations, dual=bool(args.dual), host_cores=os.cpu_count(),
+               seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), scene_seconds=round(t_scene, 2),
+               gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, log=rows)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
