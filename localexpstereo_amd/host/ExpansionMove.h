@@ -84,13 +84,24 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
 
 // The same move on a graph whose capacities were computed on the device (5 floats per node, row-major over the region;
 // include/localexp_hip.h: les_hip_batch_expansion_graph).
+// mask: region.width * region.height bytes (255 = take the proposal).  The solver object is reused per thread.
+inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, uint8_t* mask)
+{
+    static thread_local GridMaxFlow graph;
+    const int w = region.width, h = region.height;
+    graph.reset(w, h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
+    graph.set_base_flow(base_flow);
+    const double flow = graph.maxflow();
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
+    return flow;
+}
 inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, std::vector<uint8_t>& updateMask)
 {
-    GridMaxFlow graph(region.width, region.height);
-    for (int y = 0; y < region.height; y++)
-        for (int x = 0; x < region.width; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * region.width + x));
-    graph.set_base_flow(base_flow);
-    return solveExpansionGraph(graph, region, updateMask);
+    updateMask.resize((size_t)region.width * region.height);
+    return expansionMovePrebuilt(payload, base_flow, region, updateMask.data());
 }
 
 // The reference's (disabled) self-check of the graph construction, LES/FastGCStereo.h:561-594: the flow equals the

@@ -11,6 +11,7 @@
 // Graph<float,float,double>.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <limits>
 #include <vector>
@@ -23,10 +24,23 @@ public:
     // arc directions; sister(k) == k ^ 1
     enum { E = 0, W = 1, S = 2, N = 3, SW = 4, NE = 5, SE = 6, NW = 7 };
 
-    GridMaxFlow(int w, int h) : w_(w), h_(h), pw_(w + 2), flow_(0), nodes_((size_t)(w + 2) * (h + 2))
+    GridMaxFlow() : w_(0), h_(0), pw_(2), flow_(0) {}
+    GridMaxFlow(int w, int h) : GridMaxFlow() { reset(w, h); }
+    // (re)initialise for a w x h grid; the node storage is reused, so a thread that solves many small graphs (one per
+    // cell and proposal) does not go through the allocator for each of them
+    void reset(int w, int h)
     {
+        w_ = w; h_ = h; pw_ = w + 2;
+        const size_t n = (size_t)(w + 2) * (h + 2);
+        if (nodes_.size() < n) nodes_.resize(n);
+        std::fill(nodes_.begin(), nodes_.begin() + n, Node());
         const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
         for (int k = 0; k < 8; k++) off_[k] = o[k];
+        flow_ = 0;
+        time_ = 0;
+        orphans_.clear();
+        orphan_head_ = 0;
+        queue_first_[0] = queue_first_[1] = queue_last_[0] = queue_last_[1] = NONE_NODE;
     }
     int id(int x, int y) const { return (y + 1) * pw_ + (x + 1); }
 
@@ -137,7 +151,7 @@ private:
         uint8_t is_sink = 0;
     };
 
-    const int w_, h_, pw_;
+    int w_, h_, pw_;
     int off_[8];
     double flow_;
     std::vector<Node> nodes_;

@@ -25,6 +25,15 @@ int fail(const char* fmt, ...)
     return 1;
 }
 
+// Team size of a lock-step.  The cuts of one lock-step are small (tens of microseconds for a layer-0 cell), so a team of
+// every hardware thread costs more in fork/join, wake-ups and cache traffic than it buys: measured on a 2 x 64-core
+// EPYC 9575F (1436 x 992, 5 graph-cut iterations) 16 threads 0.8 s / iteration, 64 threads 1.2 s, 256 threads 1.8 s.
+int defaultThreads(int requested, int n)
+{
+    if (requested <= 0) requested = std::min(16, omp_get_max_threads());
+    return std::max(1, std::min(requested, n));
+}
+
 // the pairwise half of StereoEnergy; the unary operator lives on the GPU and is never called through this object
 class PairwiseEnergy : public StereoEnergy {
 public:
@@ -76,8 +85,7 @@ int les_gc_expansion_moves(les_gc_ctx* c, int mode, int n, const les_hip_rect* r
         const les_hip_rect& r = regions[i];
         if (r.w < 0 || r.h < 0 || r.x < 0 || r.y < 0 || r.x + r.w > c->W || r.y + r.h > c->H) return fail("les_gc_expansion_moves: region %d outside the image", i);
     }
-    if (nthreads <= 0) nthreads = omp_get_max_threads();
-    nthreads = std::max(1, std::min(nthreads, n));
+    nthreads = defaultThreads(nthreads, n);
     LabelMap& lab = c->labels[mode];
     CostMap& cur = c->costs[mode];
     const CostView prop(proposal_cost, c->W);
@@ -113,8 +121,7 @@ int les_gc_expansion_moves_prebuilt(les_gc_ctx* c, int mode, int n, const les_hi
         const les_hip_rect& r = regions[i];
         if (r.w < 0 || r.h < 0 || r.x < 0 || r.y < 0 || r.x + r.w > c->W || r.y + r.h > c->H) return fail("les_gc_expansion_moves_prebuilt: region %d outside the image", i);
     }
-    if (nthreads <= 0) nthreads = omp_get_max_threads();
-    nthreads = std::max(1, std::min(nthreads, n));
+    nthreads = defaultThreads(nthreads, n);
     LabelMap& lab = c->labels[mode];
     CostMap& cur = c->costs[mode];
     const CostView prop(proposal_cost, c->W);
@@ -140,16 +147,13 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
                           double* flows)
 {
     if (n < 0 || (n > 0 && (!regions || !payload || !offsets || !masks))) return fail("les_gc_solve_prebuilt: bad argument");
-    if (nthreads <= 0) nthreads = omp_get_max_threads();
-    nthreads = std::max(1, std::min(nthreads, n));
+    nthreads = defaultThreads(nthreads, n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int i = 0; i < n; i++) {
         const Rect region(0, 0, regions[i].w, regions[i].h);
         if (region.width <= 0 || region.height <= 0) continue;
-        std::vector<uint8_t> mask;
-        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, mask);
+        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, masks + offsets[i]);
         if (flows) flows[i] = flow;
-        std::copy(mask.begin(), mask.end(), masks + offsets[i]);
     }
     return 0;
 }

@@ -175,6 +175,7 @@ class PMRunner:
         self._prop_host = pin(torch.empty((self.H, self.W), dtype=torch.float32))
         self.gc_max_gap = 0.0
         self.gc_seconds = {"device": 0.0, "host_cuts": 0.0, "h2d": 0.0}
+        self.gc_seconds.update({f"host_cuts_layer{li}": 0.0 for li in range(len(self.shards))})
 
     def sync_gc_state(self):
         """Copy the device solution into the host graph-cut context (for its energy queries / the host-construction path)."""
@@ -184,13 +185,19 @@ class PMRunner:
         self.gc.costs[m][...] = self.cur.cpu().numpy()
 
     def _gc_buffers(self, sh):
-        if sh.payload is None:
+        """Views of the runner-wide graph / mask staging buffers (one device + one pinned host allocation, sized for the
+        largest lock-step) cut to this shard's node count."""
+        if getattr(self, "_gc_payload", None) is None:
             pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+            n = max([1] + [s.graph_nodes for layer in self.shards for s in layer])
+            self._gc_payload = torch.empty(n * 5, dtype=torch.float32, device=self.device)
+            self._gc_payload_host = pin(torch.empty(n * 5, dtype=torch.float32))
+            self._gc_masks = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._gc_masks_host = pin(torch.zeros(n, dtype=torch.uint8))
+        if sh.payload is None:
             n = max(1, sh.graph_nodes)
-            sh.payload = torch.empty(n * 5, dtype=torch.float32, device=self.device)
-            sh.payload_host = pin(torch.empty(n * 5, dtype=torch.float32))
-            sh.masks = torch.empty(n, dtype=torch.uint8, device=self.device)
-            sh.masks_host = pin(torch.zeros(n, dtype=torch.uint8))
+            sh.payload, sh.payload_host = self._gc_payload[: n * 5], self._gc_payload_host[: n * 5]
+            sh.masks, sh.masks_host = self._gc_masks[:n], self._gc_masks_host[:n]
 
     def gc_iteration(self, iteration, check=False, nthreads=0):
         import time
@@ -238,6 +245,7 @@ class PMRunner:
                             t3 = time.perf_counter()
                             self.gc_seconds["device"] += t1 - t0
                             self.gc_seconds["host_cuts"] += t2 - t1
+                            self.gc_seconds[f"host_cuts_layer{li}"] += t2 - t1
                             self.gc_seconds["h2d"] += t3 - t2
                 if self.world > 1:
                     self._sync()

@@ -23,7 +23,7 @@ class FastGCStereo:
         self.evaluator = None
         self.log = []
         self.check_flow_energy = False
-        self.host_threads = host_threads         # threads of the host max-flows (0: one per cell up to the core count)
+        self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
 
     def addLayer(self, unit_region_size, proposers):
         """proposers: list of (kind, K) with kind in api.PROPOSE_EXPANSION / _RANDOM / _RANSAC (LES/FastGCStereo.h:88-92)."""
@@ -34,15 +34,25 @@ class FastGCStereo:
         self.evaluator, self.precision = evaluator, precision
 
     def _evaluate(self, index, mode, runner, g, t0):
+        """Evaluator::evaluate (LES/Evaluator.h:113-187).  Like the reference's evaluator, it stops the run's clock while it
+        works (stop() / start() around the body, :115-116,183-184): `time` excludes evaluation."""
         if mode != 0:
             return
+        runner._sync()
+        te = time.perf_counter()
+        try:
+            self._evaluate_body(index, mode, runner, g, t0)
+        finally:
+            self.eval_seconds += time.perf_counter() - te
+
+    def _evaluate_body(self, index, mode, runner, g, t0):
         disp = runner.disparities().cpu().numpy()
         if g is not None and getattr(runner, "gc", None) is g:
             runner.sync_gc_state()
             dc, sc = g.data_cost(mode), g.smoothness_cost(mode)
         else:
             dc, sc = float(runner.cur.sum(dtype=torch.float64)), float("nan")
-        row = dict(index=index, time=time.perf_counter() - t0, energy=dc + (0.0 if sc != sc else sc), data=dc, smooth=sc)
+        row = dict(index=index, time=time.perf_counter() - t0 - self.eval_seconds, energy=dc + (0.0 if sc != sc else sc), data=dc, smooth=sc)
         if self.evaluator is not None:
             d = disp
             if self.precision > 0:                                         # Evaluator::quantize, LES/Evaluator.h:106-111
@@ -54,6 +64,7 @@ class FastGCStereo:
         """FastGCStereo::run (LES/FastGCStereo.h:133-227).  Returns (labeling, rawlabeling) of the left view as
         H x W x 4 float arrays (the raw one is the labelling before the two-view post-processing)."""
         t0 = time.perf_counter()
+        self.eval_seconds = 0.0
         runners = {m: pm.PMRunner(self.e, self.units, self.table, seed=self.seed + 7919 * m, rank=self.rank, world=self.world,
                                   device=self.device, mode=m) for m in viewModes}
         g = gc.GraphCut(self.imL, self.imR, lambda_=self.p["lambda_"], th_smooth=self.p["th_smooth"], omega=self.p["omega"],
@@ -82,7 +93,7 @@ class FastGCStereo:
             self.e.post_process(runners[0].labels.data_ptr(), runners[1].labels.data_ptr(), 1.5, self.p["omega"])     # LES/FastGCStereo.h:202
             self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
         lab = runners[0].labels.cpu().numpy().copy() if 0 in runners else None
-        self.seconds = time.perf_counter() - t0
+        self.seconds = time.perf_counter() - t0 - self.eval_seconds          # the reference's clock: evaluation excluded
         for r in runners.values():
             r.close()
         if g is not None:

@@ -101,7 +101,7 @@ def main():
     t_total = time.perf_counter() - t1
     rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
     out = dict(shape=[W, H, D], iterations=args.iterations, pm_iterations=args.pm_iterations, dual=bool(args.dual), host_cores=os.cpu_count(),
-               seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), scene_seconds=round(t_scene, 2),
+               seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, log=rows)
     print(json.dumps(out))
 
