@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="h1", choices=["h1", "h2"])
+    ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3"])
     ap.add_argument("--height", type=int, default=1000)
     ap.add_argument("--width", type=int, default=1500)
     ap.add_argument("--ndisp", type=int, default=256)
@@ -72,17 +72,42 @@ def main():
         planes = synth.slanted_planes(D, H, W, D - 1, seed=7 + rank)
         bytes_per_eval = 12.0         # two volume taps + write
     d_planes = torch.from_numpy(planes).to(dev)
-    out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
+    out = torch.empty((D, H, W) if args.workload != "h3" else (1, H, W), device=dev, dtype=torch.float32)
 
     e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1,
                                 device=local_rank, volumes_on_device=True, shape=(D, H, W))
     stream = torch.cuda.current_stream(dev)
     e.set_stream(stream.cuda_stream)
-    full = [(0, 0, W, H)] * D
-    batch = api.Batch(e, full, full, out_slabs=True)
+    if args.workload == "h3":
+        # H3: the optimiser's geometry -- LayerManager cells of units 1 % / 3 % / 9 % of the width, one
+        # random plane per cell and proposal slot (9 / 3 / 3 per cell), one launch per disjoint set and slot; the contract
+        # number counts filter-domain pixels x hypotheses
+        from localexpstereo_amd import pm
+        rng = np.random.default_rng(7 + rank)
+        batches, evals = [], 0
+        for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
+            units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
+            for cells in sets:
+                b = api.Batch(e, filt[cells], shared[cells])
+                pl = np.zeros((slots, len(cells), 4), np.float32)
+                pl[..., 0] = rng.uniform(-0.05, 0.05, pl.shape[:2]); pl[..., 1] = rng.uniform(-0.05, 0.05, pl.shape[:2])
+                cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
+                pl[..., 2] = rng.uniform(0.2, 0.8, pl.shape[:2]) * (D - 1) - pl[..., 0] * cx - pl[..., 1] * cy
+                batches.append((b, [torch.from_numpy(pl[k]).to(dev) for k in range(slots)]))
+                evals += slots * int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
+        batch = batches[0][0]
+        evals_per_step_h3 = evals
 
-    def step():
-        batch.run(d_planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
+        def step():
+            for b, pls in batches:
+                for p in pls:
+                    b.run(p.data_ptr(), out.data_ptr(), mode=0, check=True, planes_on_device=True)
+    else:
+        full = [(0, 0, W, H)] * D
+        batch = api.Batch(e, full, full, out_slabs=True)
+
+        def step():
+            batch.run(d_planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -109,9 +134,10 @@ def main():
     elapsed = float(elapsed.item())
     kern_ms = float(kern_ms.item())
 
-    evals_per_step = float(P) * D * world
+    evals_rank = float(evals_per_step_h3) if args.workload == "h3" else float(P) * D
+    evals_per_step = evals_rank * world
     value = evals_per_step * args.steps / elapsed / 1e6
-    alg_bytes = float(P) * D * bytes_per_eval + float(P) * 48.0        # per launch (= per rank per step)
+    alg_bytes = evals_rank * bytes_per_eval + float(P) * 48.0        # per step and rank (H1 / H2: one launch)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate
@@ -140,9 +166,13 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload.upper()}: {D} {'fronto-parallel' if args.workload == 'h1' else 'slanted'} planes x "
-                        f"{W}x{H} image, volume {W}x{H}x{D} f32 U[0,1) per GPU, windR=20 (GF radius 10), eps=1e-4, th_col=0.5",
-            "evals_per_step_per_gpu": P * D,
+            "workload": (f"{args.workload.upper()}: {D} {'fronto-parallel' if args.workload == 'h1' else 'slanted'} planes x "
+                         f"{W}x{H} image, volume {W}x{H}x{D} f32 U[0,1) per GPU, windR=20 (GF radius 10), eps=1e-4, th_col=0.5")
+                        if args.workload != "h3" else
+                        (f"H3: LayerManager cells (units 1/3/9 % of W={W}), 9/3/3 random planes per cell, one launch per disjoint set and "
+                         f"slot ({len(batches) and sum(len(p) for _, p in batches)} launches per step), filter-domain evaluations counted; "
+                         f"volume {W}x{H}x{D} f32 U[0,1)"),
+            "evals_per_step_per_gpu": int(evals_rank),
             "sharding": "hypotheses (disparity slices) split across ranks, no data-path collective",
             "strip_width": e.strip_width(),
             "workgroups_per_launch": batch.num_jobs,
@@ -162,7 +192,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement, double guided filter like the reference default),
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.
-    if rank == 0 and world == 1 and args.cpu_planes != 0:
+    if rank == 0 and world == 1 and args.cpu_planes != 0 and args.workload != "h3":
         from oracle import oracle as om
         cores = os.cpu_count() or 1
         ns = args.cpu_planes if args.cpu_planes > 0 else max(cores, min(D - 1, 4 * cores, 96))
