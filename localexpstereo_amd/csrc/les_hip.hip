@@ -97,6 +97,7 @@ struct ViewData {
     bool own_vol = false;
     float4* stats = nullptr;
     uint32_t* ipk = nullptr;
+    uint32_t* ipk10 = nullptr;           // the guide pixel as signed 10-bit fields (H1 operand format of the strip kernel)
     float4* feat = nullptr;              // NaiveStereoEnergy feature image (image-based matching cost)
 };
 
@@ -210,7 +211,7 @@ int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, c
     if (njobs <= 0) return LES_HIP_OK;
     if (mode < 0 || mode > 1 || !c->v[mode].stats || (c->naive ? !c->v[1 - mode].feat : !c->v[mode].vol))
         return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
-    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
+    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, c->v[mode].ipk10, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
     if (c->naive) { view.feat_self = c->v[mode].feat; view.feat_other = c->v[1 - mode].feat; }
     hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, c->stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
     HIPCHECK(hipGetLastError());
@@ -237,6 +238,7 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     HIPCHECK(hipMalloc((void**)&d_img, P * 3));
     HIPCHECK(hipMemcpy(d_img, im, P * 3, hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc((void**)&v.ipk, P * sizeof(uint32_t)));
+    HIPCHECK(hipMalloc((void**)&v.ipk10, P * sizeof(uint32_t)));
     HIPCHECK(hipMalloc((void**)&v.stats, P * 3 * sizeof(float4)));
     HIPCHECK(hipMalloc((void**)&d_hs, P * 9 * sizeof(double)));
     const int W = c->p.W, H = c->p.H;
@@ -244,7 +246,7 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
         HIPCHECK(hipMalloc((void**)&v.feat, P * sizeof(float4)));
         hipLaunchKernelGGL(les::les_naive_features_kernel, dim3((c->p.W + 255) / 256, c->p.H), dim3(256), 0, c->stream, d_img, v.feat, c->p.H, c->p.W, naive_alpha(c));
     }
-    hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, c->stream, d_img, v.ipk, (int)P);
+    hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, c->stream, d_img, v.ipk, v.ipk10, (int)P);
     hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, v.ipk, d_hs, H, W, c->R);
     hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.stats, H, W, c->R, c->p.eps);
     HIPCHECK(hipGetLastError());
@@ -332,6 +334,7 @@ void les_hip_destroy(les_hip_ctx* c)
         if (c->v[m].own_vol && c->v[m].vol) (void)hipFree(c->v[m].vol);
         if (c->v[m].stats) (void)hipFree(c->v[m].stats);
         if (c->v[m].ipk) (void)hipFree(c->v[m].ipk);
+        if (c->v[m].ipk10) (void)hipFree(c->v[m].ipk10);
         if (c->v[m].feat) (void)hipFree(c->v[m].feat);
     }
     if (c->d_planes) (void)hipFree(c->d_planes);

@@ -46,6 +46,7 @@ struct View {
     const float* vol;          // [D][H][W]   (null for the image-based "naive" matching cost)
     const float4* stats;       // [H*W][3] : {mean_I'_k, inv[k][0], inv[k][1], inv[k][2]}, k = 0..2
     const uint32_t* ipk;       // [H*W] guide pixel packed B | G<<8 | R<<16
+    const uint32_t* ipk10;     // [H*W] the same pixel as three signed 10-bit fields 2u - 255 (bits 10k..10k+9): H1's operand format
     // NaiveStereoEnergy (LES/StereoEnergy.h:629-764): 4-channel feature images {(1-alpha) B, G, R, alpha Gx} of this
     // view and of the other one; the raw cost is computed from them instead of a volume when feat_self != null
     const float4* feat_self;
@@ -181,6 +182,17 @@ __device__ __forceinline__ float guide_centred_f32(uint32_t ipk, int k)
     float w = (float)(2 * u - 255) * (1.0f / 510.0f);
     return k == 3 ? 1.0f : w;
 }
+// the same value from the signed 10-bit field format (one bit-field extract instead of shift / mask / shift / add)
+__device__ __forceinline__ float guide10_centred_f32(uint32_t w10, int k)
+{
+#if defined(LES_SIM)
+    const int v = ((int)(w10 << (22 - 10 * (k < 3 ? k : 0)))) >> 22;
+#else
+    const int v = __builtin_amdgcn_sbfe((int)w10, (unsigned)(10 * k), 10u);
+#endif
+    const float w = (float)v * (1.0f / 510.0f);
+    return k == 3 ? 1.0f : w;
+}
 __device__ __forceinline__ double guide_centred_f64(uint32_t ipk, int k)
 {
     int u = (int)((ipk >> (8 * k)) & 0xffu);
@@ -302,10 +314,14 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     constexpr int TPITCH = Cfg::TPITCH, KS = Cfg::KS, RS = Cfg::RS;
 
     __shared__ float s_p[BY][WP];            // truncated cost p (0 outside the clip); dead after H1 ...
-    __shared__ uint32_t s_ipk[BY][WP];       // packed guide pixel of the same p-rows
+    __shared__ uint32_t s_ipk[BY][WP];       // guide pixel of the same p-rows (signed 10-bit field format)
     __shared__ float s_T[BY][TPITCH];        // H1 sums, then (in place) vertical stage-2 sums
     __shared__ uint32_t s_ipk2[BY][TW];      // packed guide pixel of the output rows of this block
     __shared__ double s_rtab[2 * R + 2];     // 1/n, n = 0..2R+1
+    // per-row scalars of phase V for the current block (written by BY lanes in phase G): without the table every lane
+    // quad re-derives them on the scalar unit -- 27 SALU instructions per row that stall the three resident waves
+    struct RowInfo { double rny; int flags; uint32_t soff; };      // 1/count_y; bit 0: row in clip, bit 1: t >= 2R; stats row offset of row t + PD
+    __shared__ RowInfo s_row[BY];
     float (*s_q)[WP] = s_p;                  // ... so the finished q of the block's output rows reuses it (H2 -> F)
 
     // XCD-aware job order (guide T1): consecutive jobs (same strip, consecutive planes / neighbouring
@@ -368,6 +384,15 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     for (int j = 0; j < PD; j++) pre[j] = stats_row(j);
 
     for (int t0 = 0; t0 < Ttot; t0 += BY) {
+        if (tid < BY) {
+            const int t = t0 + tid;
+            const int gy1 = job.ty0 - 3 * R + t;                       // stage-1 row
+            RowInfo ri;
+            ri.rny = s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+            ri.flags = ((gy1 >= job.cy0 && gy1 < job.cy1) ? 1 : 0) | (t >= 2 * R ? 2 : 0);
+            ri.soff = (uint32_t)min(max(gy1 + PD, job.cy0), job.cy1 - 1) * (uint32_t)(g.W * 3);
+            s_row[tid] = ri;
+        }
         // ===================== G: gather =====================
         // A lane keeps its column for the whole job (column terms hoisted out of the march); the loads of
         // up to GB rows per lane are issued before any is consumed (memory-level parallelism, bounded so
@@ -385,7 +410,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                     const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
                     const NaivePrep np = naive_prepare(g, view.sign, plane.x, plane.y, plane.z, g_sx, sy);
                     const float4 own = view.feat_self[px], fa = view.feat_other[np.ia], fb = view.feat_other[np.ib];
-                    const uint32_t ip = view.ipk[px];
+                    const uint32_t ip = view.ipk10[px];
                     if (g_lane && i < BY) {
                         s_p[i][g_xi] = inside ? naive_finish(view, np, own, fa, fb) : 0.0f;
                         s_ipk[i][g_xi] = ip;
@@ -411,7 +436,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                         gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
                         v0[j] = view.vol[gp[j].i0];
                         v1[j] = view.vol[gp[j].i1];
-                        ipa[j] = view.ipk[px];
+                        ipa[j] = view.ipk10[px];
                     }
 #pragma unroll
                     for (int j = 0; j < JN; j++) {
@@ -448,7 +473,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 #pragma unroll
             for (int s = 0; s < L1 + 2 * R; s++) {
                 const int xi = x0 + s;                                  // p column index
-                const float f = xi < WP ? guide_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi] : 0.0f;
+                const float f = xi < WP ? guide10_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi] : 0.0f;
                 S += (H1ACC)f - (H1ACC)ring[s % KS];
                 ring[s % KS] = f;
                 if (s >= 2 * R && x0 + s - 2 * R < WA) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)S;
@@ -466,12 +491,11 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                 constexpr int BASE = decltype(base_tag)::value;
                 static_for<BY>([&](auto itag) {
                     constexpr int i = decltype(itag)::value;
-                    const int t = t0 + i;
-                    const int gy1 = job.ty0 - 3 * R + t;                // stage-1 row
-                    const bool in_clip = col_in_clip && gy1 >= job.cy0 && gy1 < job.cy1;
-                    const double rn1 = rnx1 * s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
-                    const float o = vl.template step<BASE + i>(trow[i * TPITCH], t >= 2 * R, in_clip, rn1, pre[i % PD]);
-                    pre[i % PD] = stats_row(t + PD);
+                    const RowInfo ri = s_row[i];                        // uniform address: one broadcast 16-byte LDS read
+                    const bool in_clip = col_in_clip && (ri.flags & 1);
+                    const double rn1 = rnx1 * ri.rny;
+                    const float o = vl.template step<BASE + i>(trow[i * TPITCH], (ri.flags & 2) != 0, in_clip, rn1, pre[i % PD]);
+                    pre[i % PD] = st_col[ri.soff];
                     s_T[i][vx * 4 + vk] = o;
                     LES_SCHED_FENCE_V(i);
                 });
@@ -540,10 +564,13 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 // Guide statistics (one-time per view): LES/GuidedFilter.h:58-102 in fp64, stored as fp32 AoS.
 // Pass 1: horizontal 2R+1 sums of the 9 moments (I_c, I_a I_b); pass 2: vertical sums + inverse.
 // ---------------------------------------------------------------------------------------------------
-__global__ void les_pack_guide_kernel(const uint8_t* __restrict__ bgr, uint32_t* __restrict__ ipk, int P)
+__global__ void les_pack_guide_kernel(const uint8_t* __restrict__ bgr, uint32_t* __restrict__ ipk, uint32_t* __restrict__ ipk10, int P)
 {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < P) ipk[i] = (uint32_t)bgr[3 * (size_t)i] | ((uint32_t)bgr[3 * (size_t)i + 1] << 8) | ((uint32_t)bgr[3 * (size_t)i + 2] << 16);
+    if (i >= P) return;
+    const uint32_t b = bgr[3 * (size_t)i], g = bgr[3 * (size_t)i + 1], r = bgr[3 * (size_t)i + 2];
+    ipk[i] = b | (g << 8) | (r << 16);
+    ipk10[i] = ((2u * b - 255u) & 1023u) | (((2u * g - 255u) & 1023u) << 10) | (((2u * r - 255u) & 1023u) << 20);
 }
 
 __global__ void les_stats_hsum_kernel(const uint32_t* __restrict__ ipk, double* __restrict__ hs, int H, int W, int R)
