@@ -534,11 +534,12 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                     const uint32_t ip = xo < TW ? s_ipk2[hrow][xo] : 0u;
                     // LES/GuidedFilter.h:243: (b + a_r I_r + a_g I_g + a_b I_b) / N
                     const double qn = quad_sum(S * guide_centred_f64(ip, hk));
-                    if (hk == 0 && xo < TW && row_ok) {
-                        const int gx2 = job.tx0 + xo;
-                        const double rn2 = rny2 * s_rtab[window_count(gx2, R, job.cx0, job.cx1)];
-                        s_q[hrow][xo] = (float)(qn * rn2);
-                    }
+                    // branch-free: every lane stores; the lanes that do not own a result (k != 0, padding columns, rows outside
+                    // the job) write into the unused tail of their q row instead of being masked by a divergent region per output
+                    const int gx2 = job.tx0 + xo;
+                    const double rn2 = rny2 * s_rtab[window_count(gx2, R, job.cx0, job.cx1)];
+                    const int col = (hk == 0 && xo < TW && row_ok) ? xo : TW + hk;
+                    s_q[hrow][col] = (float)(qn * rn2);
                 }
                 LES_SCHED_FENCE(s);
             }
