@@ -322,6 +322,12 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     // quad re-derives them on the scalar unit -- 27 SALU instructions per row that stall the three resident waves
     struct RowInfo { double rny; int flags; uint32_t soff; };      // 1/count_y; bit 0: row in clip, bit 1: t >= 2R; stats row offset of row t + PD
     __shared__ RowInfo s_row[BY];
+    // per-row terms of phase G (row of the clip the p-row maps to): pixel offset of the row, d_base = b*y + c
+    // (LES/CostVolumeEnergy.h:73), whether the row lies inside the clip and the march, the clamped row itself
+    struct GRow { uint32_t rowpx; float d_base; };                  // bit 31 of rowpx: row inside the clip and the march
+    __shared__ GRow s_grow[BY];
+    __shared__ double s_rnx2[TW + 4];        // 1/count_x of the strip's output columns (constant for the whole job; +4: padding columns)
+    __shared__ int s_gsy[BY];                                       // the clamped row itself (image-based matching cost only)
     float (*s_q)[WP] = s_p;                  // ... so the finished q of the block's output rows reuses it (H2 -> F)
 
     // XCD-aware job order (guide T1): consecutive jobs (same strip, consecutive planes / neighbouring
@@ -383,16 +389,29 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 #pragma unroll
     for (int j = 0; j < PD; j++) pre[j] = stats_row(j);
 
+    // Row tables of the block that starts at p-row tb, written by BY lanes one block ahead (block 0: here, before the
+    // barrier below; block n+1: in phase F of block n), so no phase re-derives per-row scalars lane by lane.
+    auto fill_row_tables = [&](int tb) {
+        const int t = tb + tid;
+        const int gy1 = job.ty0 - 3 * R + t;                           // stage-1 row (phase V)
+        RowInfo ri;
+        ri.rny = s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+        ri.flags = ((gy1 >= job.cy0 && gy1 < job.cy1) ? 1 : 0) | (t >= 2 * R ? 2 : 0);
+        ri.soff = (uint32_t)min(max(gy1 + PD, job.cy0), job.cy1 - 1) * (uint32_t)(g.W * 3);
+        s_row[tid] = ri;
+        const int gy = job.ty0 - 2 * R + t;                            // p-row (phase G)
+        GRow gr;
+        const int sy = min(max(gy, job.cy0), job.cy1 - 1);
+        gr.rowpx = ((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u);
+        gr.d_base = plane.y * (float)sy + plane.z;
+        s_grow[tid] = gr;
+        if constexpr (SRC == 1) s_gsy[tid] = sy;
+    };
+    if (tid < BY) fill_row_tables(0);
+    if (tid < TW + 4) s_rnx2[tid] = s_rtab[window_count(job.tx0 + tid, R, job.cx0, job.cx1)];
+    __syncthreads();
+
     for (int t0 = 0; t0 < Ttot; t0 += BY) {
-        if (tid < BY) {
-            const int t = t0 + tid;
-            const int gy1 = job.ty0 - 3 * R + t;                       // stage-1 row
-            RowInfo ri;
-            ri.rny = s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
-            ri.flags = ((gy1 >= job.cy0 && gy1 < job.cy1) ? 1 : 0) | (t >= 2 * R ? 2 : 0);
-            ri.soff = (uint32_t)min(max(gy1 + PD, job.cy0), job.cy1 - 1) * (uint32_t)(g.W * 3);
-            s_row[tid] = ri;
-        }
         // ===================== G: gather =====================
         // A lane keeps its column for the whole job (column terms hoisted out of the march); the loads of
         // up to GB rows per lane are issued before any is consumed (memory-level parallelism, bounded so
@@ -403,11 +422,10 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 #pragma unroll 1
                 for (int jp = 0; jp < GPASS; jp++) {
                     const int i = jp * GRP + g_ri;
-                    const int t = t0 + i;
-                    const int gy = job.ty0 - 2 * R + t;
-                    const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
-                    const int sy = min(max(gy, job.cy0), job.cy1 - 1);
-                    const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
+                    const GRow gr = s_grow[i < BY ? i : BY - 1];
+                    const bool inside = g_lane && g_col_in && i < BY && (gr.rowpx >> 31);
+                    const int sy = s_gsy[i < BY ? i : BY - 1];
+                    const uint32_t px = (gr.rowpx & 0x7fffffffu) + (uint32_t)g_sx;
                     const NaivePrep np = naive_prepare(g, view.sign, plane.x, plane.y, plane.z, g_sx, sy);
                     const float4 own = view.feat_self[px], fa = view.feat_other[np.ia], fb = view.feat_other[np.ib];
                     const uint32_t ip = view.ipk10[px];
@@ -427,13 +445,10 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 #pragma unroll
                     for (int j = 0; j < JN; j++) {
                         const int i = (J0 + j) * GRP + g_ri;
-                        const int t = t0 + i;
-                        const int gy = job.ty0 - 2 * R + t;
-                        const bool inside = g_lane && g_col_in && i < BY && t < Ttot && gy >= job.cy0 && gy < job.cy1;
-                        const int sy = min(max(gy, job.cy0), job.cy1 - 1);
-                        const uint32_t px = (uint32_t)sy * (uint32_t)g.W + (uint32_t)g_sx;
-                        const float d_base = plane.y * (float)sy + plane.z;
-                        gp[j] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
+                        const GRow gr = s_grow[i < BY ? i : BY - 1];
+                        const bool inside = g_lane && g_col_in && i < BY && (gr.rowpx >> 31);
+                        const uint32_t px = (gr.rowpx & 0x7fffffffu) + (uint32_t)g_sx;
+                        gp[j] = gather_prepare(g, g_ax, gr.d_base, px, HWu, inside);
                         v0[j] = view.vol[gp[j].i0];
                         v1[j] = view.vol[gp[j].i1];
                         ipa[j] = view.ipk10[px];
@@ -536,8 +551,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                     const double qn = quad_sum(S * guide_centred_f64(ip, hk));
                     // branch-free: every lane stores; the lanes that do not own a result (k != 0, padding columns, rows outside
                     // the job) write into the unused tail of their q row instead of being masked by a divergent region per output
-                    const int gx2 = job.tx0 + xo;
-                    const double rn2 = rny2 * s_rtab[window_count(gx2, R, job.cx0, job.cx1)];
+                    const double rn2 = rny2 * s_rnx2[xo < TW + 4 ? xo : TW + 3];
                     const int col = (hk == 0 && xo < TW && row_ok) ? xo : TW + hk;
                     s_q[hrow][col] = (float)(qn * rn2);
                 }
@@ -547,6 +561,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
         __syncthreads();
 
         // ===================== F: store =====================
+        if (tid < BY) fill_row_tables(t0 + BY);
         for (int idx = tid; idx < BY * TW; idx += NT) {
             const int i = idx / TW, xo = idx - i * TW;
             const int t = t0 + i;
