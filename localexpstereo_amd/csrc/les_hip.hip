@@ -239,7 +239,8 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     HIPCHECK(hipMemcpy(d_img, im, P * 3, hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc((void**)&v.ipk, P * sizeof(uint32_t)));
     HIPCHECK(hipMalloc((void**)&v.ipk10, P * sizeof(uint32_t)));
-    HIPCHECK(hipMalloc((void**)&v.stats, P * 3 * sizeof(float4)));
+    HIPCHECK(hipMalloc((void**)&v.stats, (P * 3 + 1) * sizeof(float4)));           // + one all-zero entry (read by the k = 3 lanes of phase V)
+    HIPCHECK(hipMemsetAsync(v.stats + P * 3, 0, sizeof(float4), c->stream));
     HIPCHECK(hipMalloc((void**)&d_hs, P * 9 * sizeof(double)));
     const int W = c->p.W, H = c->p.H;
     if (c->naive) {

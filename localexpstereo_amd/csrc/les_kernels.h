@@ -262,23 +262,23 @@ struct VLane {
     //   rn1 : 1/N of the stage-1 pixel;  st: its statistics {mean_I'_k, inv[k][0..2]} (used when in_clip && k < 3)
     // returns the vertical stage-2 sum (centred R rows above the stage-1 row)
     template <int S>
-    __device__ __forceinline__ float step(float in, bool do_algebra, bool in_clip, double rn1, float4 st)
+    __device__ __forceinline__ float step(float in, bool keep, double rn1, float4 s)
     {
         constexpr int OLD = (S + RS - KS) % RS;
         S1 += (double)in - (double)ring1[OLD];             // sum over the last 2R+1 p-rows
         ring1[S] = in;
-        // LES/GuidedFilter.h:204-221 on the centred guide.  No branch on do_algebra: straight-line code lets the
-        // scheduler overlap the dependent chains of consecutive rows (they only meet in S1 / S2).
+        // LES/GuidedFilter.h:204-221 on the centred guide.  Straight-line code: consecutive rows only meet in S1 / S2.
+        // `s` = statistics of the stage-1 pixel for lanes k < 3, the all-zero entry for lane 3 (so lane 3 contributes
+        // nothing to b's correction and its cov is the plain mean); pixels outside the clip use the statistics of the
+        // clamped pixel -- finite numbers -- and their result is discarded by `keep`.
         const double m = S1 * rn1;                         // lane k<3: mean(I'_k p), lane 3: mean(p)
         const double mp = quad_bcast<3>(m);
-        const bool use = in_clip && k < 3;
-        const float4 s = make_float4(use ? st.x : 0.f, use ? st.y : 0.f, use ? st.z : 0.f, use ? st.w : 0.f);
         const float cov = (float)(m - (double)s.x * mp);   // cov_k = mean(I'_k p) - mean_I'_k * mean_p
         const float ak = s.y * quad_bcast<0>(cov) + s.z * quad_bcast<1>(cov) + s.w * quad_bcast<2>(cov);
         // b = mean_p - sum_k a_k mean_I'_k : lanes 0..2 contribute a_k * mean_I'_k, lane 3 contributes 0
         const float bb = (float)mp - quad_sum(ak * s.x);
         float val = (k < 3) ? ak : bb;
-        if (!(in_clip && do_algebra)) val = 0.0f;          // a, b are zero-padded outside the sub-region
+        if (!keep) val = 0.0f;                             // a, b are zero-padded outside the sub-region and before the march is primed
         S2 += (double)val - (double)ring2[OLD];            // sum over the last 2R+1 stage-1 rows
         ring2[S] = val;
         return (float)S2;
@@ -379,11 +379,13 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     // runs across block boundaries), so their L2/HBM latency never sits on the V-phase critical path.
     constexpr int PD = (BY % 4 == 0) ? 4 : ((BY % 3 == 0) ? 3 : 1);      // must divide BY (static register names)
     const int sgx1 = min(max(gx1, job.cx0), job.cx1 - 1);
-    const float4* st_col = view.stats + (size_t)sgx1 * 3 + (vk < 3 ? vk : 0);
+    // lanes k < 3 walk the statistics of their stage-1 column; lane 3 (the p / b quantity) always reads the all-zero entry
+    // that follows the table
+    const float4* st_col = vk < 3 ? view.stats + (size_t)sgx1 * 3 + vk : view.stats + (size_t)g.H * g.W * 3;
     const size_t st_stride = (size_t)g.W * 3;
     auto stats_row = [&](int t) -> float4 {
         const int gy1 = min(max(job.ty0 - 3 * R + t, job.cy0), job.cy1 - 1);
-        return st_col[(size_t)gy1 * st_stride];
+        return st_col[(vk < 3 ? (size_t)gy1 : (size_t)0) * st_stride];
     };
     float4 pre[PD];
 #pragma unroll
@@ -507,10 +509,9 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                 static_for<BY>([&](auto itag) {
                     constexpr int i = decltype(itag)::value;
                     const RowInfo ri = s_row[i];                        // uniform address: one broadcast 16-byte LDS read
-                    const bool in_clip = col_in_clip && (ri.flags & 1);
                     const double rn1 = rnx1 * ri.rny;
-                    const float o = vl.template step<BASE + i>(trow[i * TPITCH], (ri.flags & 2) != 0, in_clip, rn1, pre[i % PD]);
-                    pre[i % PD] = st_col[ri.soff];
+                    const float o = vl.template step<BASE + i>(trow[i * TPITCH], col_in_clip && ri.flags == 3, rn1, pre[i % PD]);
+                    pre[i % PD] = st_col[vk < 3 ? ri.soff : 0u];
                     s_T[i][vx * 4 + vk] = o;
                     LES_SCHED_FENCE_V(i);
                 });

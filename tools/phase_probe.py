@@ -1,0 +1,24 @@
+import ctypes as C, os, sys, json, subprocess
+sys.path.insert(0, os.getcwd())
+os.environ["LES_HIP_LIB"] = os.path.join(os.getcwd(), "localexpstereo_amd/csrc/exp_t.so")
+import torch, numpy as np
+from localexpstereo_amd import api, synth
+H, W, D = 1000, 1500, 256
+dev = torch.device("cuda", 0)
+guide = synth.make_guide(H, W, 1234)
+vol = torch.rand((D, H, W), device=dev, dtype=torch.float32)
+e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1, volumes_on_device=True, shape=(D, H, W))
+planes = torch.from_numpy(synth.fronto_planes(D)).to(dev)
+out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
+full = [(0, 0, W, H)] * D
+b = api.Batch(e, full, full, out_slabs=True)
+L = e.L
+buf = (C.c_ulonglong * 8)()
+b.run(planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
+L.les_hip_debug_phases(buf)
+for it in range(2):
+    b.run(planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
+    L.les_hip_debug_phases(buf)
+    v = [buf[i] for i in range(6)]
+    tot = sum(v[:5])
+    print("WGs", v[5], "cycles per WG", tot / v[5], "phase shares G/H1/V/H2/F:", [round(100.0 * x / tot, 1) for x in v[:5]], "per block-phase cycles", [round(x / v[5] / 49.5) for x in v[:5]])
