@@ -437,7 +437,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
                     }
                 }
             } else {
-                constexpr int GB = 4;
+                constexpr int GB = 7;
                 static_for<(GPASS + GB - 1) / GB>([&](auto btag) {
                     constexpr int J0 = decltype(btag)::value * GB;
                     constexpr int JN = (GPASS - J0) < GB ? (GPASS - J0) : GB;
