@@ -165,6 +165,10 @@ int les_hip_consistency_check(les_hip_ctx* ctx, const les_hip_plane* d_labelsL, 
  * Both device label maps are updated in place.  Needs both views' images in the context; windR <= 31. */
 int les_hip_post_process(les_hip_ctx* ctx, les_hip_plane* d_labelsL, les_hip_plane* d_labelsR, float threshold, float omega);
 
+/* diagnostics: dword-per-lane streaming copy of n floats (device pointers), the known-byte-count pattern used to
+ * calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for this library's access width (profiles/). */
+int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, void* stream);
+
 /* Device memory helpers for callers without a HIP toolchain (host C++ adapter, ctypes). */
 int les_hip_malloc(les_hip_ctx* ctx, void** dev_ptr, size_t bytes);
 int les_hip_free(les_hip_ctx* ctx, void* dev_ptr);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "les_hip_batch_num_jobs", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
-    "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
+    "les_hip_calib_copy", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
 ]
 
 
@@ -68,6 +68,7 @@ def load(path=None):
         "les_hip_batch_graph_offsets": (ci, [vp, vp]),
         "les_hip_batch_expansion_graph": (ci, [vp, vp, ci, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
         "les_hip_batch_apply_masks": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+        "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
         "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
         "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),

@@ -792,6 +792,15 @@ int les_hip_post_process(les_hip_ctx* c, les_hip_plane* d_labelsL, les_hip_plane
     return LES_HIP_OK;
 }
 
+int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, void* stream)
+{
+    if (!d_src || !d_dst || n == 0) return fail(LES_HIP_ERR_ARG, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    hipLaunchKernelGGL(les::les_calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, n);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
 int les_hip_malloc(les_hip_ctx* c, void** p, size_t bytes)
 {
     if (!c || !p) return fail(LES_HIP_ERR_ARG, "null argument");

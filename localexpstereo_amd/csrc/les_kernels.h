@@ -652,6 +652,14 @@ __global__ void les_naive_features_kernel(const uint8_t* __restrict__ img, float
     feat[(size_t)y * W + x] = f;
 }
 
+// One dword per lane streaming copy: the calibration pattern for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (the strip
+// kernel reads and writes dwords; MI355X_MICROARCH.md asks for a calibration on a known byte count in the same access width).
+__global__ void les_calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Volume preparation ("next" row N3): LES/main.cpp:146-176 fillOutOfView and :178-199 convertVolumeL2R with
 // margin = 0 (interp_margin, LES/main.cpp:359).  grid = (ceil(W/256), H, D).
