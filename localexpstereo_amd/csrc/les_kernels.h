@@ -196,7 +196,7 @@ __device__ __forceinline__ float guide10_centred_f32(uint32_t w10, int k)
 __device__ __forceinline__ double guide_centred_f64(uint32_t ipk, int k)
 {
     int u = (int)((ipk >> (8 * k)) & 0xffu);
-    double w = (double)u * (1.0 / 255) - 0.5;
+    double w = fma((double)u, 1.0 / 255, -0.5);
     return k == 3 ? 1.0 : w;
 }
 
@@ -273,8 +273,8 @@ struct VLane {
         // clamped pixel -- finite numbers -- and their result is discarded by `keep`.
         const double m = S1 * rn1;                         // lane k<3: mean(I'_k p), lane 3: mean(p)
         const double mp = quad_bcast<3>(m);
-        const float cov = (float)(m - (double)s.x * mp);   // cov_k = mean(I'_k p) - mean_I'_k * mean_p
-        const float ak = s.y * quad_bcast<0>(cov) + s.z * quad_bcast<1>(cov) + s.w * quad_bcast<2>(cov);
+        const float cov = (float)fma(-(double)s.x, mp, m); // cov_k = mean(I'_k p) - mean_I'_k * mean_p  (one rounding: explicit fma)
+        const float ak = fmaf(s.w, quad_bcast<2>(cov), fmaf(s.z, quad_bcast<1>(cov), s.y * quad_bcast<0>(cov)));
         // b = mean_p - sum_k a_k mean_I'_k : lanes 0..2 contribute a_k * mean_I'_k, lane 3 contributes 0
         const float bb = (float)mp - quad_sum(ak * s.x);
         float val = (k < 3) ? ak : bb;
