@@ -134,6 +134,26 @@ def main():
     elapsed = float(elapsed.item())
     kern_ms = float(kern_ms.item())
 
+    # measured device-copy ceiling on this box (quote both denominators): dword-per-lane copy of the volume
+    # shard through the library's calibration kernel, 2 x bytes moved / time
+    import ctypes as C
+    copy_gbs = None
+    try:
+        nn = int(vol.numel())
+        tmp = torch.empty_like(vol)
+        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L = api.load()
+        L.les_hip_calib_copy(C.c_void_p(vol.data_ptr()), C.c_void_p(tmp.data_ptr()), C.c_size_t(nn), local_rank, C.c_void_p(stream.cuda_stream))
+        ca.record(stream)
+        for _ in range(3):
+            L.les_hip_calib_copy(C.c_void_p(vol.data_ptr()), C.c_void_p(tmp.data_ptr()), C.c_size_t(nn), local_rank, C.c_void_p(stream.cuda_stream))
+        cb.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_gbs = 3 * 2.0 * nn * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+        del tmp
+    except Exception:
+        copy_gbs = None
+
     evals_rank = float(evals_per_step_h3) if args.workload == "h3" else float(P) * D
     evals_per_step = evals_rank * world
     value = evals_per_step * args.steps / elapsed / 1e6
@@ -183,6 +203,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
+            # second denominator: device copy measured on this box in this run, one dword per lane like the
+            # strip kernel's accesses (a float4 copy reaches ~6.3 TB/s on MI355X, MI355X_MICROARCH.md)
+            "measured_dword_copy": None if copy_gbs is None else round(copy_gbs, 1),
+            "frac_of_measured_dword_copy": None if not copy_gbs else round(achieved / copy_gbs, 5),
             "traffic": traffic,
             "kernel": "les_strip_kernel<R=10> (gather + guided filter fused; strip width %d)" % e.strip_width(),
             "kernel_ms": round(kern_ms, 4),

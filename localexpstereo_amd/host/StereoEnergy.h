@@ -169,6 +169,41 @@ public:
         return Plane::CreatePlane((float)(sinT * cosP), (float)(sinT * sinP), (float)cosT, zs, (float)s.x, (float)s.y, 0.0f);
     }
 
+    // StereoEnergy::computePatchWeight (LES/StereoEnergy.h:251-257): exp(-|I(s) - I(t)|_1 / omega) on the float BGR image
+    float computePatchWeight(Point s, Point t, int mode = 0) const
+    {
+        const float* a = &I[mode][((size_t)s.y * width + s.x) * 3];
+        const float* b = &I[mode][((size_t)t.y * width + t.x) * 3];
+        const float absdiff = std::fabs(a[0] - b[0]) + std::fabs(a[1] - b[1]) + std::fabs(a[2] - b[2]);
+        return std::exp(-absdiff / params.omega);
+    }
+
+    // StereoEnergy::computeDisparities (LES/StereoEnergy.h:269-272) and computeNormalMap (:274-289, the visualisation of the
+    // plane normals: channels {nz, (1 - nx')/2 ... } exactly as the reference composes them: out[0] = nz = 1/sqrt(a^2+b^2+1),
+    // out[1] = (-b nz + 1)/2, out[2] = (-a nz + 1)/2)
+    std::vector<float> computeDisparities(const LabelMap& labeling) const
+    {
+        std::vector<float> d((size_t)width * height);
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) d[(size_t)y * width + x] = labeling.at(y, x).GetZ((float)x, (float)y);
+        return d;
+    }
+    std::vector<float> computeNormalMap(const LabelMap& labeling) const
+    {
+        std::vector<float> n((size_t)width * height * 3);
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) {
+                const Plane& l = labeling.at(y, x);
+                const float nz = 1.0f / std::sqrt(l.a * l.a + l.b * l.b + 1.0f);
+                float* o = &n[((size_t)y * width + x) * 3];
+                o[0] = nz; o[1] = (l.b * nz * -1.0f + 1.0f) / 2.0f; o[2] = (l.a * nz * -1.0f + 1.0f) / 2.0f;
+            }
+        return n;
+    }
+    // the reference's label maps carry a one-pixel margin (getRectWithoutMargin, LES/StereoEnergy.h:264-267); the maps here
+    // have none, so the interior is the whole image
+    Rect getRectWithoutMargin() const { return Rect(0, 0, width, height); }
+
     int getWidth() const { return width; }
     int getHeight() const { return height; }
     float maxDisparity() const { return MAX_DISPARITY; }
