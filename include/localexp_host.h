@@ -40,7 +40,7 @@ float* les_gc_costs(les_gc_ctx* ctx, int mode);
 /* One lock-step: for every i < n fuse the proposal planes[i] into the current solution over regions[i] (the cell's
  * shared region) given its unary costs in proposal_cost (row-major H x W, only regions[i] is read).  Regions of one call
  * must come from one disjoint set (LES/LayerManager.h:168-172) -- they are cut concurrently on `nthreads` threads
- * (<= 0: one per cell, at most 16 -- larger teams were measured slower).  check != 0 runs the reference's flow == energy self-check
+ * (<= 0: one per cell, at most 24 -- larger teams were measured slower; OMP_WAIT_POLICY=passive helps).  check != 0 runs the reference's flow == energy self-check
  * (LES/FastGCStereo.h:561-594) and returns the largest relative gap in *max_gap (may be NULL). */
 int les_gc_expansion_moves(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,
                            const float* proposal_cost, int nthreads, int check, double* max_gap);

@@ -89,7 +89,7 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
 {
     static thread_local GridMaxFlow graph;
     const int w = region.width, h = region.height;
-    graph.reset(w, h);
+    graph.reset_for_load(w, h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
     graph.set_base_flow(base_flow);

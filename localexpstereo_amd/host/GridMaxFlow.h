@@ -61,12 +61,30 @@ public:
         nodes_[i + off_[k]].rc[k ^ 1] += rev_cap;
     }
 
+    // reset for a graph whose every interior node is then initialised with load_node: only the padding ring is cleared
+    void reset_for_load(int w, int h)
+    {
+        w_ = w; h_ = h; pw_ = w + 2;
+        const size_t n = (size_t)(w + 2) * (h + 2);
+        if (nodes_.size() < n) nodes_.resize(n);
+        const Node blank;
+        for (int x = 0; x < pw_; x++) { nodes_[x] = blank; nodes_[(size_t)(h + 1) * pw_ + x] = blank; }
+        for (int y = 1; y <= h; y++) { nodes_[(size_t)y * pw_] = blank; nodes_[(size_t)y * pw_ + w + 1] = blank; }
+        const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
+        for (int k = 0; k < 8; k++) off_[k] = o[k];
+        flow_ = 0;
+        time_ = 0;
+        orphans_.clear();
+        orphan_head_ = 0;
+        queue_first_[0] = queue_first_[1] = queue_last_[0] = queue_last_[1] = NONE_NODE;
+    }
     // direct initialisation from / export to the 5-float node payload {terminal residual, caps E, S, SW, SE} produced by
     // the device (include/localexp_hip.h: les_hip_batch_expansion_graph); base_flow = flow already routed by the t-links
-    void load_node(int x, int y, const float* p5)
+    void load_node(int x, int y, const float* p5)          // sets every field of the node (see reset_for_load)
     {
         Node& n = nodes_[id(x, y)];
-        n.tr = p5[0]; n.rc[E] = p5[1]; n.rc[S] = p5[2]; n.rc[SW] = p5[3]; n.rc[SE] = p5[4];
+        n.rc[E] = p5[1]; n.rc[W] = 0; n.rc[S] = p5[2]; n.rc[N] = 0; n.rc[SW] = p5[3]; n.rc[NE] = 0; n.rc[SE] = p5[4]; n.rc[NW] = 0;
+        n.tr = p5[0]; n.next_active = NOT_QUEUED; n.ts = 0; n.dist = 0; n.parent = P_NONE; n.is_sink = 0;
     }
     void store_node(int x, int y, float* p5) const
     {

@@ -261,7 +261,7 @@ public:
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
                                 const auto& L = layermng.layers[li];
-                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : std::min(16, omp_get_max_threads())));
+                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : std::min(24, omp_get_max_threads())));
                                 std::chrono::steady_clock::time_point tB, tC;
                                 if (devGraph) {
                                     const long long nodes = les_hip_batch_graph_nodes(sb.b);
@@ -376,7 +376,7 @@ public:
     double gcSeconds[3] = {0, 0, 0};    // runDevice graph-cut lock-steps: GPU propose+unary+D2H / host cuts / H2D labels
     long gcLockSteps = 0;
     bool deviceGraph = true;            // runDevice: pairwise terms / graph capacities of the moves computed on the GPU (N1)
-    int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: at most 16 and one per cell -- larger teams are slower)
+    int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: at most 24 and one per cell -- larger teams are slower)
 
 private:
     static uint64_t splitmix(uint64_t x)

@@ -27,10 +27,11 @@ int fail(const char* fmt, ...)
 
 // Team size of a lock-step.  The cuts of one lock-step are small (tens of microseconds for a layer-0 cell), so a team of
 // every hardware thread costs more in fork/join, wake-ups and cache traffic than it buys: measured on a 2 x 64-core
-// EPYC 9575F (1436 x 992, 5 graph-cut iterations) 16 threads 0.8 s / iteration, 64 threads 1.2 s, 256 threads 1.8 s.
+// EPYC 9575F (1436 x 992): with the default (spinning) OpenMP wait policy 16 threads 0.7 s / iteration, 64 threads 1.2 s,
+// 256 threads 1.8 s; with OMP_WAIT_POLICY=passive 24 threads 0.54 s and flat beyond.
 int defaultThreads(int requested, int n)
 {
-    if (requested <= 0) requested = std::min(16, omp_get_max_threads());
+    if (requested <= 0) requested = std::min(24, omp_get_max_threads());
     return std::max(1, std::min(requested, n));
 }
 

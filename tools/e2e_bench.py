@@ -13,6 +13,8 @@ post-processing, Evaluator rows (bad-1.0).  Prints one JSON object with the wall
 import argparse
 import json
 import os
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # before any OpenMP runtime starts: sleeping workers between lock-steps beat spinning ones
 import sys
 import time
 
