@@ -57,10 +57,10 @@ const StripEntry kStrips[] = {
     LES_STRIP_ENTRY(7, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(8, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(9, 0, 64, 16, 4, 2),
     LES_STRIP_ENTRY(10, 0, 64, 21, 3, 3), LES_STRIP_ENTRY(12, 0, 64, 16, 4, 2), LES_STRIP_ENTRY(15, 0, 96, 16, 6, 2),
     // A/B variants for radius 10 (LES_HIP_VARIANT=n)
-    LES_STRIP_ENTRY(10, 1, 128, 16, 8, 2), LES_STRIP_ENTRY(10, 2, 128, 21, 6, 3), LES_STRIP_ENTRY(10, 3, 64, 16, 4, 2),
-    LES_STRIP_ENTRY(10, 4, 96, 21, 4, 3), LES_STRIP_ENTRY(10, 5, 80, 21, 3, 3),
-    // measured (ms per 1500x1000x256 pass): 0: 7.14 | 11 = (64,21,3) at 2 waves/SIMD: 9.57 | (128,21,SEG 3/4/6) at 2 waves: 10.2 / 11.2 / 8.8
-    // | (96,21,SEG 3/4) at 2 waves (6-wave workgroups): 15.1 / 12.4  -- occupancy beats the lower instruction count of wide strips
+    // Kept: the wide strip and the default geometry at 2 waves/SIMD.  Measured earlier in the round (ms per 1500x1000x256 pass,
+    // default then 7.14): (64,21,3) at 2 waves/SIMD 9.57 | (128,21,SEG 3/4/6) at 2 waves 10.2 / 11.2 / 8.8 | (128,16,8) 9.6 |
+    // (96,21,SEG 3/4) at 2 waves (6-wave workgroups) 15.1 / 12.4 | (80,21,3) 14.4 | anything that spills 11-15:
+    // occupancy beats the lower instruction count of wide strips
     LES_STRIP_ENTRY(10, 8, 128, 21, 6, 2), LES_STRIP_ENTRY(10, 11, 64, 21, 3, 2),
 };
 // image-based matching cost (les_hip_create_naive): one conservative configuration per radius
