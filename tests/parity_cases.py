@@ -218,6 +218,46 @@ def case_empty_and_errors(pr):
         pr.e.unary_batch([(-5, 0, 50, 50)], [(0, 0, 20, 20)], [(0, 0, 1, 0)])        # filter outside image
 
 
+def case_widened_abi_errors(lib):
+    """Error behaviour of the entry points added for the "next" rows: status codes with a message, never a crash or a
+    silent CPU path."""
+    import pytest
+    imL, imR = load_cones_crop()
+    H, W = imL.shape[:2]
+    vol = synth.make_volume(8, H, W, 1)
+    with pytest.raises(api.LesHipError, match="both views"):
+        _naive_one_view(imL, lib)
+    e = api.HipCostVolumeEnergy(imL, None, vol, None, lib=lib)                      # left view only
+    lab = api.DeviceBuffer(e, H * W * 16)
+    lab.fill(0)
+    with pytest.raises(api.LesHipError, match="both views"):
+        e.post_process(lab.ptr, lab.ptr)
+    with pytest.raises(api.LesHipError, match="null"):
+        e.post_process(0, lab.ptr)
+    with pytest.raises(api.LesHipError):
+        e.consistency_check(lab.ptr, lab.ptr, 0, 0)
+    b = api.Batch(e, [(0, 0, 40, 40)], [(10, 10, 20, 20)])
+    assert b.graph_nodes() == 400 and b.graph_offsets().tolist() == [0]
+    with pytest.raises(api.LesHipError, match="view 1"):
+        b.expansion_graph(lab.ptr, lab.ptr, lab.ptr, lab.ptr, lab.ptr, mode=1)
+    with pytest.raises(api.LesHipError, match="null"):
+        b.expansion_graph(lab.ptr, lab.ptr, 0, lab.ptr, lab.ptr)
+    with pytest.raises(api.LesHipError, match="null"):
+        b.apply_masks(lab.ptr, 0, lab.ptr, lab.ptr, lab.ptr)
+    b.destroy(); lab.free(); e.close()
+
+
+def _naive_one_view(imL, lib):
+    L = api.load(lib)
+    import ctypes as C
+    p = api.Params(imL.shape[0], imL.shape[1], 1, 20, 1e-4, 10.0, 15.0, 0.0, 0, 0)
+    h = C.c_void_p()
+    rc = L.les_hip_create_naive(C.byref(h), C.byref(p), api._ptr(np.ascontiguousarray(imL)), None, C.c_float(0.9), C.c_float(2.0))
+    if rc:
+        raise api.LesHipError(L.les_hip_last_error().decode())
+    L.les_hip_destroy(h)
+
+
 def run_slabs(pr, planes, mode=0, check=False):
     """Whole-image aggregation of n hypothesis planes into [n][H][W]."""
     n = len(planes)
