@@ -50,6 +50,15 @@ def test_host_library_symbols_are_exported():
     g.close()
 
 
+def test_integration_doc_lists_every_symbol():
+    """INTEGRATION.md names, for every exported entry point, the reference interface it replaces."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _declared() if s not in doc]
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "localexp_host.h")).read(), flags=re.S)
+    missing += [s for s in sorted(set(re.findall(r"\b(les_gc_[a-z0-9_]+)\s*\(", text))) if s not in doc]
+    assert not missing, missing
+
+
 def test_library_contains_gfx950_code_object(hip_so):
     blob = open(hip_so, "rb").read()
     assert b"gfx950" in blob
