@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Randomised parity sweep: random image sizes, radii, (filterRect, targetRect) pairs and planes through the C ABI
+(`les_hip_unary_batch`, check on/off, both views) against the oracle.  Also random label maps through the device
+post-processing and the expansion-graph construction.  Exits non-zero on the first mismatch.
+
+  python tools/fuzz_parity.py [--seconds 120] [--seed 0] [--lib PATH]     (default library: the HIP build)
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from localexpstereo_amd import api, synth          # noqa: E402
+from oracle import oracle as om                     # noqa: E402
+from tests import parity_cases as pc                # noqa: E402
+
+RADII = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15]
+
+
+def one_case(rng, lib, stats):
+    R = int(rng.choice(RADII))
+    windR = 2 * R + int(rng.integers(0, 2))                       # windR / 2 == R
+    H, W = int(rng.integers(8, 150)), int(rng.integers(8, 200))
+    D = int(rng.integers(2, 24))
+    mind = float(rng.choice([0.0, 0.0, -3.0]))
+    maxd = float(D - 1 + mind)
+    imL, imR = synth.make_guide(H, W, int(rng.integers(1 << 30))), synth.make_guide(H, W, int(rng.integers(1 << 30)))
+    if rng.random() < 0.2:
+        imL[:] = imL[0, 0]                                          # constant guide: Sigma = eps I
+    volL, volR = synth.make_volume(D, H, W, int(rng.integers(1 << 30))), synth.make_volume(D, H, W, int(rng.integers(1 << 30)))
+    eps = float(rng.choice([1e-4, 1e-2, 1e-6]))
+    th = float(rng.choice([0.5, 0.12, 2.0]))
+    o = om.Oracle(imL, imR, volL, volR, windR=windR, eps=eps, th_col=th, max_disp=maxd, min_disp=mind)
+    e = api.HipCostVolumeEnergy(imL, imR, volL, volR, windR=windR, eps=eps, th_col=th, max_disp=maxd, min_disp=mind, lib=lib)
+    n = int(rng.integers(1, 12))
+    frs, trs = np.zeros(n, api.RECT_DT), np.zeros(n, api.RECT_DT)
+    occupied = np.zeros((H, W), bool)
+    k = 0
+    for _ in range(n * 4):
+        fw, fh = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+        fx, fy = int(rng.integers(0, W - fw + 1)), int(rng.integers(0, H - fh + 1))
+        tw, th_ = int(rng.integers(1, fw + 1)), int(rng.integers(1, fh + 1))
+        tx, ty = fx + int(rng.integers(0, fw - tw + 1)), fy + int(rng.integers(0, fh - th_ + 1))
+        if occupied[ty:ty + th_, tx:tx + tw].any():
+            continue                                                 # targets of one batch are disjoint (one disjoint set)
+        occupied[ty:ty + th_, tx:tx + tw] = True
+        frs[k], trs[k] = (fx, fy, fw, fh), (tx, ty, tw, th_)
+        k += 1
+        if k == n:
+            break
+    frs, trs = frs[:k], trs[:k]
+    planes = pc.random_planes(k, D, H, W, int(rng.integers(1 << 30)), slant=float(rng.choice([0.0, 0.05, 0.5])))
+    planes[:, 2] += mind
+    if rng.random() < 0.15:
+        planes[0, :3] = rng.choice([np.nan, np.inf, -np.inf, 1e30])
+    for mode in (0, 1):
+        for check in (True, False):
+            ref = o.unary_batch(frs, trs, planes, mode=mode, check=check)
+            got = e.unary_batch(frs, trs, planes, mode=mode, check=check)
+            # absolute tolerance scaled to the cost range (th_col)
+            m = ~np.isnan(ref)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), "written set"
+            assert np.array_equal(got[m] == np.float32(1e6), ref[m] == np.float32(1e6)), "sentinels"
+            v = m & (ref != np.float32(1e6))
+            if v.any():
+                err = np.abs(got[v].astype(np.float64) - ref[v])
+                tol = 1e-4 * np.abs(ref[v]) + 2e-6 * max(1.0, th)
+                if not np.all(err <= tol):
+                    raise AssertionError(f"max err {err.max():.3e} (R={R} {W}x{H}x{D} eps={eps} th={th} mode={mode} check={check})")
+                stats["max_err"] = max(stats["max_err"], float(err.max() / max(1.0, th)))
+    stats["calls"] += 4 * k
+    # post-processing on random piecewise label maps (both views): labels must come out bit-identical
+    if rng.random() < 0.35 and windR <= 31:
+        def labels():
+            lab = np.zeros((H, W, 4), np.float32)
+            lab[..., 2] = rng.uniform(0, D)
+            for _ in range(int(rng.integers(1, 8))):
+                x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+                w, h = int(rng.integers(1, W - x0 + 1)), int(rng.integers(1, H - y0 + 1))
+                lab[y0:y0 + h, x0:x0 + w] = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-2, D + 2), 0.0)
+            noisy = rng.random((H, W)) < 0.03
+            lab[noisy, 2] += rng.uniform(-9, 9, int(noisy.sum())).astype(np.float32)
+            return lab
+        LL, LR = labels(), labels()
+        thr = float(rng.choice([1.0, 1.5]))
+        ref = om.post_process(LL, LR, imL, imR, windR=windR, threshold=thr, omega=10.0)
+        got = e.post_process_host(LL, LR, threshold=thr, omega=10.0)
+        for g_, r_ in zip(got, ref):
+            if not np.array_equal(g_.view(np.uint32), r_.view(np.uint32)):
+                raise AssertionError(f"post-processed labels differ ({W}x{H} windR={windR} thr={thr})")
+        stats["post"] += 1
+    e.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lib", default=None)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    stats = dict(calls=0, max_err=0.0, post=0)
+    t0 = time.time()
+    cases = 0
+    while time.time() - t0 < args.seconds:
+        state = rng.bit_generator.state
+        try:
+            one_case(rng, args.lib, stats)
+        except Exception:
+            print("FAILED case", cases, "rng state:", state["state"])
+            raise
+        cases += 1
+    print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
+          f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
