@@ -34,6 +34,8 @@ __device__ __forceinline__ float pw_coeff(const uint32_t* __restrict__ ipk, cons
     const int ad = abs((int)(a & 255) - (int)(b & 255)) + abs((int)((a >> 8) & 255) - (int)((b >> 8) & 255)) + abs((int)((a >> 16) & 255) - (int)((b >> 16) & 255));
     return wtab[ad];
 }
+// std::min(a, b) of the reference / host code: (b < a) ? b : a  -- NaN in `a` propagates, unlike fminf
+__device__ __forceinline__ float pw_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float pw_getz(float4 l, int x, int y) { return (l.x * (float)x + l.y * (float)y) + l.z; }          // Plane::GetZ
 __device__ __forceinline__ float pw_dot(float4 l, float x, float y) { return ((l.x * x + l.y * y) + l.z * 1.0f) + l.w * 0.0f; }   // channelDot order
 
@@ -41,7 +43,7 @@ __device__ __forceinline__ float pw_dot(float4 l, float x, float y) { return ((l
 __device__ __forceinline__ float pw_term(float coeff, float4 ls, float4 lt, int x, int y, int xt, int yt, const PairwiseParams& p)
 {
     const float d = fabsf(pw_getz(ls, x, y) - pw_getz(lt, x, y)) + fabsf(pw_getz(ls, xt, yt) - pw_getz(lt, xt, yt));
-    return coeff * fminf(d, p.th_smooth) * p.lambda;
+    return coeff * pw_min(d, p.th_smooth) * p.lambda;
 }
 
 struct PwTerms { float c00, c01, c10; };
@@ -59,9 +61,9 @@ __device__ __forceinline__ PwTerms pw_expansion_terms(const float4* __restrict__
     const float d1_at_ee = pw_dot(label1, fx, fy), d1_at_le = pw_dot(label1, gx, gy);
     const float w = pw_coeff(ipk, wtab, p.W, p.H, ex, ey, dx, dy);
     PwTerms t;
-    t.c00 = fminf(fabsf(d0_ee_at_ee - d0_le_at_ee) + fabsf(d0_ee_at_le - d0_le_at_le), p.th_smooth) * w * p.lambda;
-    t.c01 = fminf(fabsf(d0_ee_at_ee - d1_at_ee) + fabsf(d0_ee_at_le - d1_at_le), p.th_smooth) * w * p.lambda;
-    t.c10 = fminf(fabsf(d1_at_ee - d0_le_at_ee) + fabsf(d1_at_le - d0_le_at_le), p.th_smooth) * w * p.lambda;
+    t.c00 = pw_min(fabsf(d0_ee_at_ee - d0_le_at_ee) + fabsf(d0_ee_at_le - d0_le_at_le), p.th_smooth) * w * p.lambda;
+    t.c01 = pw_min(fabsf(d0_ee_at_ee - d1_at_ee) + fabsf(d0_ee_at_le - d1_at_le), p.th_smooth) * w * p.lambda;
+    t.c10 = pw_min(fabsf(d1_at_ee - d0_le_at_ee) + fabsf(d1_at_le - d0_le_at_le), p.th_smooth) * w * p.lambda;
     return t;
 }
 
@@ -125,7 +127,8 @@ __global__ void les_expansion_graph_kernel(const GraphCell* __restrict__ cells, 
             const int xn = x + fdx[d], yn = y + fdy[d];
             if (xn >= 0 && xn < c.w && yn < c.h) {
                 const PwTerms s = pw_expansion_terms(labels, ipk, wtab, label1, X, Y, fdx[d], fdy[d], p);
-                cap[d] = fmaxf(0.0f, s.c10 + s.c01 - s.c00);                 // add_edge(i, j, max(0, B + C - D), 0)
+                const float bcd = s.c10 + s.c01 - s.c00;
+                cap[d] = (0.0f < bcd) ? bcd : 0.0f;                          // add_edge(i, j, std::max(0.f, B + C - D), 0)
                 t.add(s.c01, 0.0f);                                          // add_tweights(i, C, 0)
             }
         }

@@ -93,7 +93,52 @@ def one_case(rng, lib, stats):
             if not np.array_equal(g_.view(np.uint32), r_.view(np.uint32)):
                 raise AssertionError(f"post-processed labels differ ({W}x{H} windR={windR} thr={thr})")
         stats["post"] += 1
+    # graph capacities of the expansion moves: device construction vs host construction, bit for bit
+    if rng.random() < 0.35:
+        from localexpstereo_amd import gc as lgc
+        lab = np.zeros((H, W, 4), np.float32)
+        lab[..., 0] = rng.uniform(-0.05, 0.05); lab[..., 1] = rng.uniform(-0.05, 0.05); lab[..., 2] = rng.uniform(0, D)
+        for _ in range(int(rng.integers(1, 10))):
+            x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+            w, h = int(rng.integers(1, W - x0 + 1)), int(rng.integers(1, H - y0 + 1))
+            lab[y0:y0 + h, x0:x0 + w] = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-2, D + 2), 0.0)
+        cur = rng.uniform(0, th, (H, W)).astype(np.float32)
+        prop = rng.uniform(0, th, (H, W)).astype(np.float32)
+        lam, ths = float(rng.choice([0.5, 1.0, 20.0])), float(rng.choice([1.0, 0.3]))
+        mode = int(rng.integers(0, 2))
+        g = lgc.GraphCut(imL, imR, lambda_=lam, th_smooth=ths, omega=10.0, epsilon=0.01)
+        g.labels[mode][...] = lab
+        g.costs[mode][...] = cur
+        batch = api.Batch(e, frs, trs)
+        off, nn = batch.graph_offsets(), batch.graph_nodes()
+        ref_payload, _ = g.build_graphs(trs, planes, prop, off, mode=mode)
+        bufs = [api.DeviceBuffer(e, max(1, k) * 16), api.DeviceBuffer(e, H * W * 16), api.DeviceBuffer(e, H * W * 4), api.DeviceBuffer(e, H * W * 4),
+                api.DeviceBuffer(e, max(1, nn) * 20)]
+        bufs[0].upload(api._planes(planes).view(np.float32)); bufs[1].upload(lab); bufs[2].upload(cur); bufs[3].upload(prop)
+        batch.expansion_graph(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, mode=mode, lambda_=lam, th_smooth=ths, omega=10.0, epsilon=0.01)
+        e.synchronize()
+        got = bufs[4].download((nn * 5,), np.float32)
+        finite = np.isfinite(ref_payload)
+        if not (np.array_equal(got.view(np.uint32)[finite], ref_payload.view(np.uint32)[finite]) and np.array_equal(np.isnan(got), np.isnan(ref_payload))):
+            raise AssertionError(f"expansion-graph payload differs ({W}x{H}, {k} cells, mode {mode}, lambda {lam})")
+        batch.destroy()
+        for b in bufs:
+            b.free()
+        g.close()
+        stats["graphs"] = stats.get("graphs", 0) + 1
     e.close()
+    # image-based matching cost (NaiveStereoEnergy) on the same rects
+    if rng.random() < 0.3:
+        on = om.Oracle.naive(imL, imR, maxd if mind == 0 else float(D - 1), windR=windR, eps=eps)
+        en = api.HipCostVolumeEnergy.naive(imL, imR, windR=windR, eps=eps, max_disp=maxd if mind == 0 else float(D - 1), lib=lib)
+        pl = planes.copy()
+        pl[:, 2] -= mind
+        for mode in (0, 1):
+            ref = on.unary_batch(frs, trs, pl, mode=mode, check=True)
+            got = en.unary_batch(frs, trs, pl, mode=mode, check=True)
+            pc.compare_maps(got, ref, tight=False)
+        en.close()
+        stats["naive"] = stats.get("naive", 0) + 1
 
 
 def main():
@@ -115,6 +160,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps, {stats.get('naive', 0)} image-based energies, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
