@@ -183,6 +183,17 @@ __device__ __forceinline__ float guide_centred_f32(uint32_t ipk, int k)
     return k == 3 ? 1.0f : w;
 }
 // the same value from the signed 10-bit field format (one bit-field extract instead of shift / mask / shift / add)
+// H1 form without the k == 3 select: `off` = 10 * k for k < 3; the k == 3 lanes read a constant word whose field 0 is 510, and
+// (float)510 * (1/510.f) == 1.0f exactly
+__device__ __forceinline__ float guide10_field_f32(uint32_t w10, int off)
+{
+#if defined(LES_SIM)
+    const int v = ((int)(w10 << (22 - off))) >> 22;
+#else
+    const int v = __builtin_amdgcn_sbfe((int)w10, (unsigned)off, 10u);
+#endif
+    return (float)v * (1.0f / 510.0f);
+}
 __device__ __forceinline__ float guide10_centred_f32(uint32_t w10, int k)
 {
 #if defined(LES_SIM)
@@ -318,6 +329,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     __shared__ float s_T[BY][TPITCH];        // H1 sums, then (in place) vertical stage-2 sums
     __shared__ uint32_t s_ipk2[BY][TW];      // packed guide pixel of the output rows of this block
     __shared__ double s_rtab[2 * R + 2];     // 1/n, n = 0..2R+1
+    __shared__ uint32_t s_c510[WP];          // constant "guide" row of the k = 3 lanes in H1: field 0 = 510, i.e. weight 1
     // per-row scalars of phase V for the current block (written by BY lanes in phase G): without the table every lane
     // quad re-derives them on the scalar unit -- 27 SALU instructions per row that stall the three resident waves
     struct RowInfo { double rny; int flags; uint32_t soff; };      // 1/count_y; bit 0: row in clip, bit 1: t >= 2R; stats row offset of row t + PD
@@ -345,6 +357,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     const int Ttot = job.th + 4 * R;         // p-rows to march over
 
     if (tid < 2 * R + 2) s_rtab[tid] = tid > 0 ? 1.0 / (double)tid : 0.0;
+    if (tid < WP) s_c510[tid] = 510u;
 
     // ---- V-phase identity: lane quad = 4 quantities of stage-1 column vx
     const int vx = tid >> 2, vk = tid & 3;
@@ -357,6 +370,8 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     // ---- H-phase identity: (segment, row, quantity); lanes of a wave differ in row first
     const bool h_active = tid < HL;
     const int hk = tid & 3, hrow = (tid >> 2) % BY, hseg = (tid >> 2) / BY;
+    const uint32_t* h1_guide = hk < 3 ? &s_ipk[hrow][0] : &s_c510[0];   // H1: guide words of this lane's row, or the constant row
+    const int h1_off = hk < 3 ? 10 * hk : 0;
 
     __syncthreads();
     const double rnx1 = s_rtab[nx1];
@@ -490,7 +505,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
 #pragma unroll
             for (int s = 0; s < L1 + 2 * R; s++) {
                 const int xi = x0 + s;                                  // p column index
-                const float f = xi < WP ? guide10_centred_f32(s_ipk[hrow][xi], hk) * s_p[hrow][xi] : 0.0f;
+                const float f = xi < WP ? guide10_field_f32(h1_guide[xi], h1_off) * s_p[hrow][xi] : 0.0f;
                 S += (H1ACC)f - (H1ACC)ring[s % KS];
                 ring[s % KS] = f;
                 if (s >= 2 * R && x0 + s - 2 * R < WA) s_T[hrow][(x0 + s - 2 * R) * 4 + hk] = (float)S;
