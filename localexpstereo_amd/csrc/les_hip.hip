@@ -265,6 +265,17 @@ extern "C" {
 
 const char* les_hip_last_error(void) { return g_err.c_str(); }
 
+#if defined(LES_PHASE_TIMING)
+int les_hip_debug_phases(unsigned long long* out)          // experiment builds only (tools/phase_probe.py); not part of the ABI header
+{
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(les::les_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(les::les_dbg), z, sizeof z);
+    return 0;
+}
+#endif
+
 int les_hip_strip_width(int R)
 {
     const StripEntry* e = find_strip(R);

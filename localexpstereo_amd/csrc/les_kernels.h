@@ -315,6 +315,19 @@ struct StripCfg {
     static_assert(TW > 0, "strip too narrow for this radius");
 };
 
+// -DLES_PHASE_TIMING (tools/phase_probe.py builds such a variant next to the product library): lane 0 of every workgroup
+// accumulates the cycles between the barriers of the march; read back with les_hip_debug_phases().
+#if defined(LES_PHASE_TIMING) && !defined(LES_SIM)
+__device__ unsigned long long les_dbg[8];
+#define LES_PHASE_BEGIN() unsigned long long ph_[5] = {0, 0, 0, 0, 0}; unsigned long long tl_ = clock64()
+#define LES_PHASE_MARK(k) do { const unsigned long long now_ = clock64(); ph_[k] += now_ - tl_; tl_ = now_; } while (0)
+#define LES_PHASE_END() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 5; k_++) atomicAdd(&les_dbg[k_], ph_[k_]); atomicAdd(&les_dbg[5], 1ull); } } while (0)
+#else
+#define LES_PHASE_BEGIN() ((void)0)
+#define LES_PHASE_MARK(k) ((void)0)
+#define LES_PHASE_END() ((void)0)
+#endif
+
 template <int R, int WA, int BY, int SEG, int MW, int SRC = 0>       // SRC 0: cost volume, 1: image-based matching cost
 __global__ void __launch_bounds__(4 * WA, MW)
 les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
@@ -428,6 +441,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
     if (tid < TW + 4) s_rnx2[tid] = s_rtab[window_count(job.tx0 + tid, R, job.cx0, job.cx1)];
     __syncthreads();
 
+    LES_PHASE_BEGIN();
     for (int t0 = 0; t0 < Ttot; t0 += BY) {
         // ===================== G: gather =====================
         // A lane keeps its column for the whole job (column terms hoisted out of the march); the loads of
@@ -494,6 +508,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             }
         }
         __syncthreads();
+        LES_PHASE_MARK(0);
 
         // ===================== H1: horizontal sums of F_k = I'_k p =====================
         if (h_active) {
@@ -513,6 +528,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             }
         }
         __syncthreads();
+        LES_PHASE_MARK(1);
 
         // ===================== V: vertical sums, algebra, vertical sums =====================
         // Rows of a block map to compile-time ring slots: slot = (t0 % RS) + i, and t0 % RS takes only
@@ -542,6 +558,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             }
         }
         __syncthreads();
+        LES_PHASE_MARK(2);
 
         // ===================== H2: horizontal sums + guide weighting + quad reduction =====================
         if (h_active) {
@@ -575,6 +592,7 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             }
         }
         __syncthreads();
+        LES_PHASE_MARK(3);
 
         // ===================== F: store =====================
         if (tid < BY) fill_row_tables(t0 + BY);
@@ -589,7 +607,9 @@ les_strip_kernel(Geom g, View view, const Job* __restrict__ jobs, const float4* 
             }
         }
         __syncthreads();
+        LES_PHASE_MARK(4);
     }
+    LES_PHASE_END();
 }
 
 // ---------------------------------------------------------------------------------------------------

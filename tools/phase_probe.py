@@ -1,6 +1,15 @@
+"""Share of a workgroup's time spent in each phase of the strip kernel (G, H1, V, H2, F), measured with clock64() around the
+barriers in a -DLES_PHASE_TIMING build of the same sources.  Build the instrumented library first (here, or in the build
+container -- it travels with the snapshot):  python tools/phase_probe.py --build ; then on the GPU: python tools/phase_probe.py"""
 import ctypes as C, os, sys, json, subprocess
 sys.path.insert(0, os.getcwd())
-os.environ["LES_HIP_LIB"] = os.path.join(os.getcwd(), "localexpstereo_amd/csrc/exp_t.so")
+LIB = os.path.join(os.getcwd(), "localexpstereo_amd/csrc/libles_phase_timing.so")
+if "--build" in sys.argv:
+    from localexpstereo_amd import build
+    subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-DLES_PHASE_TIMING", os.path.join(build.CSRC, "les_hip.hip"), "-o", LIB], cwd=build.CSRC)
+    print("built", LIB)
+    sys.exit(0)
+os.environ["LES_HIP_LIB"] = LIB
 import torch, numpy as np
 from localexpstereo_amd import api, synth
 H, W, D = 1000, 1500, 256
