@@ -60,3 +60,59 @@ def slanted_planes(n, H, W, max_disp, seed=7):
     p = np.zeros((n, 4), np.float32)
     p[:, 0], p[:, 1], p[:, 2] = a, b, c
     return p
+
+
+# ---- synthetic stereo scene with ground truth (end-to-end runs at data-set shapes that are not in the container)
+def make_scene(H, W, D, seed=3):
+    """Piecewise-planar ground-truth disparity, textured left image, right image = left forward-warped by the ground truth
+    (z-buffered, holes filled horizontally).  Returns (imL, imR, gt)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    # piecewise planar disparity: background plane + a few slanted quadrilateral "objects"
+    gt = 0.08 * D + 0.00004 * D * xs + 0.00006 * D * ys
+    for _ in range(9):
+        cx, cy = rng.uniform(0.1, 0.9) * W, rng.uniform(0.1, 0.9) * H
+        rw, rh = rng.uniform(0.06, 0.2) * W, rng.uniform(0.08, 0.25) * H
+        m = (np.abs(xs - cx) < rw) & (np.abs(ys - cy) < rh)
+        a, b = rng.uniform(-0.03, 0.03), rng.uniform(-0.03, 0.03)
+        z = rng.uniform(0.25, 0.8) * D + a * (xs - cx) + b * (ys - cy)
+        gt = np.where(m & (z > gt), z, gt)
+    gt = np.clip(gt, 1, D - 2).astype(np.float32)
+    # texture: multi-scale noise, colour
+    tex = np.zeros((H, W, 3), np.float32)
+    for s in (2, 5, 13, 37):
+        n = rng.uniform(0, 1, (H // s + 2, W // s + 2, 3)).astype(np.float32)
+        tex += np.kron(n, np.ones((s, s, 1), np.float32))[:H, :W] / 4
+    imL = np.clip(tex * 255, 0, 255).astype(np.uint8)
+    # right view by forward warping (nearest, z-buffered by processing small disparities first), holes filled from the left
+    imR = np.zeros_like(imL)
+    filled = np.zeros((H, W), bool)
+    order = np.argsort(gt, axis=None)
+    yy, xx = np.unravel_index(order, gt.shape)
+    xr = np.rint(xx - gt[yy, xx]).astype(int)
+    ok = (xr >= 0) & (xr < W)
+    imR[yy[ok], xr[ok]] = imL[yy[ok], xx[ok]]
+    filled[yy[ok], xr[ok]] = True
+    for y in range(H):                                    # horizontal hole filling
+        row = filled[y]
+        if not row.all():
+            idx = np.where(row, np.arange(W), -1)
+            np.maximum.accumulate(idx, out=idx)
+            idx[idx < 0] = np.argmax(row)
+            imR[y] = imR[y, idx]
+    return imL, imR, gt
+
+
+def ad_volume(imL, imR, D, device):
+    """vol[d][y][x] = min(1, mean_c |L(y,x,c) - R(y,x-d,c)| / 64): a stand-in for the MC-CNN matching cost in [0,1]."""
+    import torch
+    L = torch.from_numpy(imL).to(device).float()
+    R = torch.from_numpy(imR).to(device).float()
+    H, W = L.shape[:2]
+    vol = torch.empty((D, H, W), device=device, dtype=torch.float32)
+    for d in range(D):
+        Rs = torch.roll(R, shifts=d, dims=1)
+        vol[d] = ((L - Rs).abs().mean(dim=2) / 64.0).clamp_(max=1.0)
+    return vol
+
+

@@ -223,6 +223,28 @@ def test_gpu_config1_cones_end_to_end():
     assert all(b <= a * (1 + 1e-6) for a, b in zip(en, en[1:]))
 
 
+def test_gpu_midv3_small_end_to_end(tmp_path):
+    """The MidV3 front end (LES/main.cpp:330-420) on a small synthetic scene with ground truth: raw .acrt volume file ->
+    device ingest (right volume synthesised) -> 1 PatchMatch + 2 graph-cut iterations, two views, post-processing."""
+    import torch
+    from localexpstereo_amd import io as lio
+    from localexpstereo_amd import stereo, synth
+    H, W, D = 120, 200, 32
+    imL, imR, gt = synth.make_scene(H, W, D, seed=5)
+    lio.save_cost_volume(str(tmp_path / "im0.acrt"), synth.ad_volume(imL, imR, D, "cuda").cpu().numpy())
+    volL = lio.load_cost_volume(str(tmp_path / "im0.acrt"), D, H, W)
+    volR = lio.load_cost_volume(str(tmp_path / "im1.acrt"), D, H, W)          # absent -> None -> convertVolumeL2R
+    assert volR is None
+    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    st, lab, raw = stereo.MidV3(data, volL, volR, iterations=2, pmIterations=1, doDual=True, smooth_weight=0.5, mc_threshold=0.5)
+    print([(r["index"], round(r["time"], 2), round(r["energy"]), round(r["all"], 2)) for r in st.log])
+    assert st.log[0]["all"] > 85 and st.log[-1]["all"] < 20
+    en = [r["energy"] for r in st.log[2:4]]
+    assert en[1] <= en[0] * (1 + 1e-6)
+    lio.write_pfm(str(tmp_path / "disp0.pfm"), stereo.disparities(lab))
+    assert np.array_equal(lio.read_pfm(str(tmp_path / "disp0.pfm")), stereo.disparities(lab))
+
+
 def test_gpu_ingest_files(oracle_mod, tmp_path):
     pc.case_ingest_files(None, "cuda", tmp_path, D=40, H=64, W=333)
 
