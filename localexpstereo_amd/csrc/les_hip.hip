@@ -11,6 +11,7 @@
 #include "les_pairwise.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +121,7 @@ struct les_hip_ctx {
     float4* d_wta_planes = nullptr; size_t wta_planes_cap = 0;
     // smoothness-coefficient table of the pairwise terms, cached per (omega, epsilon)
     float* d_pw_tab = nullptr; float pw_omega = -1.f, pw_epsilon = -1.f;
+    std::mutex mu;                       // guards the lazily built tables when two host threads (the two views) share the context
 };
 
 struct les_hip_batch {
@@ -465,6 +467,7 @@ int les_hip_batch_set_units(les_hip_ctx* c, les_hip_batch* b, const les_hip_rect
 int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int m, les_hip_plane* labels, uint64_t* rng,
                           les_hip_plane* planes)
 {
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !labels || !rng || !planes) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
     if (!b->d_units) return fail(LES_HIP_ERR_ARG, "les_hip_batch_set_units was not called for this batch");
@@ -499,6 +502,7 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
 int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plane* planes, float* cur, const float* prop,
                       les_hip_plane* labels)
 {
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !planes || !cur || !prop || !labels) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
     if (!b->d_targets) return fail(LES_HIP_ERR_ARG, "batch has no target table");
@@ -526,6 +530,8 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
     if (!c || !b || !d_planes || !d_labels || !d_cur || !d_prop || !d_payload) return fail(LES_HIP_ERR_ARG, "null argument");
     if (mode < 0 || mode > 1 || !c->v[mode].ipk) return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
     if (b->n == 0) return LES_HIP_OK;
+    HIPCHECK(hipSetDevice(c->p.device));                     // the calling host thread may be new (one thread per view)
+    std::unique_lock<std::mutex> lk(c->mu);
     if (c->pw_omega != omega || c->pw_epsilon != epsilon || !c->d_pw_tab) {
         // initSmoothnessCoeff (LES/StereoEnergy.h:131-163): max(epsilon, exp(-|dI|_1 / omega)) in float
         std::vector<float> tab(766);
@@ -535,6 +541,7 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
         HIPCHECK(hipStreamSynchronize(c->stream));
         c->pw_omega = omega; c->pw_epsilon = epsilon;
     }
+    lk.unlock();
     const les::PairwiseParams pp{c->p.H, c->p.W, lambda, th_smooth};
     const les::GraphCell* cells = reinterpret_cast<const les::GraphCell*>(b->d_targets);
     const long long* offs = b->d_graph_off;
@@ -561,6 +568,7 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
 int les_hip_batch_apply_masks(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plane* d_planes, const unsigned char* d_masks, float* d_cur,
                               const float* d_prop, les_hip_plane* d_labels)
 {
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !d_planes || !d_masks || !d_cur || !d_prop || !d_labels) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
     const les::GraphCell* cells = reinterpret_cast<const les::GraphCell*>(b->d_targets);
@@ -575,6 +583,7 @@ int les_hip_batch_apply_masks(les_hip_ctx* c, const les_hip_batch* b, const les_
 int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const les_hip_plane* planes, int planes_on_device,
                       float* out_dev, int check)
 {
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !out_dev || (b->n > 0 && !planes)) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->R != c->R) return fail(LES_HIP_ERR_ARG, "batch was prepared for a different context");
     const float4* d_planes = reinterpret_cast<const float4*>(planes);
