@@ -9,6 +9,8 @@
 // A pixel takes the proposal iff it ends on the SOURCE side (:555-559).
 #pragma once
 
+#include <thread>
+
 #include "GridMaxFlow.h"
 #include "StereoEnergy.h"
 
@@ -63,10 +65,10 @@ inline void buildExpansionGraph(GridMaxFlow& graph, const StereoEnergy& E, const
 }
 
 // max-flow + segment readout (LES/FastGCStereo.h:553-559)
-inline double solveExpansionGraph(GridMaxFlow& graph, const Rect& region, std::vector<uint8_t>& updateMask)
+inline double solveExpansionGraph(GridMaxFlow& graph, const Rect& region, std::vector<uint8_t>& updateMask, int bands = 1)
 {
     const int w = region.width, h = region.height;
-    const double flow = graph.maxflow();
+    const double flow = graph.maxflow(bands);
     updateMask.resize((size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) updateMask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
@@ -85,17 +87,31 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
 // The same move on a graph whose capacities were computed on the device (5 floats per node, row-major over the region;
 // include/localexp_hip.h: les_hip_batch_expansion_graph).
 // mask: region.width * region.height bytes (255 = take the proposal).  The solver object is reused per thread.
-inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, uint8_t* mask)
+// bands > 1: parallel first phase of the max-flow on that many row bands (large regions when few cells share a lock-step)
+inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, uint8_t* mask, int bands = 1)
 {
-    static thread_local GridMaxFlow graph;
+    static thread_local GridMaxFlow graph_tls;
+    GridMaxFlow& graph = graph_tls;                 // (a reference: the helper threads below must use THIS thread's solver, not their own)
     const int w = region.width, h = region.height;
     graph.reset_for_load(w, h);
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
+    // large regions: the node load and the segment read-out are split over the same number of threads as the first max-flow phase
+    auto rows_parallel = [&](auto&& body) {
+        if (bands <= 1) { body(0, h); return; }
+        std::vector<std::thread> th;
+        for (int b = 1; b < bands; b++) th.emplace_back([&, b] { body((int)((long long)h * b / bands), (int)((long long)h * (b + 1) / bands)); });
+        body(0, (int)((long long)h / bands));
+        for (auto& t : th) t.join();
+    };
+    rows_parallel([&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
+    });
     graph.set_base_flow(base_flow);
-    const double flow = graph.maxflow();
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
+    const double flow = graph.maxflow(bands);
+    rows_parallel([&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
+    });
     return flow;
 }
 inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, std::vector<uint8_t>& updateMask)

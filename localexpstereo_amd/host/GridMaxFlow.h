@@ -13,6 +13,11 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <thread>
+#ifdef LES_GMF_TRACE
+#include <chrono>
+#include <cstdio>
+#endif
 #include <limits>
 #include <vector>
 
@@ -37,10 +42,7 @@ public:
         const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
         for (int k = 0; k < 8; k++) off_[k] = o[k];
         flow_ = 0;
-        time_ = 0;
-        orphans_.clear();
-        orphan_head_ = 0;
-        queue_first_[0] = queue_first_[1] = queue_last_[0] = queue_last_[1] = NONE_NODE;
+        main_ = Ctx();
     }
     int id(int x, int y) const { return (y + 1) * pw_ + (x + 1); }
 
@@ -73,10 +75,7 @@ public:
         const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
         for (int k = 0; k < 8; k++) off_[k] = o[k];
         flow_ = 0;
-        time_ = 0;
-        orphans_.clear();
-        orphan_head_ = 0;
-        queue_first_[0] = queue_first_[1] = queue_last_[0] = queue_last_[1] = NONE_NODE;
+        main_ = Ctx();
     }
     // direct initialisation from / export to the 5-float node payload {terminal residual, caps E, S, SW, SE} produced by
     // the device (include/localexp_hip.h: les_hip_batch_expansion_graph); base_flow = flow already routed by the t-links
@@ -94,60 +93,73 @@ public:
     void set_base_flow(double f) { flow_ = f; }
     double base_flow() const { return flow_; }
 
-    double maxflow()
+    // bands > 1: parallel first phase.  The rows are cut into `bands` bands; every band runs the search on its own thread as
+    // if the arcs into the other bands did not exist (the flows found are feasible for the whole graph and the trees are
+    // valid), then one search continues on the whole graph from the union of the trees with the nodes next to the band
+    // borders re-activated (the standard "capacities increased, reuse the trees" continuation).  The final flow is a
+    // maximum flow of the whole graph, so the cut read-out is the same as for bands == 1.
+    double maxflow(int bands = 1)
     {
-        init_trees();
-        int current = NONE_NODE;
-        for (;;) {
-            int i = current;
-            if (i != NONE_NODE) {
-                nodes_[i].next_active = NOT_QUEUED;
-                if (nodes_[i].parent == P_NONE) i = NONE_NODE;
-            }
-            if (i == NONE_NODE) {
-                i = next_active();
-                if (i == NONE_NODE) break;
-            }
-            Node& ni = nodes_[i];
-            int mid_s = NONE_NODE, mid_k = 0;                   // connecting arc: S-tree node mid_s, direction mid_k
-            if (!ni.is_sink) {
-                for (int k = 0; k < 8; k++) {
-                    if (!(ni.rc[k] > 0)) continue;
-                    const int j = i + off_[k];
-                    Node& nj = nodes_[j];
-                    if (nj.parent == P_NONE) {
-                        nj.is_sink = 0; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
-                        set_active(j);
-                    } else if (nj.is_sink) { mid_s = i; mid_k = k; break; }
-                    else if (nj.ts <= ni.ts && nj.dist > ni.dist) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
-                }
-            } else {
-                for (int k = 0; k < 8; k++) {
-                    const int j = i + off_[k];
-                    Node& nj = nodes_[j];
-                    if (!(nj.rc[k ^ 1] > 0)) continue;          // residual capacity j -> i
-                    if (nj.parent == P_NONE) {
-                        nj.is_sink = 1; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
-                        set_active(j);
-                    } else if (!nj.is_sink) { mid_s = j; mid_k = k ^ 1; break; }
-                    else if (nj.ts <= ni.ts && nj.dist > ni.dist) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
-                }
-            }
-            time_++;
-            if (mid_s != NONE_NODE) {
-                ni.next_active = i;                              // stays active (not queued): more paths may start here
-                current = i;
-                augment(mid_s, mid_k);
-                while (orphan_head_ < orphans_.size()) {
-                    const int o = orphans_[orphan_head_++];
-                    if (nodes_[o].is_sink) adopt<true>(o);
-                    else adopt<false>(o);
-                }
-                orphans_.clear();
-                orphan_head_ = 0;
-            } else current = NONE_NODE;
+        if (bands > h_ / 8) bands = h_ / 8;                      // at least 8 rows per band
+        if (bands > 64) bands = 64;
+        if (bands <= 1) {
+            init_trees(main_, 0, h_);
+            search(main_);
+            return flow_ + main_.flow;
         }
-        return flow_;
+#ifdef LES_GMF_TRACE
+        const auto tt0 = std::chrono::steady_clock::now();
+#endif
+        std::vector<int> row0(bands + 1);
+        for (int b = 0; b <= bands; b++) row0[b] = (int)((long long)h_ * b / bands);
+        for (int b = 0; b < bands; b++)
+            for (int y = row0[b]; y < row0[b + 1]; y++)
+                for (int x = 0; x < w_; x++) nodes_[id(x, y)].band = (uint8_t)b;
+        markPadding();
+        std::vector<Ctx> ctx(bands);
+        std::vector<std::thread> th;
+        auto run = [&](int b) {
+#ifdef LES_GMF_TRACE
+            const auto r0 = std::chrono::steady_clock::now();
+#endif
+            ctx[b].band = b;
+            init_trees(ctx[b], row0[b], row0[b + 1]);
+#ifdef LES_GMF_TRACE
+            const auto r1 = std::chrono::steady_clock::now();
+#endif
+            search(ctx[b]);
+#ifdef LES_GMF_TRACE
+            fprintf(stderr, "  band %d: start +%.2f ms, init %.2f ms, search %.2f ms\n", b, 1e3 * std::chrono::duration<double>(r0 - tt0).count(),
+                    1e3 * std::chrono::duration<double>(r1 - r0).count(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - r1).count());
+#endif
+        };
+        for (int b = 1; b < bands; b++) th.emplace_back(run, b);
+        run(0);
+        for (auto& t : th) t.join();
+#ifdef LES_GMF_TRACE
+        const auto tt1 = std::chrono::steady_clock::now();
+        { double f1 = 0; for (int b = 0; b < bands; b++) f1 += ctx[b].flow; fprintf(stderr, "phase 1 flow %.3f, steps per band:", f1); for (int b = 0; b < bands; b++) fprintf(stderr, " %d", ctx[b].time); fprintf(stderr, "\n"); }
+#endif
+        // continuation on the whole graph
+        main_ = Ctx();
+        for (int b = 0; b < bands; b++) { main_.flow += ctx[b].flow; main_.time = std::max(main_.time, ctx[b].time); }
+        main_.time += 1;
+        main_.epoch = main_.time;
+        for (int b = 1; b < bands; b++)
+            for (int dy = -1; dy <= 0; dy++) {                   // last row of band b-1 and first row of band b
+                const int y = row0[b] + dy;
+                for (int x = 0; x < w_; x++) {
+                    const int i = id(x, y);
+                    if (nodes_[i].parent != P_NONE) set_active(main_, i);
+                }
+            }
+        search(main_);
+#ifdef LES_GMF_TRACE
+        fprintf(stderr, "phase 1 %.2f ms, phase 2 %.2f ms\n", 1e3 * std::chrono::duration<double>(tt1 - tt0).count(),
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tt1).count());
+        fprintf(stderr, "phase 2 flow %.3f steps %d\n", main_.flow, main_.time - main_.epoch);
+#endif
+        return flow_ + main_.flow;
     }
 
     termtype what_segment(int x, int y) const
@@ -167,54 +179,128 @@ private:
         int ts = 0, dist = 0;
         int8_t parent = P_NONE;                    // direction towards the tree parent, or P_TERMINAL / P_ORPHAN / P_NONE (free)
         uint8_t is_sink = 0;
+        uint8_t band = 0;                          // row band of the node (parallel first phase); padding nodes: 255
+    };
+
+    // state of one search: the whole graph, or -- in the parallel first phase -- one band of rows whose arcs into other bands
+    // are ignored
+    struct alignas(128) Ctx {                      // one cache-line pair per search: the band searches run on different cores
+        int queue_first[2] = {NONE_NODE, NONE_NODE}, queue_last[2] = {NONE_NODE, NONE_NODE};
+        std::vector<int> orphans;
+        size_t orphan_head = 0;
+        int time = 0;
+        int epoch = 0;                             // marks older than this come from another clock: not used by the re-parenting heuristic
+        double flow = 0;
+        int band = -1;                             // >= 0: restricted to this band
     };
 
     int w_, h_, pw_;
     int off_[8];
-    double flow_;
+    double flow_;                                  // flow routed by the t-links while the graph was built
     std::vector<Node> nodes_;
-    std::vector<int> orphans_;
-    size_t orphan_head_ = 0;
-    int time_ = 0;
-    int queue_first_[2] = {NONE_NODE, NONE_NODE}, queue_last_[2] = {NONE_NODE, NONE_NODE};
+    Ctx main_;
 
-    void set_active(int i)
+    void markPadding()
+    {
+        for (int x = 0; x < pw_; x++) { nodes_[x].band = 255; nodes_[(size_t)(h_ + 1) * pw_ + x].band = 255; }
+        for (int y = 1; y <= h_; y++) { nodes_[(size_t)y * pw_].band = 255; nodes_[(size_t)y * pw_ + w_ + 1].band = 255; }
+    }
+    // may the search `c` look at node j?  (whole graph: always; band search: only nodes of its band -- padding has band 255)
+    bool allowed(const Ctx& c, const Node& nj) const { return c.band < 0 || nj.band == c.band; }
+
+    void set_active(Ctx& c, int i)
     {
         if (nodes_[i].next_active != NOT_QUEUED) return;
         nodes_[i].next_active = i;
-        if (queue_last_[1] != NONE_NODE) nodes_[queue_last_[1]].next_active = i;
-        else queue_first_[1] = i;
-        queue_last_[1] = i;
+        if (c.queue_last[1] != NONE_NODE) nodes_[c.queue_last[1]].next_active = i;
+        else c.queue_first[1] = i;
+        c.queue_last[1] = i;
     }
-    int next_active()
+    int next_active(Ctx& c)
     {
         for (;;) {
-            int i = queue_first_[0];
+            int i = c.queue_first[0];
             if (i == NONE_NODE) {
-                queue_first_[0] = i = queue_first_[1];
-                queue_last_[0] = queue_last_[1];
-                queue_first_[1] = queue_last_[1] = NONE_NODE;
+                c.queue_first[0] = i = c.queue_first[1];
+                c.queue_last[0] = c.queue_last[1];
+                c.queue_first[1] = c.queue_last[1] = NONE_NODE;
                 if (i == NONE_NODE) return NONE_NODE;
             }
-            if (nodes_[i].next_active == i) queue_first_[0] = queue_last_[0] = NONE_NODE;
-            else queue_first_[0] = nodes_[i].next_active;
+            if (nodes_[i].next_active == i) c.queue_first[0] = c.queue_last[0] = NONE_NODE;
+            else c.queue_first[0] = nodes_[i].next_active;
             nodes_[i].next_active = NOT_QUEUED;
             if (nodes_[i].parent != P_NONE) return i;
         }
     }
-    void init_trees()
+    void init_trees(Ctx& c, int y0, int y1)
     {
-        for (int y = 0; y < h_; y++)
+        for (int y = y0; y < y1; y++)
             for (int x = 0; x < w_; x++) {
                 const int i = id(x, y);
                 Node& n = nodes_[i];
-                if (n.tr > 0) { n.is_sink = 0; n.parent = P_TERMINAL; n.dist = 1; set_active(i); }
-                else if (n.tr < 0) { n.is_sink = 1; n.parent = P_TERMINAL; n.dist = 1; set_active(i); }
+                if (n.tr > 0) { n.is_sink = 0; n.parent = P_TERMINAL; n.dist = 1; set_active(c, i); }
+                else if (n.tr < 0) { n.is_sink = 1; n.parent = P_TERMINAL; n.dist = 1; set_active(c, i); }
             }
     }
-    void make_orphan(int i) { nodes_[i].parent = P_ORPHAN; orphans_.push_back(i); }
+    void make_orphan(Ctx& c, int i) { nodes_[i].parent = P_ORPHAN; c.orphans.push_back(i); }
 
-    void augment(int s, int k)
+    void search(Ctx& c)
+    {
+        int current = NONE_NODE;
+        for (;;) {
+            int i = current;
+            if (i != NONE_NODE) {
+                nodes_[i].next_active = NOT_QUEUED;
+                if (nodes_[i].parent == P_NONE) i = NONE_NODE;
+            }
+            if (i == NONE_NODE) {
+                i = next_active(c);
+                if (i == NONE_NODE) break;
+            }
+            Node& ni = nodes_[i];
+            int mid_s = NONE_NODE, mid_k = 0;                   // connecting arc: S-tree node mid_s, direction mid_k
+            if (!ni.is_sink) {
+                for (int k = 0; k < 8; k++) {
+                    if (!(ni.rc[k] > 0)) continue;
+                    const int j = i + off_[k];
+                    Node& nj = nodes_[j];
+                    if (!allowed(c, nj)) continue;
+                    if (nj.parent == P_NONE) {
+                        nj.is_sink = 0; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
+                        set_active(c, j);
+                    } else if (nj.is_sink) { mid_s = i; mid_k = k; break; }
+                    else if (nj.ts <= ni.ts && nj.dist > ni.dist && nj.ts >= c.epoch) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
+                }
+            } else {
+                for (int k = 0; k < 8; k++) {
+                    const int j = i + off_[k];
+                    Node& nj = nodes_[j];
+                    if (!allowed(c, nj)) continue;              // (first: a band search must not even read another band's capacities)
+                    if (!(nj.rc[k ^ 1] > 0)) continue;          // residual capacity j -> i
+                    if (nj.parent == P_NONE) {
+                        nj.is_sink = 1; nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1;
+                        set_active(c, j);
+                    } else if (!nj.is_sink) { mid_s = j; mid_k = k ^ 1; break; }
+                    else if (nj.ts <= ni.ts && nj.dist > ni.dist && nj.ts >= c.epoch) { nj.parent = (int8_t)(k ^ 1); nj.ts = ni.ts; nj.dist = ni.dist + 1; }
+                }
+            }
+            c.time++;
+            if (mid_s != NONE_NODE) {
+                ni.next_active = i;                              // stays active (not queued): more paths may start here
+                current = i;
+                augment(c, mid_s, mid_k);
+                while (c.orphan_head < c.orphans.size()) {
+                    const int o = c.orphans[c.orphan_head++];
+                    if (nodes_[o].is_sink) adopt<true>(c, o);
+                    else adopt<false>(c, o);
+                }
+                c.orphans.clear();
+                c.orphan_head = 0;
+            } else current = NONE_NODE;
+        }
+    }
+
+    void augment(Ctx& c, int s, int k)
     {
         const int t = s + off_[k];
         float bottleneck = nodes_[s].rc[k];
@@ -222,15 +308,15 @@ private:
             const int p = nodes_[i].parent;
             if (p == P_TERMINAL) { if (bottleneck > nodes_[i].tr) bottleneck = nodes_[i].tr; break; }
             const int m = i + off_[p];
-            const float c = nodes_[m].rc[p ^ 1];                 // parent -> i
-            if (bottleneck > c) bottleneck = c;
+            const float cc = nodes_[m].rc[p ^ 1];                // parent -> i
+            if (bottleneck > cc) bottleneck = cc;
             i = m;
         }
         for (int i = t;;) {                                      // down to the sink
             const int p = nodes_[i].parent;
             if (p == P_TERMINAL) { if (bottleneck > -nodes_[i].tr) bottleneck = -nodes_[i].tr; break; }
-            const float c = nodes_[i].rc[p];
-            if (bottleneck > c) bottleneck = c;
+            const float cc = nodes_[i].rc[p];
+            if (bottleneck > cc) bottleneck = cc;
             i += off_[p];
         }
         nodes_[s].rc[k] -= bottleneck;
@@ -239,76 +325,78 @@ private:
             const int p = nodes_[i].parent;
             if (p == P_TERMINAL) {
                 nodes_[i].tr -= bottleneck;
-                if (!(nodes_[i].tr > 0)) make_orphan(i);
+                if (!(nodes_[i].tr > 0)) make_orphan(c, i);
                 break;
             }
             const int m = i + off_[p];
             nodes_[i].rc[p] += bottleneck;
             nodes_[m].rc[p ^ 1] -= bottleneck;
-            if (!(nodes_[m].rc[p ^ 1] > 0)) make_orphan(i);
+            if (!(nodes_[m].rc[p ^ 1] > 0)) make_orphan(c, i);
             i = m;
         }
         for (int i = t;;) {
             const int p = nodes_[i].parent;
             if (p == P_TERMINAL) {
                 nodes_[i].tr += bottleneck;
-                if (!(nodes_[i].tr < 0)) make_orphan(i);
+                if (!(nodes_[i].tr < 0)) make_orphan(c, i);
                 break;
             }
             const int m = i + off_[p];
             nodes_[m].rc[p ^ 1] += bottleneck;
             nodes_[i].rc[p] -= bottleneck;
-            if (!(nodes_[i].rc[p] > 0)) make_orphan(i);
+            if (!(nodes_[i].rc[p] > 0)) make_orphan(c, i);
             i = m;
         }
-        flow_ += bottleneck;
+        c.flow += bottleneck;
     }
 
-    int origin_distance(int j)
+    int origin_distance(Ctx& c, int j)
     {
         int d = 0, k = j;
         for (;;) {
-            if (nodes_[k].ts == time_) { d += nodes_[k].dist; break; }
+            if (nodes_[k].ts == c.time) { d += nodes_[k].dist; break; }
             const int p = nodes_[k].parent;
             d++;
-            if (p == P_TERMINAL) { nodes_[k].ts = time_; nodes_[k].dist = 1; break; }
+            if (p == P_TERMINAL) { nodes_[k].ts = c.time; nodes_[k].dist = 1; break; }
             if (p == P_ORPHAN || p == P_NONE) return -1;
             k += off_[p];
         }
         int dd = d;
-        for (k = j; nodes_[k].ts != time_; k += off_[nodes_[k].parent]) {
-            nodes_[k].ts = time_;
+        for (k = j; nodes_[k].ts != c.time; k += off_[nodes_[k].parent]) {
+            nodes_[k].ts = c.time;
             nodes_[k].dist = dd--;
         }
         return d;
     }
 
     template <bool SINKTREE>
-    void adopt(int i)
+    void adopt(Ctx& c, int i)
     {
         Node& ni = nodes_[i];
         int best = -1, best_d = std::numeric_limits<int>::max();
         for (int k = 0; k < 8; k++) {
             const int j = i + off_[k];
             const Node& nj = nodes_[j];
+            if (!allowed(c, nj)) continue;
             // source tree: need residual j -> i; sink tree: need residual i -> j
             if (SINKTREE ? !(ni.rc[k] > 0) : !(nj.rc[k ^ 1] > 0)) continue;
             if ((bool)nj.is_sink != SINKTREE || nj.parent == P_NONE) continue;
-            const int d = origin_distance(j);
+            const int d = origin_distance(c, j);
             if (d >= 0 && d < best_d) { best = k; best_d = d; }
         }
         if (best >= 0) {
-            ni.parent = (int8_t)best; ni.ts = time_; ni.dist = best_d + 1;
+            ni.parent = (int8_t)best; ni.ts = c.time; ni.dist = best_d + 1;
             return;
         }
         ni.ts = 0;
         for (int k = 0; k < 8; k++) {
             const int j = i + off_[k];
             Node& nj = nodes_[j];
+            if (!allowed(c, nj)) continue;
             const int pa = nj.parent;
             if ((bool)nj.is_sink == SINKTREE && pa != P_NONE) {
-                if (SINKTREE ? (ni.rc[k] > 0) : (nj.rc[k ^ 1] > 0)) set_active(j);
-                if (pa == (k ^ 1)) make_orphan(j);               // j's parent is i
+                if (SINKTREE ? (ni.rc[k] > 0) : (nj.rc[k ^ 1] > 0)) set_active(c, j);
+                if (pa == (k ^ 1)) make_orphan(c, j);            // j's parent is i
             }
         }
         ni.parent = P_NONE;

@@ -35,6 +35,15 @@ int defaultThreads(int requested, int n)
     return std::max(1, std::min(requested, n));
 }
 
+// Row bands of the parallel first max-flow phase: only for large regions (the coarsest layer: 4-6 cells of ~400 x 400 nodes per
+// lock-step, which leave most of the host idle), up to 8 bands and never more threads in total than the machine has.
+int bandsFor(const Rect& region, int cells_in_lockstep)
+{
+    if ((long long)region.width * region.height < 40000) return 1;
+    const int spare = omp_get_max_threads() / std::max(1, cells_in_lockstep);
+    return std::max(1, std::min(8, spare));
+}
+
 // the pairwise half of StereoEnergy; the unary operator lives on the GPU and is never called through this object
 class PairwiseEnergy : public StereoEnergy {
 public:
@@ -153,7 +162,7 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
     for (int i = 0; i < n; i++) {
         const Rect region(0, 0, regions[i].w, regions[i].h);
         if (region.width <= 0 || region.height <= 0) continue;
-        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, masks + offsets[i]);
+        const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, masks + offsets[i], bandsFor(region, n));
         if (flows) flows[i] = flow;
     }
     return 0;

@@ -126,6 +126,39 @@ static int grid_vs_generic()
     return fail;
 }
 
+// band-parallel first phase vs the plain search on larger random grids: identical flow and identical segments
+static int banded_vs_plain()
+{
+    RNG rng(77);
+    int fail = 0;
+    for (int trial = 0; trial < 12; trial++) {
+        const int w = rng.uniform(20, 90), h = rng.uniform(64, 200), bands = rng.uniform(2, 9);
+        GridMaxFlow a(w, h), b(w, h);
+        const int range = trial % 2 ? 6 : 100;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                // smooth-ish terminals so that flow has to travel (and cross bands), plus noise
+                const float bias = (float)((x * 7 + y * 13) % 23) - 11.0f;
+                const float s = (float)rng.uniform(0, range) + (bias > 0 ? bias : 0), t = (float)rng.uniform(0, range) + (bias < 0 ? -bias : 0);
+                a.add_tweights(x, y, s, t); b.add_tweights(x, y, s, t);
+                const int dx[4] = {1, 0, -1, 1}, dy[4] = {0, 1, 1, 1}, dir[4] = {GridMaxFlow::E, GridMaxFlow::S, GridMaxFlow::SW, GridMaxFlow::SE};
+                for (int k = 0; k < 4; k++) {
+                    const int xx = x + dx[k], yy = y + dy[k];
+                    if (xx < 0 || xx >= w || yy >= h) continue;
+                    const float c = (float)rng.uniform(0, range), r = (float)rng.uniform(0, trial % 3 ? 1 : range);
+                    a.add_edge(x, y, dir[k], c, r); b.add_edge(x, y, dir[k], c, r);
+                }
+            }
+        const double fa = a.maxflow(1), fb = b.maxflow(bands);
+        int diff = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) diff += (int)a.what_segment(x, y) != (int)b.what_segment(x, y);
+        if (fa != fb || diff) { printf("FAIL banded max-flow trial %d (%dx%d, %d bands): flow %.1f vs %.1f, %d segment differences\n", trial, w, h, bands, fa, fb, diff); fail = 1; }
+    }
+    printf("band-parallel max-flow vs plain: 12 random grids %s\n", fail ? "FAILED" : "identical");
+    return fail;
+}
+
 int main(int argc, char** argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 120, H = argc > 2 ? atoi(argv[2]) : 80, D = argc > 3 ? atoi(argv[3]) : 24;
@@ -140,6 +173,7 @@ int main(int argc, char** argv)
         Scene tiny = make_scene(16, 12, 8);
         fail |= brute_force(tiny, param, 7.0f);
         fail |= grid_vs_generic();
+        fail |= banded_vs_plain();
     }
     PMStereo st(W, H, param, maxd);
     st.setSeed(11);

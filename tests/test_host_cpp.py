@@ -127,3 +127,34 @@ def test_host_maxflow_matches_networkx(demo, tmp_path):
                     stack.append(u)
         for i in range(n):
             assert (seg[i] == 1) == (i in reach), (trial, i)
+
+
+def test_host_banded_solver_matches_plain():
+    """A region of more than 40 000 nodes goes through the band-parallel max-flow (and parallel node load / read-out) in
+    les_gc_solve_prebuilt; the same move through les_gc_expansion_moves uses the plain search.  Same labels."""
+    from localexpstereo_amd import build, gc, synth
+    build.build_host_lib()
+    H, W = 230, 260
+    im = synth.make_guide(H, W, 3)
+    rng = np.random.default_rng(4)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    lab = np.zeros((H, W, 4), np.float32)
+    lab[..., 2] = 6 + 3 * ((xs // 40 + ys // 35) % 3)
+    lab[..., 0] = 0.01
+    cur = (0.25 + 0.15 * np.sin(0.05 * xs) + rng.uniform(0, 0.03, (H, W))).astype(np.float32)
+    prop = (0.25 + 0.15 * np.cos(0.04 * ys) + rng.uniform(0, 0.03, (H, W))).astype(np.float32)
+    region = [(5, 4, 240, 215)]                                   # 51 600 nodes
+    plane = [(0.005, -0.004, 7.5, 0.0)]
+    g = gc.GraphCut(im, None, lambda_=0.3)
+    g.labels[0][...] = lab
+    g.costs[0][...] = cur
+    off = np.zeros(1, np.int64)
+    payload, flow0 = g.build_graphs(region, plane, prop, off)
+    masks = np.zeros(240 * 215, np.uint8)
+    gc.solve_prebuilt(region, payload, off, masks)               # banded: one cell, spare threads
+    gap = g.expansion_moves(region, plane, prop, check=True)     # plain search on the host-built graph
+    assert gap <= 1e-5
+    took = (g.labels[0][4:219, 5:245].view(np.uint32) != lab[4:219, 5:245].view(np.uint32)).any(axis=2)
+    assert np.array_equal(took, masks.reshape(215, 240) > 0)
+    assert 0.05 < took.mean() < 0.95                              # a real cut, crossing every band
+    g.close()
