@@ -25,7 +25,9 @@ class FastGCStereo:
         self.check_flow_energy = False
         # two-view runs: graph-cut iterations of the two views in parallel host threads.  Pays when the host cuts dominate
         # (1436 x 992: 14.2 -> 11.6 s); on small images the shared stream's synchronisations cost more (cones: 2.3 -> 3.1 s)
-        self.concurrent_views = int(np.asarray(imL).shape[0]) * int(np.asarray(imL).shape[1]) >= 500_000
+        # (never with several ranks: the per-set all-gathers of the two views would be issued from two threads in an order
+        # that differs between ranks)
+        self.concurrent_views = world == 1 and int(np.asarray(imL).shape[0]) * int(np.asarray(imL).shape[1]) >= 500_000
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
 
     def addLayer(self, unit_region_size, proposers):
