@@ -14,10 +14,6 @@
 #include <algorithm>
 #include <cstdint>
 #include <thread>
-#ifdef LES_GMF_TRACE
-#include <chrono>
-#include <cstdio>
-#endif
 #include <limits>
 #include <vector>
 
@@ -107,9 +103,6 @@ public:
             search(main_);
             return flow_ + main_.flow;
         }
-#ifdef LES_GMF_TRACE
-        const auto tt0 = std::chrono::steady_clock::now();
-#endif
         std::vector<int> row0(bands + 1);
         for (int b = 0; b <= bands; b++) row0[b] = (int)((long long)h_ * b / bands);
         for (int b = 0; b < bands; b++)
@@ -119,27 +112,13 @@ public:
         std::vector<Ctx> ctx(bands);
         std::vector<std::thread> th;
         auto run = [&](int b) {
-#ifdef LES_GMF_TRACE
-            const auto r0 = std::chrono::steady_clock::now();
-#endif
             ctx[b].band = b;
             init_trees(ctx[b], row0[b], row0[b + 1]);
-#ifdef LES_GMF_TRACE
-            const auto r1 = std::chrono::steady_clock::now();
-#endif
             search(ctx[b]);
-#ifdef LES_GMF_TRACE
-            fprintf(stderr, "  band %d: start +%.2f ms, init %.2f ms, search %.2f ms\n", b, 1e3 * std::chrono::duration<double>(r0 - tt0).count(),
-                    1e3 * std::chrono::duration<double>(r1 - r0).count(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - r1).count());
-#endif
         };
         for (int b = 1; b < bands; b++) th.emplace_back(run, b);
         run(0);
         for (auto& t : th) t.join();
-#ifdef LES_GMF_TRACE
-        const auto tt1 = std::chrono::steady_clock::now();
-        { double f1 = 0; for (int b = 0; b < bands; b++) f1 += ctx[b].flow; fprintf(stderr, "phase 1 flow %.3f, steps per band:", f1); for (int b = 0; b < bands; b++) fprintf(stderr, " %d", ctx[b].time); fprintf(stderr, "\n"); }
-#endif
         // continuation on the whole graph
         main_ = Ctx();
         for (int b = 0; b < bands; b++) { main_.flow += ctx[b].flow; main_.time = std::max(main_.time, ctx[b].time); }
@@ -154,11 +133,6 @@ public:
                 }
             }
         search(main_);
-#ifdef LES_GMF_TRACE
-        fprintf(stderr, "phase 1 %.2f ms, phase 2 %.2f ms\n", 1e3 * std::chrono::duration<double>(tt1 - tt0).count(),
-                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tt1).count());
-        fprintf(stderr, "phase 2 flow %.3f steps %d\n", main_.flow, main_.time - main_.epoch);
-#endif
         return flow_ + main_.flow;
     }
 
