@@ -17,7 +17,8 @@ dev = torch.device("cuda", 0)
 guide = synth.make_guide(H, W, 1234)
 vol = torch.rand((D, H, W), device=dev, dtype=torch.float32)
 e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1, volumes_on_device=True, shape=(D, H, W))
-planes = torch.from_numpy(synth.fronto_planes(D)).to(dev)
+slanted = "--slanted" in sys.argv
+planes = torch.from_numpy(synth.slanted_planes(D, H, W, D - 1, seed=7) if slanted else synth.fronto_planes(D)).to(dev)
 out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
 full = [(0, 0, W, H)] * D
 b = api.Batch(e, full, full, out_slabs=True)
