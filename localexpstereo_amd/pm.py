@@ -142,6 +142,31 @@ class PMRunner:
         self._sync()
         self._exchange(sh)
 
+    def init_from_labels(self, labels, rows_per_launch=64):
+        """The warm-start branch of initCurrentFast (LES/FastGCStereo.h:116-130, "very slow" on the CPU): start from a
+        given H x W x 4 label map; the current cost of every pixel is the unary cost of its own label, evaluated with
+        a 1 x 1 target and the filter region pixel +- windR -- one job per pixel, `rows_per_launch` image rows per launch."""
+        lab = torch.as_tensor(np.ascontiguousarray(labels, np.float32)).to(self.device)
+        assert tuple(lab.shape) == (self.H, self.W, 4)
+        self.labels.copy_(lab)
+        R, W, H = self.e.params.windR, self.W, self.H
+        xs = np.arange(W, dtype=np.int32)
+        x0, x1 = np.maximum(xs - R, 0), np.minimum(xs + R + 1, W)
+        for ya in range(0, H, rows_per_launch):
+            yb = min(H, ya + rows_per_launch)
+            ys = np.arange(ya, yb, dtype=np.int32)
+            y0, y1 = np.maximum(ys - R, 0), np.minimum(ys + R + 1, H)
+            fr = np.stack([np.broadcast_to(x0, (yb - ya, W)), np.broadcast_to(y0[:, None], (yb - ya, W)),
+                           np.broadcast_to(x1 - x0, (yb - ya, W)), np.broadcast_to((y1 - y0)[:, None], (yb - ya, W))], -1).reshape(-1, 4)
+            tr = np.stack([np.broadcast_to(xs, (yb - ya, W)), np.broadcast_to(ys[:, None], (yb - ya, W)),
+                           np.ones((yb - ya, W), np.int32), np.ones((yb - ya, W), np.int32)], -1).reshape(-1, 4)
+            b = api.Batch(self.e, np.ascontiguousarray(fr, np.int32), np.ascontiguousarray(tr, np.int32))
+            b.run(self.labels[ya:yb].data_ptr(), self.cur.data_ptr(), mode=self.mode, check=True, planes_on_device=True)
+            self._sync()
+            b.destroy()
+        if self.world > 1:
+            pass        # every rank evaluates the whole map here (replicated state, nothing to exchange)
+
     def iteration(self, iteration):
         """One PatchMatch iteration over all layers (LES/FastGCStereo.h:143-157 with doGC == false)."""
         for li, layer in enumerate(self.shards):

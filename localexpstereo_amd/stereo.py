@@ -65,9 +65,10 @@ class FastGCStereo:
             row["all"], row["nonocc"] = self.evaluator.evaluate(d)
         self.log.append(row)
 
-    def run(self, maxIteration, viewModes=(0,), pmInit=0):
+    def run(self, maxIteration, viewModes=(0,), pmInit=0, labeling=None):
         """FastGCStereo::run (LES/FastGCStereo.h:133-227).  Returns (labeling, rawlabeling) of the left view as
-        H x W x 4 float arrays (the raw one is the labelling before the two-view post-processing)."""
+        H x W x 4 float arrays (the raw one is the labelling before the two-view post-processing).  `labeling`: optional
+        start labelling (the reference's `labeling` argument; every view starts from it, as in the reference)."""
         t0 = time.perf_counter()
         self.eval_seconds = 0.0
         runners = {m: pm.PMRunner(self.e, self.units, self.table, seed=self.seed + 7919 * m, rank=self.rank, world=self.world,
@@ -75,7 +76,10 @@ class FastGCStereo:
         g = gc.GraphCut(self.imL, self.imR, lambda_=self.p["lambda_"], th_smooth=self.p["th_smooth"], omega=self.p["omega"],
                         epsilon=self.p["epsilon"]) if maxIteration > 0 else None
         for m in viewModes:
-            runners[m].init_labels()
+            if labeling is None:
+                runners[m].init_labels()
+            else:
+                runners[m].init_from_labels(labeling)          # warm start from a given labelling (LES/FastGCStereo.h:116-130)
             self._evaluate(0, m, runners[m], None, t0)
         for it in range(pmInit):
             for m in viewModes:

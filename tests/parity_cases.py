@@ -876,3 +876,27 @@ def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
             b.free()
     g.close()
     return worst_cells
+
+
+def case_warm_start(lib, device):
+    """initCurrentFast from a given labelling (LES/FastGCStereo.h:116-130): per-pixel 1 x 1 targets."""
+    from localexpstereo_amd import pm
+    H, W, D = 40, 52, 12
+    imL = synth.make_guide(H, W, 5)
+    vol = synth.make_volume(D, H, W, 6)
+    o = om.Oracle(imL, None, vol, None, windR=8, eps=1e-4, th_col=0.5, max_disp=D - 1.0)
+    e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=8, eps=1e-4, th_col=0.5, max_disp=D - 1.0, lib=lib)
+    labels = _label_map(H, W, D, 3, noise=0.3).view(np.float32).reshape(H, W, 4)
+    labels[3, 4] = (0.0, 0.0, 500.0, 0.0)                       # an invalid label: sentinel expected
+    r = pm.PMRunner(e, (8,), [[(api.PROPOSE_EXPANSION, 1)]], seed=1, device=device)
+    r.init_from_labels(labels, rows_per_launch=7)
+    got = r.cur.cpu().numpy()
+    ref = np.zeros((H, W), np.float32)
+    for y in range(H):
+        for x in range(W):
+            fr = (max(x - 8, 0), max(y - 8, 0), min(x + 9, W) - max(x - 8, 0), min(y + 9, H) - max(y - 8, 0))
+            ref[y, x] = o.unary(fr, (x, y, 1, 1), tuple(labels[y, x]), check=True)[y, x]
+    assert got[3, 4] == np.float32(1e6)
+    assert np.array_equal(r.labels.cpu().numpy(), labels)
+    r.close(); e.close()
+    return compare_maps(got, ref)

@@ -74,6 +74,10 @@ def test_gpu_empty_and_errors(cones):
     pc.case_empty_and_errors(cones)
 
 
+def test_gpu_warm_start(oracle_mod):
+    pc.case_warm_start(None, "cuda")
+
+
 def test_gpu_widened_abi_errors(oracle_mod):
     pc.case_widened_abi_errors(None)
 

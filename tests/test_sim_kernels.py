@@ -102,6 +102,10 @@ def test_sim_empty_and_errors(cones):
     pc.case_empty_and_errors(cones)
 
 
+def test_sim_warm_start(sim_lib, oracle_mod):
+    pc.case_warm_start(sim_lib, "cpu")
+
+
 def test_sim_widened_abi_errors(sim_lib, oracle_mod):
     pc.case_widened_abi_errors(sim_lib)
 
