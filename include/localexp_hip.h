@@ -96,6 +96,11 @@ int les_hip_batch_create(les_hip_ctx* ctx, int n, const les_hip_rect* filterRect
                          int out_slabs, les_hip_batch** out);
 void les_hip_batch_destroy(les_hip_batch* b);
 int les_hip_batch_num_jobs(const les_hip_batch* b);     /* workgroups one run launches                   */
+/* Diagnostic: which kernel les_hip_batch_run launches for this batch and view: 1 = the fixed-point march kernel
+ * (csrc/les_march.h; needs a finite volume with th_col - min <= 8 th_col, radius 10 and every target at least windR away from
+ * filterRect borders that are not image borders -- the geometry of every LayerManager cell), 0 = the fp64 strip kernel
+ * (csrc/les_kernels.h; any input), -1 = bad argument.  Both implement LES/CostVolumeEnergy.h:55-183. */
+int les_hip_batch_kernel_kind(const les_hip_ctx* ctx, const les_hip_batch* b, int mode);
 /* planes: n labels, HOST (planes_on_device == 0) or DEVICE memory; out: DEVICE memory.  Asynchronous
  * on the context's stream. */
 int les_hip_batch_run(les_hip_ctx* ctx, const les_hip_batch* b, int mode, const les_hip_plane* planes,

@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
     "les_hip_calib_copy", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
@@ -81,6 +81,7 @@ def load(path=None):
         "les_hip_batch_create": (ci, [vp, ci, vp, vp, ci, C.POINTER(vp)]),
         "les_hip_batch_destroy": (None, [vp]),
         "les_hip_batch_num_jobs": (ci, [vp]),
+        "les_hip_batch_kernel_kind": (ci, [vp, vp, ci]),
         "les_hip_batch_run": (ci, [vp, vp, ci, vp, ci, vp, ci]),
         "les_hip_batch_set_units": (ci, [vp, vp, vp]),
         "les_hip_batch_propose": (ci, [vp, vp, ci, ci, vp, vp, vp]),
@@ -186,6 +187,10 @@ class Batch:
     @property
     def num_jobs(self):
         return self.e.L.les_hip_batch_num_jobs(self.h)
+
+    def kernel_kind(self, mode=0):
+        """1: the fixed-point march kernel serves this batch, 0: the fp64 strip kernel."""
+        return self.e.L.les_hip_batch_kernel_kind(self.e.h, self.h, mode)
 
     def run(self, planes, out_dev_ptr, mode=0, check=True, planes_on_device=False):
         """planes: host array (n,4) or a device pointer (int) when planes_on_device; out_dev_ptr: int."""

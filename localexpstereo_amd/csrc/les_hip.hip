@@ -6,6 +6,7 @@
 // (tools/hipsim compiles this same file against a CPU fiber simulator for logic tests only.)
 #include "../../include/localexp_hip.h"
 #include "les_kernels.h"
+#include "les_march.h"
 #include "les_propose.h"
 #include "les_post.h"
 #include "les_pairwise.h"
@@ -91,6 +92,23 @@ const StripEntry* find_strip(int R)
     return def;
 }
 
+// ---- the fixed-point march kernel (les_march.h): (radius, columns per job slot, job slots per workgroup, rows per block, waves/SIMD)
+typedef void (*MarchKernel)(les::Geom, les::MarchView, const les::Job*, const float4*, float*, int, int);
+struct MarchEntry { int R; int TW; int NJ; int NT; MarchKernel fn; };
+#define LES_MARCH_ENTRY(R_, WGC_, NJ_, BY_, MW_) \
+    { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, les::les_march_kernel<R_, WGC_, NJ_, BY_, MW_> }
+const MarchEntry kMarch[] = {
+    LES_MARCH_ENTRY(10, 128, 2, 7, 2),
+};
+static_assert((2 * 10 + 1) * (2 * 10 + 1) * (1ll << les::kMarchPB) < (1ll << 31), "stage-1 box sums must fit int32");
+const MarchEntry* find_march(int R)
+{
+    if (const char* k = getenv("LES_HIP_KERNEL")) if (!strcmp(k, "strip")) return nullptr;     // A/B measurements: force the fp64 strip kernel
+    for (const auto& e : kMarch)
+        if (e.R == R) return &e;
+    return nullptr;
+}
+
 constexpr int kRansacMaxSam = 500;   // RansacProposer default MAX_SAM, LES/Proposer.h:265
 
 struct ViewData {
@@ -100,6 +118,11 @@ struct ViewData {
     uint32_t* ipk = nullptr;
     uint32_t* ipk10 = nullptr;           // the guide pixel as signed 10-bit fields (H1 operand format of the strip kernel)
     float4* feat = nullptr;              // NaiveStereoEnergy feature image (image-based matching cost)
+    // march kernel (les_march.h): guide as signed bytes, statistics in its format, cost range of the volume
+    uint32_t* ipk8 = nullptr;
+    float4* mstats = nullptr;
+    bool march_ok = false;               // volume finite, range condition met, tables built
+    les::MarchView mv = {};
 };
 
 }  // namespace
@@ -108,6 +131,7 @@ struct les_hip_ctx {
     les_hip_params p;
     int R;
     const StripEntry* strip;
+    const MarchEntry* march = nullptr;   // null: radius not instantiated (or LES_HIP_KERNEL=strip)
     hipStream_t stream;
     les::Geom geom;
     ViewData v[2];
@@ -127,6 +151,11 @@ struct les_hip_ctx {
 struct les_hip_batch {
     int n = 0, njobs = 0, out_slabs = 0, R = 0;
     les::Job* d_jobs = nullptr;
+    // the same calls cut for the march kernel (groups of NJ jobs); march_ok: every target keeps 2R distance from clip borders
+    // that are not image borders, so the kernel's bound on |a| holds (les_march.h)
+    les::Job* d_mjobs = nullptr;
+    int nmgroups = 0;
+    bool march_ok = false;
     std::vector<les_hip_rect> targets;
     int device = 0;
     // cell geometry for the proposers / WTA
@@ -197,6 +226,67 @@ int build_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_h
     return LES_HIP_OK;
 }
 
+// The same calls cut for the march kernel: balanced strips of at most TW columns (a 45-column target becomes 23 + 22, never
+// 44 + 1), groups of NJ consecutive jobs per workgroup (padded with empty jobs), and the geometric precondition of the kernel.
+bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs,
+                      std::vector<les::Job>& jobs, bool& ok)
+{
+    const MarchEntry* m = c->march;
+    jobs.clear();
+    ok = false;
+    if (!m) return true;
+    const int TW = m->TW, R = c->R, NJ = m->NJ, W = c->p.W, H = c->p.H;
+    const long long P = (long long)H * W;
+    ok = true;
+    long long strips = 0;
+    int tallest = 0;
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect &f = frs[i], &t = trs[i];
+        if (t.w <= 0 || t.h <= 0) continue;
+        if ((f.x > 0 && t.x - f.x < 2 * R) || (f.x + f.w < W && (f.x + f.w) - (t.x + t.w) < 2 * R) ||
+            (f.y > 0 && t.y - f.y < 2 * R) || (f.y + f.h < H && (f.y + f.h) - (t.y + t.h) < 2 * R)) ok = false;
+        strips += (t.w + TW - 1) / TW;
+        tallest = std::max(tallest, t.h);
+    }
+    if (!ok) return true;
+    // row chunking as in build_jobs: few strips -> split tall targets so that every CU gets several workgroups
+    int max_rows = 1 << 30;
+    const long long want_jobs = 1536ll * NJ;
+    if (strips > 0 && strips < want_jobs) {
+        const long long want = (want_jobs + strips - 1) / strips;
+        max_rows = (int)std::max<long long>(std::max(16 * R, 128), (tallest + want - 1) / want);
+    }
+    if (const char* e = getenv("LES_HIP_MARCH_ROWS")) max_rows = std::max(1, atoi(e));
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect &f = frs[i], &t = trs[i];
+        if (t.w <= 0 || t.h <= 0) continue;
+        const int ns = (t.w + TW - 1) / TW, sw = (t.w + ns - 1) / ns;
+        const int nr = (t.h + max_rows - 1) / max_rows, sh = (t.h + nr - 1) / nr;
+        for (int sy = 0; sy < t.h; sy += sh)
+            for (int sx = 0; sx < t.w; sx += sw) {
+                les::Job j;
+                j.tx0 = t.x + sx; j.ty0 = t.y + sy;
+                j.tw = std::min(sw, t.w - sx); j.th = std::min(sh, t.h - sy);
+                j.cx0 = f.x; j.cy0 = f.y; j.cx1 = f.x + f.w; j.cy1 = f.y + f.h;
+                j.out_off = (out_slabs ? (long long)i * P : 0) + (long long)j.ty0 * W + j.tx0;
+                j.out_stride = W;
+                j.plane_idx = i;
+                jobs.push_back(j);
+            }
+    }
+    std::stable_sort(jobs.begin(), jobs.end(), [](const les::Job& a, const les::Job& b) {
+        if (a.tx0 != b.tx0) return a.tx0 < b.tx0;
+        if (a.ty0 != b.ty0) return a.ty0 < b.ty0;
+        return a.plane_idx < b.plane_idx;
+    });
+    while (!jobs.empty() && jobs.size() % NJ) {
+        les::Job pad = jobs.back();
+        pad.tw = 0; pad.th = 0;
+        jobs.push_back(pad);
+    }
+    return true;
+}
+
 int ensure_planes(les_hip_ctx* c, size_t n)
 {
     if (n <= c->planes_cap) return LES_HIP_OK;
@@ -205,6 +295,14 @@ int ensure_planes(les_hip_ctx* c, size_t n)
     size_t cap = std::max<size_t>(n, 1024);
     HIPCHECK(hipMalloc((void**)&c->d_planes, cap * sizeof(float4)));
     c->planes_cap = cap;
+    return LES_HIP_OK;
+}
+
+int launch_march(les_hip_ctx* c, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check)
+{
+    if (ngroups <= 0) return LES_HIP_OK;
+    hipLaunchKernelGGL(c->march->fn, dim3(ngroups), dim3(c->march->NT), 0, c->stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
+    HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
 
@@ -221,6 +319,64 @@ int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, c
 }
 
 float naive_alpha(const les_hip_ctx* c);
+
+// Tables and constants of the march kernel for view m (les_march.h): statistics in its format, the guide as signed bytes,
+// the cost range of the volume and the stage-2 scale from the bound |a_c| <= sqrt(inv_cc) * sd(p) <= sqrt(max inv_cc) * range / 2.
+int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
+{
+    ViewData& v = c->v[m];
+    const size_t P = (size_t)c->p.H * c->p.W;
+    const int W = c->p.W, H = c->p.H;
+    v.march_ok = false;
+    const float th = c->p.th_col;
+    if (!(th > 0.0f) || !(th < INFINITY)) return LES_HIP_OK;
+    // cost range
+    const int nb = 2048;
+    float* d_min = nullptr; int* d_bad = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_min, nb * sizeof(float)));
+    HIPCHECK(hipMalloc((void**)&d_bad, nb * sizeof(int)));
+    hipLaunchKernelGGL(les::les_range_kernel, dim3(nb), dim3(256), 0, c->stream, v.vol, P * (size_t)c->p.D, d_min, d_bad);
+    std::vector<float> hmin(nb); std::vector<int> hbad(nb);
+    HIPCHECK(hipMemcpyAsync(hmin.data(), d_min, nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(hbad.data(), d_bad, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipFree(d_min)); HIPCHECK(hipFree(d_bad));
+    float vmin = INFINITY; int bad = 0;
+    for (int i = 0; i < nb; i++) { vmin = std::min(vmin, hmin[i]); bad |= hbad[i]; }
+    if (bad || !(vmin < INFINITY)) return LES_HIP_OK;              // NaN / inf costs: the fp64 strip kernel reproduces the reference's propagation
+    vmin = std::min(vmin, 0.5f * th);                                // a volume entirely above th_col: p == th_col everywhere
+    const double range = (double)th - (double)vmin;
+    if (!(range <= 8.0 * (double)th)) return LES_HIP_OK;            // the 22-bit fixed point would resolve th_col too coarsely
+    // tables
+    unsigned* d_dmax = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_dmax, sizeof(unsigned)));
+    HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), c->stream));
+    HIPCHECK(hipMalloc((void**)&v.ipk8, P * sizeof(uint32_t)));
+    HIPCHECK(hipMalloc((void**)&v.mstats, P * 3 * sizeof(float4)));
+    hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
+    HIPCHECK(hipGetLastError());
+    unsigned dbits = 0;
+    HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipFree(d_dmax));
+    float dmax;
+    memcpy(&dmax, &dbits, sizeof dmax);
+    if (!(dmax > 0.0f) || !(dmax < INFINITY)) return LES_HIP_OK;
+    const int K = 2 * c->R + 1;
+    const double Ba = 0.5 * range * std::sqrt((double)dmax), Bb = range + 1.5 * Ba;
+    const double scale = 1073741824.0 / ((double)K * Bb * 1.25);    // horizontal box sums of the quantised a, b stay below 2^30
+    const double up = range / (double)((1 << les::kMarchPB) - 1);
+    les::MarchView mv;
+    mv.vol = v.vol; mv.ipk8 = v.ipk8; mv.mstats = v.mstats;
+    mv.vmin = vmin;
+    mv.sp = (float)((double)((1 << les::kMarchPB) - 1) / range);
+    mv.kapS = (float)((double)(1 << les::kMarchSH) * up / 255.0 * scale);
+    mv.upS = (float)(up * scale);
+    mv.qscale = 1.0 / (255.0 * scale);
+    v.mv = mv;
+    v.march_ok = true;
+    return LES_HIP_OK;
+}
 
 int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
 {
@@ -253,6 +409,10 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, v.ipk, d_hs, H, W, c->R);
     hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.stats, H, W, c->R, c->p.eps);
     HIPCHECK(hipGetLastError());
+    if (c->march && v.vol) {
+        int rc = build_march_view(c, m, d_hs);
+        if (rc) { (void)hipFree(d_img); (void)hipFree(d_hs); return rc; }
+    }
     HIPCHECK(hipStreamSynchronize(c->stream));
     HIPCHECK(hipFree(d_img));
     HIPCHECK(hipFree(d_hs));
@@ -304,6 +464,7 @@ static int create_common(les_hip_ctx** out, const les_hip_params* params, const 
     c->p = p;
     c->R = p.windR / 2;
     c->strip = strip;
+    c->march = naive ? nullptr : find_march(p.windR / 2);
     c->stream = nullptr;
     c->geom.H = p.H; c->geom.W = p.W; c->geom.D = p.D;
     c->geom.D0 = (int)(-p.min_disparity);                       // LES/CostVolumeEnergy.h:67
@@ -350,6 +511,8 @@ void les_hip_destroy(les_hip_ctx* c)
         if (c->v[m].ipk) (void)hipFree(c->v[m].ipk);
         if (c->v[m].ipk10) (void)hipFree(c->v[m].ipk10);
         if (c->v[m].feat) (void)hipFree(c->v[m].feat);
+        if (c->v[m].ipk8) (void)hipFree(c->v[m].ipk8);
+        if (c->v[m].mstats) (void)hipFree(c->v[m].mstats);
     }
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_map) (void)hipFree(c->d_map);
@@ -408,6 +571,20 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
             return fail(LES_HIP_ERR_DEVICE, "upload of the target table failed");
         }
     }
+    {
+        std::vector<les::Job> mjobs;
+        bool mok = false;
+        build_march_jobs(c, n, frs, trs, out_slabs, mjobs, mok);
+        if (mok && !mjobs.empty()) {
+            if (hipMalloc((void**)&b->d_mjobs, mjobs.size() * sizeof(les::Job)) != hipSuccess ||
+                hipMemcpy(b->d_mjobs, mjobs.data(), mjobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
+                les_hip_batch_destroy(b);
+                return fail(LES_HIP_ERR_DEVICE, "upload of the march job table failed");
+            }
+            b->nmgroups = (int)(mjobs.size() / c->march->NJ);
+            b->march_ok = true;
+        }
+    }
     if (!jobs.empty()) {
         if (hipMalloc((void**)&b->d_jobs, jobs.size() * sizeof(les::Job)) != hipSuccess) { les_hip_batch_destroy(b); return fail(LES_HIP_ERR_DEVICE, "hipMalloc(jobs) failed"); }
         if (hipMemcpy(b->d_jobs, jobs.data(), jobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
@@ -422,6 +599,7 @@ void les_hip_batch_destroy(les_hip_batch* b)
 {
     if (!b) return;
     if (b->d_jobs) (void)hipFree(b->d_jobs);
+    if (b->d_mjobs) (void)hipFree(b->d_mjobs);
     if (b->d_units) (void)hipFree(b->d_units);
     if (b->d_targets) (void)hipFree(b->d_targets);
     if (b->d_graph_off) (void)hipFree(b->d_graph_off);
@@ -512,7 +690,13 @@ int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plan
     return LES_HIP_OK;
 }
 
-int les_hip_batch_num_jobs(const les_hip_batch* b) { return b ? b->njobs : 0; }
+int les_hip_batch_num_jobs(const les_hip_batch* b) { return b ? (b->march_ok ? b->nmgroups : b->njobs) : 0; }
+
+int les_hip_batch_kernel_kind(const les_hip_ctx* c, const les_hip_batch* b, int mode)
+{
+    if (!c || !b || mode < 0 || mode > 1) return -1;
+    return (b->march_ok && c->march && c->v[mode].march_ok) ? 1 : 0;
+}
 
 long long les_hip_batch_graph_nodes(const les_hip_batch* b) { return b ? b->graph_nodes : 0; }
 
@@ -593,6 +777,8 @@ int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const le
         HIPCHECK(hipMemcpyAsync(c->d_planes, planes, (size_t)b->n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         d_planes = c->d_planes;
     }
+    if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok)
+        return launch_march(c, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check);
     return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check);
 }
 

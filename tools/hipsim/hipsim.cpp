@@ -42,6 +42,19 @@ void quad_sync()
     while (B->quad_gen[q] == g) yield_to_sched();
 }
 
+void group16_sync()
+{
+    Block* B = g_block;
+    const int q = B->current >> 4;
+    const unsigned g = B->g16_gen[q];
+    if (++B->g16_count[q] == 16) {
+        B->g16_count[q] = 0;
+        B->g16_gen[q]++;
+        return;
+    }
+    while (B->g16_gen[q] == g) yield_to_sched();
+}
+
 static void fiber_entry()
 {
     Block* B = g_block;
@@ -69,6 +82,8 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
         B->quad_count.resize((n + 3) / 4);
         B->quad_gen.resize((n + 3) / 4);
         B->exch.resize(n);
+        B->g16_count.resize((n + 15) / 16);
+        B->g16_gen.resize((n + 15) / 16);
     }
     B->body = body;
     B->alive = n;
@@ -76,6 +91,8 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     B->bar_gen = 0;
     std::fill(B->quad_count.begin(), B->quad_count.end(), 0u);
     std::fill(B->quad_gen.begin(), B->quad_gen.end(), 0u);
+    std::fill(B->g16_count.begin(), B->g16_count.end(), 0u);
+    std::fill(B->g16_gen.begin(), B->g16_gen.end(), 0u);
     std::fill(B->done.begin(), B->done.end(), 0);
     gridDim = grid;
     blockDim = block;

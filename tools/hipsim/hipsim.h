@@ -73,6 +73,7 @@ struct Block {
     std::vector<char> stacks;
     unsigned bar_count = 0, bar_gen = 0;
     std::vector<unsigned> quad_count, quad_gen;
+    std::vector<unsigned> g16_count, g16_gen;
     std::vector<uint64_t> exch;
     std::function<void()> body;
 };
@@ -81,6 +82,7 @@ extern thread_local Block* g_block;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void sync_block();
 void quad_sync();
+void group16_sync();
 
 template <typename T>
 inline void quad_allgather(T v, T out[4])
@@ -96,7 +98,31 @@ inline void quad_allgather(T v, T out[4])
     quad_sync();
 }
 
+// exchange among the 16 work-items of a DPP row (lanes 16r .. 16r+15): every one of them must call it
+template <typename T>
+inline void group16_allgather(T v, T out[16])
+{
+    static_assert(sizeof(T) <= 8, "row exchange of <= 8 byte values");
+    Block* B = g_block;
+    const int tid = B->current;
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    B->exch[tid] = bits;
+    group16_sync();
+    for (int j = 0; j < 16; j++) memcpy(&out[j], &B->exch[(tid & ~15) + j], sizeof(T));
+    group16_sync();
+}
+
 }  // namespace hipsim
+
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned atomicMax(unsigned* p, unsigned v)
+{
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 static inline void __syncthreads() { hipsim::sync_block(); }
 

@@ -31,4 +31,7 @@ for it in range(2):
     L.les_hip_debug_phases(buf)
     v = [buf[i] for i in range(6)]
     tot = sum(v[:5])
-    print("WGs", v[5], "cycles per WG", tot / v[5], "phase shares G/H1/V/H2/F:", [round(100.0 * x / tot, 1) for x in v[:5]], "per block-phase cycles", [round(x / v[5] / 49.5) for x in v[:5]])
+    kind = b.kernel_kind(0)
+    nblk = (H + 40 + 6) // 7 if kind == 1 else 49.5
+    print("kernel", "march (phases A/B1/C/B2/D)" if kind == 1 else "strip (phases G/H1/V/H2/F)", "WGs", v[5], "cycles per WG", tot / v[5], "phase shares:", [round(100.0 * x / tot, 1) for x in v[:5]],
+          "per block-phase cycles", [round(x / v[5] / nblk) for x in v[:5]])
