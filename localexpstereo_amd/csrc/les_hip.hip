@@ -92,21 +92,26 @@ const StripEntry* find_strip(int R)
     return def;
 }
 
-// ---- the fixed-point march kernel (les_march.h): (radius, columns per job slot, job slots per workgroup, rows per block, waves/SIMD)
+// ---- the fixed-point march kernel (les_march.h): (radius, columns per job slot, job slots per workgroup, rows per block)
 typedef void (*MarchKernel)(les::Geom, les::MarchView, const les::Job*, const float4*, float*, int, int);
 struct MarchEntry { int R; int TW; int NJ; int NT; MarchKernel fn; };
-#define LES_MARCH_ENTRY(R_, WGC_, NJ_, BY_, MW_) \
-    { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, les::les_march_kernel<R_, WGC_, NJ_, BY_, MW_> }
+#define LES_MARCH_ENTRY(R_, WGC_, NJ_, BY_) \
+    { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, les::les_march_kernel<R_, WGC_, NJ_, BY_> }
+// two geometries per radius: wide jobs (216 output columns: whole-image hypothesis slabs, layer-1/2 cells) and two narrow jobs
+// per workgroup (88 output columns each: layer-0 cells); both run 12 waves per workgroup
 const MarchEntry kMarch[] = {
-    LES_MARCH_ENTRY(10, 128, 2, 7, 2),
+    LES_MARCH_ENTRY(10, 256, 1, 7),
+    LES_MARCH_ENTRY(10, 128, 2, 7),
 };
 static_assert((2 * 10 + 1) * (2 * 10 + 1) * (1ll << les::kMarchPB) < (1ll << 31), "stage-1 box sums must fit int32");
-const MarchEntry* find_march(int R)
+// wide != 0: the entry with the widest jobs, else the one with the narrowest
+const MarchEntry* find_march(int R, int wide = 1)
 {
     if (const char* k = getenv("LES_HIP_KERNEL")) if (!strcmp(k, "strip")) return nullptr;     // A/B measurements: force the fp64 strip kernel
+    const MarchEntry* best = nullptr;
     for (const auto& e : kMarch)
-        if (e.R == R) return &e;
-    return nullptr;
+        if (e.R == R && (!best || (wide ? e.TW > best->TW : e.TW < best->TW))) best = &e;
+    return best;
 }
 
 constexpr int kRansacMaxSam = 500;   // RansacProposer default MAX_SAM, LES/Proposer.h:265
@@ -154,6 +159,7 @@ struct les_hip_batch {
     // the same calls cut for the march kernel (groups of NJ jobs); march_ok: every target keeps 2R distance from clip borders
     // that are not image borders, so the kernel's bound on |a| holds (les_march.h)
     les::Job* d_mjobs = nullptr;
+    const MarchEntry* mentry = nullptr;  // the geometry the table was cut for
     int nmgroups = 0;
     bool march_ok = false;
     std::vector<les_hip_rect> targets;
@@ -229,12 +235,19 @@ int build_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_h
 // The same calls cut for the march kernel: balanced strips of at most TW columns (a 45-column target becomes 23 + 22, never
 // 44 + 1), groups of NJ consecutive jobs per workgroup (padded with empty jobs), and the geometric precondition of the kernel.
 bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs,
-                      std::vector<les::Job>& jobs, bool& ok)
+                      std::vector<les::Job>& jobs, bool& ok, const MarchEntry*& entry)
 {
-    const MarchEntry* m = c->march;
     jobs.clear();
     ok = false;
-    if (!m) return true;
+    entry = nullptr;
+    if (!c->march) return true;
+    // narrow targets (at most the narrow geometry's job width, e.g. layer-0 cells) take two jobs per workgroup
+    const MarchEntry* narrow = find_march(c->R, 0);
+    int widest = 0;
+    for (int i = 0; i < n; i++) widest = std::max(widest, trs[i].w);
+    if (const char* e = getenv("LES_HIP_MARCH_WIDE")) widest = atoi(e) ? (1 << 30) : 0;
+    const MarchEntry* m = (narrow && widest <= narrow->TW) ? narrow : c->march;
+    entry = m;
     const int TW = m->TW, R = c->R, NJ = m->NJ, W = c->p.W, H = c->p.H;
     const long long P = (long long)H * W;
     ok = true;
@@ -298,10 +311,10 @@ int ensure_planes(les_hip_ctx* c, size_t n)
     return LES_HIP_OK;
 }
 
-int launch_march(les_hip_ctx* c, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check)
+int launch_march(les_hip_ctx* c, const MarchEntry* m, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check)
 {
     if (ngroups <= 0) return LES_HIP_OK;
-    hipLaunchKernelGGL(c->march->fn, dim3(ngroups), dim3(c->march->NT), 0, c->stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
+    hipLaunchKernelGGL(m->fn, dim3(ngroups), dim3(m->NT), 0, c->stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -431,8 +444,8 @@ const char* les_hip_last_error(void) { return g_err.c_str(); }
 int les_hip_debug_phases(unsigned long long* out)          // experiment builds only (tools/phase_probe.py); not part of the ABI header
 {
     (void)hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(les::les_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(les::les_dbg), 12 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(les::les_dbg), z, sizeof z);
     return 0;
 }
@@ -574,14 +587,14 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
     {
         std::vector<les::Job> mjobs;
         bool mok = false;
-        build_march_jobs(c, n, frs, trs, out_slabs, mjobs, mok);
+        build_march_jobs(c, n, frs, trs, out_slabs, mjobs, mok, b->mentry);
         if (mok && !mjobs.empty()) {
             if (hipMalloc((void**)&b->d_mjobs, mjobs.size() * sizeof(les::Job)) != hipSuccess ||
                 hipMemcpy(b->d_mjobs, mjobs.data(), mjobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
                 les_hip_batch_destroy(b);
                 return fail(LES_HIP_ERR_DEVICE, "upload of the march job table failed");
             }
-            b->nmgroups = (int)(mjobs.size() / c->march->NJ);
+            b->nmgroups = (int)(mjobs.size() / b->mentry->NJ);
             b->march_ok = true;
         }
     }
@@ -778,7 +791,7 @@ int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const le
         d_planes = c->d_planes;
     }
     if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok)
-        return launch_march(c, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check);
+        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check);
     return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check);
 }
 

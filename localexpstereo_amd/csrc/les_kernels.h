@@ -318,7 +318,7 @@ struct StripCfg {
 // -DLES_PHASE_TIMING (tools/phase_probe.py builds such a variant next to the product library): lane 0 of every workgroup
 // accumulates the cycles between the barriers of the march; read back with les_hip_debug_phases().
 #if defined(LES_PHASE_TIMING) && !defined(LES_SIM)
-__device__ unsigned long long les_dbg[8];
+__device__ unsigned long long les_dbg[12];
 #define LES_PHASE_BEGIN() unsigned long long ph_[5] = {0, 0, 0, 0, 0}; unsigned long long tl_ = clock64()
 #define LES_PHASE_MARK(k) do { const unsigned long long now_ = clock64(); ph_[k] += now_ - tl_; tl_ = now_; } while (0)
 #define LES_PHASE_END() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 5; k_++) atomicAdd(&les_dbg[k_], ph_[k_]); atomicAdd(&les_dbg[5], 1ull); } } while (0)

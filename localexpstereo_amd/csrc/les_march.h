@@ -47,16 +47,6 @@ __device__ inline int cvt_rpi_i32(float x)
     if (f <= -2147483648.0f) return (int)0x80000000;
     return (int)f;
 }
-// exclusive prefix sum over the 16 lanes of a DPP row
-__device__ inline int row16_excl_scan(int v)
-{
-    int o[16];
-    hipsim::group16_allgather(v, o);
-    const int l = hipsim::g_block->current & 15;
-    int s = 0;
-    for (int j = 0; j < l; j++) s = (int)((unsigned)s + (unsigned)o[j]);
-    return s;
-}
 #else
 __device__ __forceinline__ int readfirstlane_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // floor(x + 0.5) in one instruction (saturating): round-half-up keeps the quantisation of a, b unbiased
@@ -70,15 +60,6 @@ template <int N>
 __device__ __forceinline__ int dpp_row_shr(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);       // row_shr:N, lanes shifted in read 0
-}
-__device__ __forceinline__ int row16_excl_scan(int v)
-{
-    int s = v;
-    s += dpp_row_shr<1>(s);
-    s += dpp_row_shr<2>(s);
-    s += dpp_row_shr<4>(s);
-    s += dpp_row_shr<8>(s);
-    return s - v;
 }
 #endif
 
@@ -102,37 +83,111 @@ template <int R, int WGC, int NJ, int BY>
 struct MarchCfg {
     static constexpr int KS = 2 * R + 1;
     static constexpr int TW = WGC - 4 * R;                 // output columns per job
-    static constexpr int NT = WGC * NJ;
+    static constexpr int HWV = WGC / 64;                   // waves per role and job slot
+    static constexpr int NW = 3 * HWV * NJ;                // waves per workgroup: roles A, C, D
+    static constexpr int NT = 64 * NW;
     static constexpr int SEGL = 8;                         // columns per prefix segment
-    static constexpr int NSEG = WGC / SEGL;                // <= 16: one DPP row per (job, row)
-    static constexpr int PCOLS = 1 + WGC + NSEG;           // physical columns: leading zero element (P(-1)) + one pad per segment
-    static constexpr int NBL = NJ * BY * 16;               // lanes of the prefix phases
+    static constexpr int PCOLS = 1 + WGC + WGC / SEGL;     // physical columns: leading zero element (P(-1)) + one pad per segment
     static_assert(KS % BY == 0, "the block height must divide the ring length (compile-time ring slots)");
+    static_assert(KS / BY == 1 || KS / BY == 3, "unsupported ring / block ratio");
     static_assert(WGC % 64 == 0, "a job slot is a whole number of waves");
-    static_assert(NSEG <= 16 && WGC % SEGL == 0, "one DPP row per prefix row");
-    static_assert(NBL <= NT, "more prefix lanes than threads");
+    static_assert(BY * (64 / SEGL) <= 64, "one wave prefixes its own tile");
     static_assert(TW > 0, "job too narrow for this radius");
+    static_assert(2 * R + 1 < 64, "a window crosses at most one wave boundary");
     __host__ __device__ static constexpr int pcol(int ci) { return 1 + ci + ci / SEGL; }
 };
 
-template <int R, int WGC, int NJ, int BY, int MW>
-__global__ void __launch_bounds__(WGC * NJ, MW)
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised pipeline.  A workgroup owns NJ jobs; each job slot has 3 x (WGC/64) waves:
+//   role A (wave = 64 columns of the job)   block k   : gather, fixed point, vertical sums -> T1[k&1], prefix of its own tile
+//   role C                                   block k-1 : box sums from T1, algebra -> T2[(k-1)&1], prefix of its own tile
+//   role D                                   block k-2 : box sums from T2, vertical sums, output
+// and ONE workgroup barrier per block ("tick").  Every role issues the global loads of its next block before it waits at
+// the barrier, so memory latency is covered by the other two roles' work; role A / D keep their rings in registers, role C
+// has no state and can hold the 12 statistics words of all BY rows in flight.  The prefix sums are wave-local (each wave
+// prefixes the 64 columns it wrote, no cross-wave synchronisation): a window that crosses a wave boundary adds the total of
+// the left neighbour's tile (its last prefix element).
+// ---------------------------------------------------------------------------------------------------
+#if defined(LES_SIM)
+#define LES_MARCH_SCHED_FENCE() ((void)0)
+__device__ inline void wave_sync() { hipsim::group_sync(6); }
+// value of `v` in lane `l` of this wave (every lane of the wave must call it)
+__device__ inline int readlane_i32(int v, int l) { return hipsim::wave_readlane(v, l); }
+template <int N>
+__device__ inline int dpp_row_shr(int v)
+{
+    int o[16];
+    hipsim::group16_allgather(v, o);
+    const int l = hipsim::g_block->current & 15;
+    return l >= N ? o[l - N] : 0;
+}
+#else
+// the row groups are fully unrolled; without a fence the scheduler hoists the LDS reads of every group to the top of the block
+// and the register footprint is set by that alone
+#define LES_MARCH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// LDS traffic of one wave is processed in order; the fence only keeps the compiler from moving accesses across it
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+#endif
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(readlane_i32(__float_as_int(v), l)); }
+
+
+// prefix sums along x of the BY x 64 tile this wave wrote (rows i, physical columns of ci0 .. ci0+63), in place, modulo 2^32
+template <int BY, int PCOLS>
+__device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int lane)
+{
+    constexpr int SEGL = 8;
+    const int row = lane >> 3, seg = lane & 7;
+    const bool act = row < BY;
+    int4* p = &T[act ? row : 0][1 + (ci0 / SEGL + seg) * (SEGL + 1)];
+    int4 v[SEGL];
+#pragma unroll
+    for (int j = 0; j < SEGL; j++) v[j] = act ? p[j] : int4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 1; j < SEGL; j++) { v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w; }
+    // exclusive scan of the segment totals over the 8 lanes of the row (two rows share a DPP row of 16 lanes: masked steps)
+    int4 inc = v[SEGL - 1];
+#define LES_SCAN_STEP(N)                                                                                        \
+    {                                                                                                           \
+        const int tx = dpp_row_shr<N>(inc.x), ty = dpp_row_shr<N>(inc.y), tz = dpp_row_shr<N>(inc.z), tw = dpp_row_shr<N>(inc.w); \
+        if (seg >= N) { inc.x += tx; inc.y += ty; inc.z += tz; inc.w += tw; }                                   \
+    }
+    LES_SCAN_STEP(1) LES_SCAN_STEP(2) LES_SCAN_STEP(4)
+#undef LES_SCAN_STEP
+    const int4 off = int4{inc.x - v[SEGL - 1].x, inc.y - v[SEGL - 1].y, inc.z - v[SEGL - 1].z, inc.w - v[SEGL - 1].w};
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < SEGL; j++) { v[j].x += off.x; v[j].y += off.y; v[j].z += off.z; v[j].w += off.w; p[j] = v[j]; }
+    }
+}
+
+// -DLES_PHASE_TIMING: lane 0 of every wave accumulates the cycles it computes per tick and the cycles it waits at the tick
+// barrier: les_dbg[2 role] += compute, les_dbg[2 role + 1] += wait, les_dbg[6 + role] += ticks (tools/phase_probe.py)
+#if defined(LES_PHASE_TIMING) && !defined(LES_SIM)
+#define LES_TICK_BEGIN() unsigned long long tk_c_ = 0, tk_w_ = 0, tk_n_ = 0, tk_t_ = clock64()
+#define LES_TICK_BARRIER() do { const unsigned long long a_ = clock64(); __syncthreads(); const unsigned long long b_ = clock64(); tk_c_ += a_ - tk_t_; tk_w_ += b_ - a_; tk_t_ = b_; tk_n_++; } while (0)
+#define LES_TICK_END(role_) do { if (lane == 0) { atomicAdd(&les_dbg[2 * (role_)], tk_c_); atomicAdd(&les_dbg[2 * (role_) + 1], tk_w_); atomicAdd(&les_dbg[6 + (role_)], tk_n_); } } while (0)
+#else
+#define LES_TICK_BEGIN() ((void)0)
+#define LES_TICK_BARRIER() __syncthreads()
+#define LES_TICK_END(role_) ((void)0)
+#endif
+
+template <int R, int WGC, int NJ, int BY>
+__global__ void __launch_bounds__(3 * WGC * NJ)
 les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
                  float* __restrict__ out, int ngroups, int check)
 {
     using Cfg = MarchCfg<R, WGC, NJ, BY>;
-    constexpr int KS = Cfg::KS, NT = Cfg::NT, SEGL = Cfg::SEGL, NSEG = Cfg::NSEG, PCOLS = Cfg::PCOLS, NBL = Cfg::NBL;
+    constexpr int KS = Cfg::KS, NT = Cfg::NT, HWV = Cfg::HWV, NW = Cfg::NW, PCOLS = Cfg::PCOLS;
 
-    __shared__ int4 s_T1[NJ][BY][PCOLS];     // stage 1: vertical sums, then (in place) their prefix sums along x
-    __shared__ int4 s_T2[NJ][BY][PCOLS];     // stage 2: quantised (a_0, a_1, a_2, b), then their prefix sums
+    __shared__ int4 s_T1[2][NJ][BY][PCOLS];  // stage 1: vertical sums, then (in place) their prefix sums along x; double buffered over blocks
+    __shared__ int4 s_T2[2][NJ][BY][PCOLS];  // stage 2: quantised (a_0, a_1, a_2, b), then their prefix sums
     __shared__ double s_rtab[KS + 1];        // 1/n, n = 0..2R+1
-    // per-row scalars, written one block ahead by NJ*BY lanes (double buffered by block parity)
-    struct RowA { uint32_t rowpx; float d_base; };                   // p-row: pixel offset of the (clamped) row | bit 31: row inside clip and march
-    struct RowC { float rny1; uint32_t srow; };                      // stage-1 row: 1/count_y, statistics row offset | bit 31: row inside clip and primed
-    struct RowD { double rny2; uint32_t grow; uint32_t pad_; };      // output row: 1/count_y, guide row offset | bit 31: the row is an output row of the job
-    __shared__ RowA s_rowA[2][NJ][BY];
-    __shared__ RowC s_rowC[2][NJ][BY];
-    __shared__ RowD s_rowD[2][NJ][BY];
 
     // XCD-aware group order (cf. les_strip_kernel): consecutive groups (same strip, consecutive planes) share an XCD's L2
     int grp;
@@ -143,287 +198,268 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     }
     if (grp >= ngroups) return;
     const int tid = (int)threadIdx.x;
-    const int slot = readfirstlane_i32(tid / WGC);       // a job slot is a whole number of waves
-    const int ci = tid - slot * WGC;
+    const int lane = tid & 63;
+    const int wave = readfirstlane_i32(tid >> 6);
+    const int slot = wave / (3 * HWV), role = (wave % (3 * HWV)) / HWV, half = wave % HWV;
+    const int ci0 = half * 64, ci = ci0 + lane;
     const Job job = jobs[grp * NJ + slot];
     int th_max = 0;
 #pragma unroll
     for (int s = 0; s < NJ; s++) th_max = max(th_max, jobs[grp * NJ + s].th);
-    const int TtotMax = th_max + 4 * R;
+    const int nblk = (th_max + 4 * R + BY - 1) / BY;
+    const int nticks = nblk + 2;
     const int Ttot = job.th > 0 ? job.th + 4 * R : 0;     // an empty slot (padding of the last group) never passes a row test
     const float4 plane = planes[job.plane_idx];
+    const int cy1m = max(job.cy1 - 1, job.cy0);
 
     if (tid <= KS) s_rtab[tid] = tid > 0 ? 1.0 / (double)tid : 0.0;
     // zero the LDS tiles once: element 0 of every row is P(-1) = 0 and stays untouched; the pads are never read
-    for (int k = tid; k < NJ * BY * PCOLS; k += NT) {
-        (&s_T1[0][0][0])[k] = int4{0, 0, 0, 0};
-        (&s_T2[0][0][0])[k] = int4{0, 0, 0, 0};
+    for (int k = tid; k < 2 * NJ * BY * PCOLS; k += NT) {
+        (&s_T1[0][0][0][0])[k] = int4{0, 0, 0, 0};
+        (&s_T2[0][0][0][0])[k] = int4{0, 0, 0, 0};
     }
+    __syncthreads();
 
-    // ---- per-thread column constants
+    // ---- per-lane column constants
     const int gx = job.tx0 - 2 * R + ci;                                  // image column of this lane (p, stage-1 and output column alike)
     const bool col_in = gx >= job.cx0 && gx < job.cx1 && job.th > 0;
     const int sx = min(max(gx, job.cx0), max(job.cx1 - 1, job.cx0));      // clamped: addresses stay inside the image
-    const bool s1_col = col_in && ci >= R && ci < WGC - R;                // stage-1 column with a complete horizontal window
-    const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
     const int nx = window_count(gx, R, job.cx0, job.cx1);                 // the same count serves stage 1 and stage 2 (same column)
-    const uint32_t HWu = (uint32_t)g.H * (uint32_t)g.W;
-    const float g_ax = plane.x * (float)sx;                               // a * x, LES/CostVolumeEnergy.h:76
-    // fronto-parallel planes (a = b = 0): d = c for every pixel, so taps / weight / mode are per-job constants
-    const bool fronto = plane.x == 0.0f && plane.y == 0.0f;
-    GatherPrep gpc = gather_prepare(g, 0.0f, plane.z, 0u, HWu, true);
-    if (gpc.f1 == 0.0f) gpc.i1 = gpc.i0;                                  // weight 0 on a finite volume: the second tap is never needed
-    const int pcP = Cfg::pcol(min(ci + R, WGC - 1));                      // physical columns of P(x+R) and P(x-R-1)
-    const int pcM = ci - R - 1 >= 0 ? Cfg::pcol(ci - R - 1) : 0;
+    // physical columns of P(x+R), P(x-R-1) and, when the window crosses a wave boundary, of the left neighbour's tile total
+    const int cP = min(ci + R, WGC - 1), cM = ci - R - 1;
+    const int pcP = Cfg::pcol(cP);
+    const int pcM = cM >= 0 ? Cfg::pcol(cM) : 0;
+    const bool cross = cM >= 0 && (cP >> 6) != (cM >> 6);
+    const int pcX = cross ? Cfg::pcol((cP >> 6) * 64 - 1) : 0;           // element 0 is the constant zero
     const int pcS = Cfg::pcol(ci);
 
-    __syncthreads();
-    const float rnx_f = (float)s_rtab[nx];
-    const double rnx_d = s_rtab[nx];
-
-    // ---- row tables of the block that starts at p-row tb (lanes tid < NJ*BY; slot / row of the TABLE entry, not of the lane's own job)
-    auto fill_tables = [&](int tb, int par) {
-        const int s = tid / BY, i = tid - s * BY;
-        const Job js = jobs[grp * NJ + s];
-        const float4 pl = planes[js.plane_idx];
-        const int t = tb + i;
-        const int tt = js.th > 0 ? js.th + 4 * R : 0;
-        const int cy1m = max(js.cy1 - 1, js.cy0);
-        {   // p-row (phase A)
-            const int gy = js.ty0 - 2 * R + t;
-            const int sy = min(max(gy, js.cy0), cy1m);
-            RowA ra;
-            ra.rowpx = ((uint32_t)sy * (uint32_t)g.W) | ((t < tt && gy >= js.cy0 && gy < js.cy1) ? 0x80000000u : 0u);
-            ra.d_base = pl.y * (float)sy + pl.z;                        // b*y + c, LES/CostVolumeEnergy.h:73
-            s_rowA[par][s][i] = ra;
-        }
-        {   // stage-1 row (phase C): centre of the vertical window that ends at p-row t
-            const int gy1 = js.ty0 - 3 * R + t;
-            RowC rc;
-            rc.rny1 = (float)s_rtab[window_count(gy1, R, js.cy0, js.cy1)];
-            rc.srow = ((uint32_t)min(max(gy1, js.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= js.cy0 && gy1 < js.cy1 && t >= 2 * R && t < tt) ? 0x80000000u : 0u);
-            s_rowC[par][s][i] = rc;
-        }
-        {   // output row (phase D)
-            const int gy2 = js.ty0 - 4 * R + t;
-            RowD rd;
-            rd.rny2 = s_rtab[window_count(gy2, R, js.cy0, js.cy1)];
-            rd.grow = ((uint32_t)min(max(gy2, js.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < tt) ? 0x80000000u : 0u);
-            rd.pad_ = 0;
-            s_rowD[par][s][i] = rd;
-        }
-    };
-    if (tid < NJ * BY) fill_tables(0, 0);
-
-    // ---- persistent state of the vertical passes
-    int ringP[KS];                       // fixed-point cost of the last 2R+1 p-rows of this column
-    uint32_t ringG[KS];                  // their guide pixels
-    int ring2[4][KS];                    // horizontal box sums of (a_0, a_1, a_2, b) of the last 2R+1 stage-1 rows
+#ifndef LES_MARCH_ROLE_MASK
+#define LES_MARCH_ROLE_MASK 7
+#endif
+    if (role == 0 && (LES_MARCH_ROLE_MASK & 1)) {
+        // ================================================= role A =================================================
+        const uint32_t HWu = (uint32_t)g.H * (uint32_t)g.W;
+        const float g_ax = plane.x * (float)sx;                           // a * x, LES/CostVolumeEnergy.h:76
+        // fronto-parallel planes (a = b = 0): d = c for every pixel, so taps / weight / mode are per-job constants
+        const bool fronto = plane.x == 0.0f && plane.y == 0.0f;
+        GatherPrep gpc = gather_prepare(g, 0.0f, plane.z, 0u, HWu, true);
+        if (gpc.f1 == 0.0f) gpc.i1 = gpc.i0;                              // weight 0 on a finite volume: the second tap is never needed
+        int ringP[KS];                   // fixed-point cost of the last 2R+1 p-rows of this column
+        uint32_t ringG[KS];              // their guide pixels
 #pragma unroll
-    for (int k = 0; k < KS; k++) { ringP[k] = 0; ringG[k] = 0u; ring2[0][k] = ring2[1][k] = ring2[2][k] = ring2[3][k] = 0; }
-    int Sp = 0;
-    long long Sc[3] = {1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
-    double S2[4] = {0.0, 0.0, 0.0, 0.0};
-
-    __syncthreads();
-
-    int par = 0;
-    LES_PHASE_BEGIN();
-    for (int t0 = 0; t0 < TtotMax; t0 += BY, par ^= 1) {
-        const int base = t0 % KS;                            // ring slot of the block's first row: one of KS/BY values
-        // ===================== A: gather, fixed point, vertical running sums =====================
-        {
-            GatherPrep gp[BY];
-            float v0[BY], v1[BY];
-            uint32_t gw[BY];
+        for (int k = 0; k < KS; k++) { ringP[k] = 0; ringG[k] = 0u; }
+        int Sp = 0;
+        long long Sc[3] = {1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
+        GatherPrep gp[BY];
+        float v0[BY], v1[BY];
+        uint32_t gw[BY];
+        // row scalars of block b (lane i < BY computes those of p-row b*BY + i; v_readlane hands them to the wave as scalars) and the
+        // loads of its BY rows
+        auto issue = [&](int b) {
+            const int t = b * BY + lane;
+            const int gy = job.ty0 - 2 * R + t;
+            const int sy = min(max(gy, job.cy0), cy1m);
+            const int my_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
+            const float my_dbase = plane.y * (float)sy + plane.z;       // b*y + c, LES/CostVolumeEnergy.h:73
 #pragma unroll
             for (int i = 0; i < BY; i++) {
-                const RowA ra = s_rowA[par][slot][i];
-                const bool inside = col_in && (ra.rowpx >> 31);
-                const uint32_t px = (ra.rowpx & 0x7fffffffu) + (uint32_t)sx;
+                const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
+                const float d_base = readlane_f32(my_dbase, i);
+                const bool inside = col_in && (rowpx >> 31);
+                const uint32_t px = (rowpx & 0x7fffffffu) + (uint32_t)sx;
                 if (fronto) {
                     gp[i] = gpc;
                     gp[i].i0 += px; gp[i].i1 += px;
                     gp[i].mode = inside ? gpc.mode : 3;
                 } else {
-                    gp[i] = gather_prepare(g, g_ax, ra.d_base, px, HWu, inside);
+                    gp[i] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
                     if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
                 }
                 v0[i] = view.vol[gp[i].i0];
                 v1[i] = view.vol[gp[i].i1];
                 gw[i] = view.ipk8[px];
             }
-            auto blockA = [&](auto base_tag) {
-                constexpr int BASE = decltype(base_tag)::value;
-                static_for<BY>([&](auto itag) {
-                    constexpr int i = decltype(itag)::value;
-                    constexpr int SLOT = BASE + i;           // ring slot of p-row t0 + i; it holds the row that leaves the window (2R+1 rows ago)
-                    const float p = gather_finish(g, gp[i], v0[i], v1[i]);
-                    const int pi = gp[i].mode == 3 ? 0 : (int)fmaf(p - view.vmin, view.sp, 0.5f);
-                    const uint32_t gi = gw[i];
-                    const int po = ringP[SLOT];
-                    const uint32_t go = ringG[SLOT];
-                    ringP[SLOT] = pi;
-                    ringG[SLOT] = gi;
-                    Sp += pi - po;
-                    const int npo = -po;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const int qi = ((int)(gi << (24 - 8 * c))) >> 24, qo = ((int)(go << (24 - 8 * c))) >> 24;
-                        Sc[c] += (long long)qi * (long long)pi;
-                        Sc[c] += (long long)qo * (long long)npo;
-                    }
-                    s_T1[slot][i][pcS] = int4{Sp, (int)(Sc[0] >> kMarchSH), (int)(Sc[1] >> kMarchSH), (int)(Sc[2] >> kMarchSH)};
-                });
-            };
-            if constexpr (KS / BY == 1) blockA(IntTag<0>{});
-            else if constexpr (KS / BY == 3) { if (base == 0) blockA(IntTag<0>{}); else if (base == BY) blockA(IntTag<BY>{}); else blockA(IntTag<2 * BY>{}); }
-            else {
-                static_assert(KS / BY == 1 || KS / BY == 3, "unsupported ring / block ratio");
-            }
-        }
-        __syncthreads();
-        LES_PHASE_MARK(0);
-
-        // ===================== B1: prefix sums of T1 along x (in place, modulo 2^32) =====================
-        auto prefix_phase = [&](int4 (*T)[BY][PCOLS]) {
-            if (tid < NBL) {
-                const int rh = tid >> 4, seg = tid & 15;
-                const int s = rh / BY, i = rh - s * BY;
-                int4 v[SEGL];
-                int4* row = &T[s][i][1 + (seg < NSEG ? seg : 0) * (SEGL + 1)];
-#pragma unroll
-                for (int j = 0; j < SEGL; j++) v[j] = row[j];
-#pragma unroll
-                for (int j = 1; j < SEGL; j++) {
-                    v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w;
-                }
-                const bool act = seg < NSEG;
-                int4 off;
-                off.x = row16_excl_scan(act ? v[SEGL - 1].x : 0);
-                off.y = row16_excl_scan(act ? v[SEGL - 1].y : 0);
-                off.z = row16_excl_scan(act ? v[SEGL - 1].z : 0);
-                off.w = row16_excl_scan(act ? v[SEGL - 1].w : 0);
-                if (act) {
-#pragma unroll
-                    for (int j = 0; j < SEGL; j++) {
-                        v[j].x += off.x; v[j].y += off.y; v[j].z += off.z; v[j].w += off.w;
-                        row[j] = v[j];
-                    }
-                }
-            }
         };
-        prefix_phase(s_T1);
-        if (tid < NJ * BY) fill_tables(t0 + BY, par ^ 1);     // the next block's row tables (other parity: nobody reads them before the barriers below)
-        __syncthreads();
-        LES_PHASE_MARK(1);
-
-        // ===================== C: box sums, covariance, 3x3 algebra, quantise =====================
-        {
-            auto rowsC = [&](auto lo_tag, auto n_tag) {
-                constexpr int LO = decltype(lo_tag)::value, N = decltype(n_tag)::value;
-                float4 st[N][3];
-                int4 pp[N], pm[N];
-                RowC rc[N];
+        issue(0);
+        LES_TICK_BEGIN();
+        // three ticks per loop iteration: the ring slot of a block's first row, (k * BY) mod KS, is then a compile-time constant
+        // and the rings stay in fixed registers (a branch per block on the slot base made the allocator spill half of them)
+        constexpr int UN = KS / BY;
+        for (int k0 = 0; k0 < nticks; k0 += UN) {
+            static_for<UN>([&](auto utag) {
+                constexpr int BASE = decltype(utag)::value * BY;
+                const int k = k0 + decltype(utag)::value;
+                if (k < nticks) {
+                    if (k < nblk) {
+                        int4 (*T)[PCOLS] = s_T1[k & 1][slot];
+                        static_for<BY>([&](auto itag) {
+                            constexpr int i = decltype(itag)::value;
+                            constexpr int SLOT = BASE + i;       // ring slot of p-row k*BY + i; it holds the row that leaves the window (2R+1 rows ago)
+                            const float p = gather_finish(g, gp[i], v0[i], v1[i]);
+                            const int pi = gp[i].mode == 3 ? 0 : (int)fmaf(p - view.vmin, view.sp, 0.5f);
+                            const uint32_t gi = gw[i];
+                            const int po = ringP[SLOT];
+                            const uint32_t go = ringG[SLOT];
+                            ringP[SLOT] = pi;
+                            ringG[SLOT] = gi;
+                            Sp += pi - po;
+                            const int npo = -po;
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    rc[k] = s_rowC[par][slot][LO + k];
-                    const float4* sp = view.mstats + (size_t)((rc[k].srow & 0x7fffffffu) + (uint32_t)sx) * 3;
-                    st[k][0] = sp[0]; st[k][1] = sp[1]; st[k][2] = sp[2];
-                    pp[k] = s_T1[slot][LO + k][pcP];
-                    pm[k] = s_T1[slot][LO + k][pcM];
+                            for (int c = 0; c < 3; c++) {
+                                const int qi = ((int)(gi << (24 - 8 * c))) >> 24, qo = ((int)(go << (24 - 8 * c))) >> 24;
+                                Sc[c] += (long long)qi * (long long)pi;
+                                Sc[c] += (long long)qo * (long long)npo;
+                            }
+                            T[i][pcS] = int4{Sp, (int)(Sc[0] >> kMarchSH), (int)(Sc[1] >> kMarchSH), (int)(Sc[2] >> kMarchSH)};
+                        });
+                        wave_sync();
+                        march_prefix_tile<BY, PCOLS>(T, ci0, lane);
+                        if (k + 1 < nblk) issue(k + 1);
+                    }
+                    LES_TICK_BARRIER();
                 }
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const int s = pp[k].x - pm[k].x;                       // sum of pi over the window (exact)
-                    const int t0c = pp[k].y - pm[k].y, t1c = pp[k].z - pm[k].z, t2c = pp[k].w - pm[k].w;
-                    const float4 q0 = st[k][0], q1 = st[k][1], q2 = st[k][2];
-                    const int M0 = __float_as_int(q2.y), M1 = __float_as_int(q2.z), M2 = __float_as_int(q2.w);
-                    // N cov_c in units of 2^SH (u8 * pi): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
-                    const float d0 = (float)(t0c - (int)(((long long)M0 * (long long)s + (1ll << 31)) >> 32));
-                    const float d1 = (float)(t1c - (int)(((long long)M1 * (long long)s + (1ll << 31)) >> 32));
-                    const float d2 = (float)(t2c - (int)(((long long)M2 * (long long)s + (1ll << 31)) >> 32));
-                    // LES/GuidedFilter.h:204-221 with the scale of the integer stage 2 folded into the normalisation
-                    const float rn = rnx_f * rc[k].rny1;
-                    const float ka = view.kapS * rn;
-                    const float a0 = fmaf(q0.z, d2, fmaf(q0.y, d1, q0.x * d0)) * ka;     // inv00 inv01 inv02
-                    const float a1 = fmaf(q1.x, d2, fmaf(q0.w, d1, q0.y * d0)) * ka;     // inv01 inv11 inv12
-                    const float a2 = fmaf(q1.y, d2, fmaf(q1.x, d1, q0.z * d0)) * ka;     // inv02 inv12 inv22
-                    const float mp = (float)s * (view.upS * rn);
-                    const float bb = fmaf(-a2, q2.x, fmaf(-a1, q1.w, fmaf(-a0, q1.z, mp)));
-                    const bool keep = s1_col && (rc[k].srow >> 31);
-                    int4 o;
-                    o.x = keep ? cvt_rpi_i32(a0) : 0;
-                    o.y = keep ? cvt_rpi_i32(a1) : 0;
-                    o.z = keep ? cvt_rpi_i32(a2) : 0;
-                    o.w = keep ? cvt_rpi_i32(bb) : 0;
-                    s_T2[slot][LO + k][pcS] = o;
-                }
-            };
-            constexpr int GC = 2;                               // rows in flight (statistics + prefix reads: 24 registers per row)
-            static_for<(BY + GC - 1) / GC>([&](auto gtag) {
-                constexpr int LO = decltype(gtag)::value * GC;
-                constexpr int N = (BY - LO) < GC ? (BY - LO) : GC;
-                rowsC(IntTag<LO>{}, IntTag<N>{});
             });
         }
-        __syncthreads();
-        LES_PHASE_MARK(2);
-
-        // ===================== B2: prefix sums of T2 =====================
-        prefix_phase(s_T2);
-        __syncthreads();
-        LES_PHASE_MARK(3);
-
-        // ===================== D: horizontal box, vertical running sums, output =====================
-        {
-            auto blockD = [&](auto base_tag) {
-                constexpr int BASE = decltype(base_tag)::value;
-                constexpr int GD = 4;                           // rows in flight
-                static_for<(BY + GD - 1) / GD>([&](auto gtag) {
-                    constexpr int LO = decltype(gtag)::value * GD;
-                    constexpr int N = (BY - LO) < GD ? (BY - LO) : GD;
-                    RowD rd[N];
-                    uint32_t gq[N];
-                    int4 pp[N], pm[N];
+        LES_TICK_END(0);
+    } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
+        // ================================================= role C =================================================
+        const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
+        const float rnx_f = (float)s_rtab[nx];
+        float4 st[BY][3];
+        uint32_t keepbits = 0;                                            // bit i: stage-1 row i of the block in flight is inside the clip and primed
+        float rny[BY];                                                    // 1 / count_y of its rows (wave-uniform: scalar registers)
+        auto issue = [&](int b) {
+            const int t = b * BY + lane;
+            const int gy1 = job.ty0 - 3 * R + t;                          // centre of the vertical window that ends at p-row t
+            const float my_rny = (float)s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+            const int my_srow = (int)(((uint32_t)min(max(gy1, job.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot) ? 0x80000000u : 0u));
+            keepbits = 0;
 #pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        rd[k] = s_rowD[par][slot][LO + k];
-                        gq[k] = view.ipk8[(rd[k].grow & 0x7fffffffu) + (uint32_t)sx];
-                        pp[k] = s_T2[slot][LO + k][pcP];
-                        pm[k] = s_T2[slot][LO + k][pcM];
-                    }
-                    static_for<N>([&](auto ktag) {
-                        constexpr int k = decltype(ktag)::value;
-                        constexpr int i = LO + k;
-                        constexpr int SLOT = BASE + i;
-                        const int h0 = pp[k].x - pm[k].x, h1 = pp[k].y - pm[k].y, h2 = pp[k].z - pm[k].z, h3 = pp[k].w - pm[k].w;
-                        S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
-                        S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
-                        S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
-                        S2[3] += (double)(h3 - ring2[3][SLOT]); ring2[3][SLOT] = h3;
-                        if (out_col && (rd[k].grow >> 31)) {
-                            const int t = t0 + i;
-                            const uint32_t gi = gq[k];
-                            const double i0 = (double)(((int)(gi << 24)) >> 24), i1 = (double)(((int)(gi << 16)) >> 24), i2 = (double)(((int)(gi << 8)) >> 24);
-                            // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide, in integers < 2^53
-                            const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
-                            float q = (float)fma(acc, view.qscale * (rnx_d * rd[k].rny2), (double)view.vmin);
-                            const int gy2 = job.ty0 + t - 4 * R;
-                            if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx, gy2)) q = LES_COST_INVALID;
-                            out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
-                        }
+            for (int i = 0; i < BY; i++) {
+                const uint32_t srow = (uint32_t)readlane_i32(my_srow, i);
+                rny[i] = readlane_f32(my_rny, i);
+                keepbits |= (srow >> 31) << i;
+                const float4* sp = view.mstats + (size_t)((srow & 0x7fffffffu) + (uint32_t)sx) * 3;
+                st[i][0] = sp[0]; st[i][1] = sp[1]; st[i][2] = sp[2];
+            }
+        };
+        issue(0);
+        LES_TICK_BEGIN();
+        for (int k = 0; k < nticks; k++) {
+            if (k >= 1 && k <= nblk) {
+                const int b = k - 1;
+                const int4 (*T1)[PCOLS] = s_T1[b & 1][slot];
+                int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
+                constexpr int GC = 2;                           // rows whose prefix reads are in flight together
+                static_for<(BY + GC - 1) / GC>([&](auto gtag) {
+                    constexpr int LO = decltype(gtag)::value * GC;
+                    constexpr int N = (BY - LO) < GC ? (BY - LO) : GC;
+                    int4 pp[N], pm[N], px[N];
+#pragma unroll
+                    for (int j = 0; j < N; j++) { pp[j] = T1[LO + j][pcP]; pm[j] = T1[LO + j][pcM]; px[j] = T1[LO + j][pcX]; }
+                    static_for<N>([&](auto jtag) {
+                        constexpr int j = decltype(jtag)::value;
+                        constexpr int i = LO + j;
+                        const int s = pp[j].x - pm[j].x + px[j].x;                         // sum of pi over the window (exact)
+                        const int t0c = pp[j].y - pm[j].y + px[j].y, t1c = pp[j].z - pm[j].z + px[j].z, t2c = pp[j].w - pm[j].w + px[j].w;
+                        const float4 q0 = st[i][0], q1 = st[i][1], q2 = st[i][2];
+                        const int M0 = __float_as_int(q2.y), M1 = __float_as_int(q2.z), M2 = __float_as_int(q2.w);
+                        // N cov_c in units of 2^SH (u8 * pi): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
+                        const float d0 = (float)(t0c - (int)(((long long)M0 * (long long)s + (1ll << 31)) >> 32));
+                        const float d1 = (float)(t1c - (int)(((long long)M1 * (long long)s + (1ll << 31)) >> 32));
+                        const float d2 = (float)(t2c - (int)(((long long)M2 * (long long)s + (1ll << 31)) >> 32));
+                        // LES/GuidedFilter.h:204-221 with the scale of the integer stage 2 folded into the normalisation
+                        const float rn = rnx_f * rny[i];
+                        const float ka = view.kapS * rn;
+                        const float a0 = fmaf(q0.z, d2, fmaf(q0.y, d1, q0.x * d0)) * ka;     // inv00 inv01 inv02
+                        const float a1 = fmaf(q1.x, d2, fmaf(q0.w, d1, q0.y * d0)) * ka;     // inv01 inv11 inv12
+                        const float a2 = fmaf(q1.y, d2, fmaf(q1.x, d1, q0.z * d0)) * ka;     // inv02 inv12 inv22
+                        const float mp = (float)s * (view.upS * rn);
+                        const float bb = fmaf(-a2, q2.x, fmaf(-a1, q1.w, fmaf(-a0, q1.z, mp)));
+                        const int km = (s1_col && ((keepbits >> i) & 1u)) ? -1 : 0;      // a, b are zero outside the clip and before the march is primed
+                        int4 o;
+                        o.x = cvt_rpi_i32(a0) & km;
+                        o.y = cvt_rpi_i32(a1) & km;
+                        o.z = cvt_rpi_i32(a2) & km;
+                        o.w = cvt_rpi_i32(bb) & km;
+                        T2[i][pcS] = o;
                     });
+                    LES_MARCH_SCHED_FENCE();
                 });
-            };
-            if constexpr (KS / BY == 1) blockD(IntTag<0>{});
-            else { if (base == 0) blockD(IntTag<0>{}); else if (base == BY) blockD(IntTag<BY>{}); else blockD(IntTag<2 * BY>{}); }
+                wave_sync();
+                march_prefix_tile<BY, PCOLS>(T2, ci0, lane);
+                if (k < nblk) issue(k);
+            }
+            LES_TICK_BARRIER();
         }
-        // no barrier here: phase A of the next block writes T1 (last read in phase C, two barriers ago) and reads the
-        // other parity of the row tables (written before the barrier that ended B1)
-        LES_PHASE_MARK(4);
+        LES_TICK_END(1);
+    } else if (LES_MARCH_ROLE_MASK & 4) {
+        // ================================================= role D =================================================
+        const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
+        const double c_lane = view.qscale * s_rtab[nx];                    // 1 / (255 scale count_x)
+        int ring2[4][KS];                // horizontal box sums of (a_0, a_1, a_2, b) of the last 2R+1 stage-1 rows
+#pragma unroll
+        for (int k = 0; k < KS; k++) ring2[0][k] = ring2[1][k] = ring2[2][k] = ring2[3][k] = 0;
+        double S2[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t gq[BY];
+        float rny2[BY];                                                   // 1 / count_y of the block's output rows
+        uint32_t okbits = 0;
+        auto issue = [&](int b) {
+            const int t = b * BY + lane;
+            const int gy2 = job.ty0 - 4 * R + t;
+            const float my_rny = (float)s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
+            const int my_grow = (int)(((uint32_t)min(max(gy2, job.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < Ttot) ? 0x80000000u : 0u));
+            okbits = 0;
+#pragma unroll
+            for (int i = 0; i < BY; i++) {
+                const uint32_t grow = (uint32_t)readlane_i32(my_grow, i);
+                rny2[i] = readlane_f32(my_rny, i);
+                okbits |= (grow >> 31) << i;
+                gq[i] = view.ipk8[(grow & 0x7fffffffu) + (uint32_t)sx];
+            }
+        };
+        LES_TICK_BEGIN();
+        constexpr int UN = KS / BY;
+        for (int k0 = 0; k0 < nticks; k0 += UN) {
+            static_for<UN>([&](auto utag) {
+                constexpr int U = decltype(utag)::value;
+                constexpr int BASE = ((U + UN - 2 % UN) % UN) * BY;     // block k - 2: its ring slot base is a compile-time constant (see role A)
+                const int k = k0 + U;
+                if (k < nticks) {
+                    if (k >= 2) {
+                        const int b = k - 2;
+                        const int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
+                        static_for<BY>([&](auto itag) {
+                            constexpr int i = decltype(itag)::value;
+                            constexpr int SLOT = BASE + i;
+                            const int4 pp = T2[i][pcP], pm = T2[i][pcM], px = T2[i][pcX];
+                            const int h0 = pp.x - pm.x + px.x, h1 = pp.y - pm.y + px.y, h2 = pp.z - pm.z + px.z, h3 = pp.w - pm.w + px.w;
+                            S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
+                            S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
+                            S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
+                            S2[3] += (double)(h3 - ring2[3][SLOT]); ring2[3][SLOT] = h3;
+                            if (out_col && ((okbits >> i) & 1u)) {
+                                const int t = b * BY + i;
+                                const uint32_t gi = gq[i];
+                                const double i0 = (double)(((int)(gi << 24)) >> 24), i1 = (double)(((int)(gi << 16)) >> 24), i2 = (double)(((int)(gi << 8)) >> 24);
+                                // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide, in integers < 2^53
+                                const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
+                                // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
+                                float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
+                                const int gy2 = job.ty0 + t - 4 * R;
+                                if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx, gy2)) q = LES_COST_INVALID;
+                                out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
+                            }
+                            if constexpr (i % 2 == 1) LES_MARCH_SCHED_FENCE();
+                        });
+                    }
+                    if (k >= 1 && k <= nblk) issue(k - 1);        // guide rows of the block this role handles at the next tick
+                    LES_TICK_BARRIER();
+                }
+            });
+        }
+        LES_TICK_END(2);
     }
-    LES_PHASE_END();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -55,6 +55,21 @@ void group16_sync()
     while (B->g16_gen[q] == g) yield_to_sched();
 }
 
+void group_sync(int log2size)
+{
+    if (log2size == 4) { group16_sync(); return; }
+    Block* B = g_block;
+    const int q = B->current >> 6;
+    const int members = std::min(64, B->nthreads - q * 64);
+    const unsigned g = B->g64_gen[q];
+    if (++B->g64_count[q] == (unsigned)members) {
+        B->g64_count[q] = 0;
+        B->g64_gen[q]++;
+        return;
+    }
+    while (B->g64_gen[q] == g) yield_to_sched();
+}
+
 static void fiber_entry()
 {
     Block* B = g_block;
@@ -84,6 +99,8 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
         B->exch.resize(n);
         B->g16_count.resize((n + 15) / 16);
         B->g16_gen.resize((n + 15) / 16);
+        B->g64_count.resize((n + 63) / 64);
+        B->g64_gen.resize((n + 63) / 64);
     }
     B->body = body;
     B->alive = n;
@@ -93,6 +110,8 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     std::fill(B->quad_gen.begin(), B->quad_gen.end(), 0u);
     std::fill(B->g16_count.begin(), B->g16_count.end(), 0u);
     std::fill(B->g16_gen.begin(), B->g16_gen.end(), 0u);
+    std::fill(B->g64_count.begin(), B->g64_count.end(), 0u);
+    std::fill(B->g64_gen.begin(), B->g64_gen.end(), 0u);
     std::fill(B->done.begin(), B->done.end(), 0);
     gridDim = grid;
     blockDim = block;

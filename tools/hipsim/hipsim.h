@@ -74,6 +74,7 @@ struct Block {
     unsigned bar_count = 0, bar_gen = 0;
     std::vector<unsigned> quad_count, quad_gen;
     std::vector<unsigned> g16_count, g16_gen;
+    std::vector<unsigned> g64_count, g64_gen;
     std::vector<uint64_t> exch;
     std::function<void()> body;
 };
@@ -83,6 +84,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void sync_block();
 void quad_sync();
 void group16_sync();
+void group_sync(int log2size);     // 4: DPP row of 16 work-items, 6: wave of 64
 
 template <typename T>
 inline void quad_allgather(T v, T out[4])
@@ -111,6 +113,18 @@ inline void group16_allgather(T v, T out[16])
     group16_sync();
     for (int j = 0; j < 16; j++) memcpy(&out[j], &B->exch[(tid & ~15) + j], sizeof(T));
     group16_sync();
+}
+
+// value of v in work-item `l` of this wave of 64 (every work-item of the wave must call it)
+inline int wave_readlane(int v, int l)
+{
+    Block* B = g_block;
+    const int tid = B->current;
+    B->exch[tid] = (uint64_t)(uint32_t)v;
+    group_sync(6);
+    const int r = (int)(uint32_t)B->exch[(tid & ~63) + l];
+    group_sync(6);
+    return r;
 }
 
 }  // namespace hipsim

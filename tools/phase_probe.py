@@ -23,15 +23,21 @@ out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
 full = [(0, 0, W, H)] * D
 b = api.Batch(e, full, full, out_slabs=True)
 L = e.L
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 12)()
 b.run(planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
 L.les_hip_debug_phases(buf)
 for it in range(2):
     b.run(planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
     L.les_hip_debug_phases(buf)
+    kind = b.kernel_kind(0)
+    if kind == 1:
+        v = [buf[i] for i in range(12)]
+        for r, name in enumerate("ACD"):
+            n = max(1, v[6 + r])
+            print(f"march role {name}: wave-ticks {v[6 + r]}, cycles per tick: compute {v[2 * r] / n:.0f}, barrier wait {v[2 * r + 1] / n:.0f}")
+        continue
     v = [buf[i] for i in range(6)]
     tot = sum(v[:5])
-    kind = b.kernel_kind(0)
     nblk = (H + 40 + 6) // 7 if kind == 1 else 49.5
     print("kernel", "march (phases A/B1/C/B2/D)" if kind == 1 else "strip (phases G/H1/V/H2/F)", "WGs", v[5], "cycles per WG", tot / v[5], "phase shares:", [round(100.0 * x / tot, 1) for x in v[:5]],
           "per block-phase cycles", [round(x / v[5] / nblk) for x in v[:5]])
