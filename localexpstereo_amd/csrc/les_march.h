@@ -36,33 +36,6 @@
 
 namespace les {
 
-#if defined(LES_SIM)
-struct alignas(16) int4 { int x, y, z, w; };
-__device__ inline int readfirstlane_i32(int v) { return v; }
-__device__ inline int cvt_rpi_i32(float x)
-{
-    if (!(x == x)) return 0;
-    const float f = floorf(x + 0.5f);
-    if (f >= 2147483648.0f) return 2147483647;
-    if (f <= -2147483648.0f) return (int)0x80000000;
-    return (int)f;
-}
-#else
-__device__ __forceinline__ int readfirstlane_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// floor(x + 0.5) in one instruction (saturating): round-half-up keeps the quantisation of a, b unbiased
-__device__ __forceinline__ int cvt_rpi_i32(float x)
-{
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-template <int N>
-__device__ __forceinline__ int dpp_row_shr(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);       // row_shr:N, lanes shifted in read 0
-}
-#endif
-
 constexpr int kMarchPB = 22;      // bits of the fixed-point cost
 constexpr int kMarchSH = 9;       // right shift of the vertical sums of Iq * pi before the horizontal pass (M_c has 23 fraction bits: SH + 23 = 32)
 
@@ -108,34 +81,6 @@ struct MarchCfg {
 // prefixes the 64 columns it wrote, no cross-wave synchronisation): a window that crosses a wave boundary adds the total of
 // the left neighbour's tile (its last prefix element).
 // ---------------------------------------------------------------------------------------------------
-#if defined(LES_SIM)
-#define LES_MARCH_SCHED_FENCE() ((void)0)
-__device__ inline void wave_sync() { hipsim::group_sync(6); }
-// value of `v` in lane `l` of this wave (every lane of the wave must call it)
-__device__ inline int readlane_i32(int v, int l) { return hipsim::wave_readlane(v, l); }
-template <int N>
-__device__ inline int dpp_row_shr(int v)
-{
-    int o[16];
-    hipsim::group16_allgather(v, o);
-    const int l = hipsim::g_block->current & 15;
-    return l >= N ? o[l - N] : 0;
-}
-#else
-// the row groups are fully unrolled; without a fence the scheduler hoists the LDS reads of every group to the top of the block
-// and the register footprint is set by that alone
-#define LES_MARCH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// LDS traffic of one wave is processed in order; the fence only keeps the compiler from moving accesses across it
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-#endif
-__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(readlane_i32(__float_as_int(v), l)); }
-
-
 // prefix sums along x of the BY x 64 tile this wave wrote (rows i, physical columns of ci0 .. ci0+63), in place, modulo 2^32
 template <int BY, int PCOLS>
 __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int lane)
@@ -250,9 +195,15 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         for (int k = 0; k < KS; k++) { ringP[k] = 0; ringG[k] = 0u; }
         int Sp = 0;
         long long Sc[3] = {1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
+        // Per-row load state of the block in flight.  General planes: taps / weight / mode per lane and row.  Fronto-parallel
+        // planes: everything but the clip test is per-job, the row bases are scalars and the loads need no address arithmetic.
         GatherPrep gp[BY];
         float v0[BY], v1[BY];
         uint32_t gw[BY];
+        uint32_t rowbits = 0;            // fronto path: bit i = p-row i of the block is inside the clip and the march
+        const uint32_t i0s = (uint32_t)readfirstlane_i32((int)gpc.i0), i1s = (uint32_t)readfirstlane_i32((int)gpc.i1);
+        const float f1s = __int_as_float(readfirstlane_i32(__float_as_int(gpc.f1)));
+        const int modes = readfirstlane_i32(gpc.mode);
         // row scalars of block b (lane i < BY computes those of p-row b*BY + i; v_readlane hands them to the wave as scalars) and the
         // loads of its BY rows
         auto issue = [&](int b) {
@@ -260,28 +211,39 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             const int gy = job.ty0 - 2 * R + t;
             const int sy = min(max(gy, job.cy0), cy1m);
             const int my_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
-            const float my_dbase = plane.y * (float)sy + plane.z;       // b*y + c, LES/CostVolumeEnergy.h:73
+            if (fronto) {
+                rowbits = 0;
 #pragma unroll
-            for (int i = 0; i < BY; i++) {
-                const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
-                const float d_base = readlane_f32(my_dbase, i);
-                const bool inside = col_in && (rowpx >> 31);
-                const uint32_t px = (rowpx & 0x7fffffffu) + (uint32_t)sx;
-                if (fronto) {
-                    gp[i] = gpc;
-                    gp[i].i0 += px; gp[i].i1 += px;
-                    gp[i].mode = inside ? gpc.mode : 3;
-                } else {
-                    gp[i] = gather_prepare(g, g_ax, d_base, px, HWu, inside);
-                    if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
+                for (int i = 0; i < BY; i++) {
+                    const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
+                    rowbits |= (rowpx >> 31) << i;
+                    const uint32_t ro = rowpx & 0x7fffffffu;
+                    const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
+                    v0[i] = r0[sx];
+                    if (f1s != 0.0f) { const float* r1 = view.vol + (size_t)(i1s + ro); v1[i] = r1[sx]; }
+                    const uint32_t* rg = view.ipk8 + (size_t)ro;
+                    gw[i] = rg[sx];
                 }
-                v0[i] = view.vol[gp[i].i0];
-                v1[i] = view.vol[gp[i].i1];
-                gw[i] = view.ipk8[px];
+            } else {
+                const float my_dbase = plane.y * (float)sy + plane.z;   // b*y + c, LES/CostVolumeEnergy.h:73
+#pragma unroll
+                for (int i = 0; i < BY; i++) {
+                    const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
+                    const float d_base = readlane_f32(my_dbase, i);
+                    const bool inside = col_in && (rowpx >> 31);
+                    const uint32_t ro = rowpx & 0x7fffffffu;
+                    gp[i] = gather_prepare(g, g_ax, d_base, ro + (uint32_t)sx, HWu, inside);
+                    if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
+                    v0[i] = view.vol[gp[i].i0];
+                    v1[i] = view.vol[gp[i].i1];
+                    const uint32_t* rg = view.ipk8 + (size_t)ro;
+                    gw[i] = rg[sx];
+                }
             }
         };
         issue(0);
         LES_TICK_BEGIN();
+        const float pbias = fmaf(-view.vmin, view.sp, 0.5f);             // pi = trunc(p * sp + (0.5 - vmin * sp))
         // three ticks per loop iteration: the ring slot of a block's first row, (k * BY) mod KS, is then a compile-time constant
         // and the rings stay in fixed registers (a branch per block on the slot base made the allocator spill half of them)
         constexpr int UN = KS / BY;
@@ -295,8 +257,19 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         static_for<BY>([&](auto itag) {
                             constexpr int i = decltype(itag)::value;
                             constexpr int SLOT = BASE + i;       // ring slot of p-row k*BY + i; it holds the row that leaves the window (2R+1 rows ago)
-                            const float p = gather_finish(g, gp[i], v0[i], v1[i]);
-                            const int pi = gp[i].mode == 3 ? 0 : (int)fmaf(p - view.vmin, view.sp, 0.5f);
+                            int pi;
+                            if (fronto) {
+                                // LES/CostVolumeEnergy.h:78-96 with per-job taps: clamped / interpolated / invalid, then min(C, th_col)
+                                float C = v0[i];
+                                if (f1s != 0.0f) C = (1.0f - f1s) * v0[i] + f1s * v1[i];
+                                if (modes == 1) C = v0[i];
+                                if (modes == 2) C = LES_COST_INVALID;
+                                const float p = (g.th_col < C) ? g.th_col : C;
+                                pi = (col_in && ((rowbits >> i) & 1u)) ? (int)fmaf(p, view.sp, pbias) : 0;
+                            } else {
+                                const float p = gather_finish(g, gp[i], v0[i], v1[i]);
+                                pi = gp[i].mode == 3 ? 0 : (int)fmaf(p, view.sp, pbias);
+                            }
                             const uint32_t gi = gw[i];
                             const int po = ringP[SLOT];
                             const uint32_t go = ringG[SLOT];
@@ -325,6 +298,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // ================================================= role C =================================================
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
         const float rnx_f = (float)s_rtab[nx];
+        const int sx3 = sx * 3;
         float4 st[BY][3];
         uint32_t keepbits = 0;                                            // bit i: stage-1 row i of the block in flight is inside the clip and primed
         float rny[BY];                                                    // 1 / count_y of its rows (wave-uniform: scalar registers)
@@ -339,8 +313,8 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 const uint32_t srow = (uint32_t)readlane_i32(my_srow, i);
                 rny[i] = readlane_f32(my_rny, i);
                 keepbits |= (srow >> 31) << i;
-                const float4* sp = view.mstats + (size_t)((srow & 0x7fffffffu) + (uint32_t)sx) * 3;
-                st[i][0] = sp[0]; st[i][1] = sp[1]; st[i][2] = sp[2];
+                const float4* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * 3;      // scalar row base + the lane's column
+                st[i][0] = sp[sx3]; st[i][1] = sp[sx3 + 1]; st[i][2] = sp[sx3 + 2];
             }
         };
         issue(0);
@@ -350,7 +324,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 const int b = k - 1;
                 const int4 (*T1)[PCOLS] = s_T1[b & 1][slot];
                 int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
-                constexpr int GC = 2;                           // rows whose prefix reads are in flight together
+                constexpr int GC = 4;                           // rows whose prefix reads are in flight together
                 static_for<(BY + GC - 1) / GC>([&](auto gtag) {
                     constexpr int LO = decltype(gtag)::value * GC;
                     constexpr int N = (BY - LO) < GC ? (BY - LO) : GC;
@@ -415,7 +389,8 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 const uint32_t grow = (uint32_t)readlane_i32(my_grow, i);
                 rny2[i] = readlane_f32(my_rny, i);
                 okbits |= (grow >> 31) << i;
-                gq[i] = view.ipk8[(grow & 0x7fffffffu) + (uint32_t)sx];
+                const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
+                gq[i] = rg[sx];
             }
         };
         LES_TICK_BEGIN();
@@ -429,28 +404,37 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     if (k >= 2) {
                         const int b = k - 2;
                         const int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
-                        static_for<BY>([&](auto itag) {
-                            constexpr int i = decltype(itag)::value;
-                            constexpr int SLOT = BASE + i;
-                            const int4 pp = T2[i][pcP], pm = T2[i][pcM], px = T2[i][pcX];
-                            const int h0 = pp.x - pm.x + px.x, h1 = pp.y - pm.y + px.y, h2 = pp.z - pm.z + px.z, h3 = pp.w - pm.w + px.w;
-                            S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
-                            S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
-                            S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
-                            S2[3] += (double)(h3 - ring2[3][SLOT]); ring2[3][SLOT] = h3;
-                            if (out_col && ((okbits >> i) & 1u)) {
-                                const int t = b * BY + i;
-                                const uint32_t gi = gq[i];
-                                const double i0 = (double)(((int)(gi << 24)) >> 24), i1 = (double)(((int)(gi << 16)) >> 24), i2 = (double)(((int)(gi << 8)) >> 24);
-                                // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide, in integers < 2^53
-                                const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
-                                // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
-                                float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
-                                const int gy2 = job.ty0 + t - 4 * R;
-                                if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx, gy2)) q = LES_COST_INVALID;
-                                out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
-                            }
-                            if constexpr (i % 2 == 1) LES_MARCH_SCHED_FENCE();
+                        constexpr int GD = 2;                       // rows whose prefix reads are in flight together (role D lives at the 168-register limit)
+                        static_for<(BY + GD - 1) / GD>([&](auto gtag) {
+                            constexpr int LO = decltype(gtag)::value * GD;
+                            constexpr int N = (BY - LO) < GD ? (BY - LO) : GD;
+                            int4 pp[N], pm[N], px[N];
+#pragma unroll
+                            for (int j = 0; j < N; j++) { pp[j] = T2[LO + j][pcP]; pm[j] = T2[LO + j][pcM]; px[j] = T2[LO + j][pcX]; }
+                            static_for<N>([&](auto jtag) {
+                                constexpr int j = decltype(jtag)::value;
+                                constexpr int i = LO + j;
+                                constexpr int SLOT = BASE + i;
+                                const int h0 = pp[j].x - pm[j].x + px[j].x, h1 = pp[j].y - pm[j].y + px[j].y;
+                                const int h2 = pp[j].z - pm[j].z + px[j].z, h3 = pp[j].w - pm[j].w + px[j].w;
+                                S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
+                                S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
+                                S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
+                                S2[3] += (double)(h3 - ring2[3][SLOT]); ring2[3][SLOT] = h3;
+                                if (out_col && ((okbits >> i) & 1u)) {
+                                    const int t = b * BY + i;
+                                    const uint32_t gi = gq[i];
+                                    const double i0 = (double)(((int)(gi << 24)) >> 24), i1 = (double)(((int)(gi << 16)) >> 24), i2 = (double)(((int)(gi << 8)) >> 24);
+                                    // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide, in integers < 2^53
+                                    const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
+                                    // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
+                                    float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
+                                    const int gy2 = job.ty0 + t - 4 * R;
+                                    if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx, gy2)) q = LES_COST_INVALID;
+                                    out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
+                                }
+                            });
+                            LES_MARCH_SCHED_FENCE();
                         });
                     }
                     if (k >= 1 && k <= nblk) issue(k - 1);        // guide rows of the block this role handles at the next tick

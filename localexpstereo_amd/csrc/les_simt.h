@@ -38,6 +38,32 @@ __device__ inline T quad_sum(T v)
     return a + b;
 }
 
+// ---- primitives of the march kernel (les_march.h)
+struct alignas(16) int4 { int x, y, z, w; };
+#define LES_MARCH_SCHED_FENCE() ((void)0)
+__device__ inline int readfirstlane_i32(int v) { return v; }
+// floor(x + 0.5), saturating (v_cvt_rpi_i32_f32)
+__device__ inline int cvt_rpi_i32(float x)
+{
+    if (!(x == x)) return 0;
+    const float f = floorf(x + 0.5f);
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int)0x80000000;
+    return (int)f;
+}
+// DPP row_shr:N within rows of 16 lanes, lanes shifted in read 0 (every lane of the row must call it)
+template <int N>
+__device__ inline int dpp_row_shr(int v)
+{
+    int o[16];
+    hipsim::group16_allgather(v, o);
+    const int l = hipsim::g_block->current & 15;
+    return l >= N ? o[l - N] : 0;
+}
+__device__ inline void wave_sync() { hipsim::group_sync(6); }
+// value of `v` in lane `l` of this wave (every lane of the wave must call it)
+__device__ inline int readlane_i32(int v, int l) { return hipsim::wave_readlane(v, l); }
+
 #else
 
 // dpp_ctrl for quad_perm:[k,k,k,k]
@@ -93,6 +119,33 @@ __device__ __forceinline__ void quad_allgather(T v, T out[4])
     out[3] = quad_bcast<3>(v);
 }
 
+// ---- primitives of the march kernel (les_march.h)
+// the row groups are fully unrolled; without a fence the scheduler hoists the LDS reads of every group to the top of the block
+// and the register footprint is set by that alone
+#define LES_MARCH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ int readfirstlane_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// floor(x + 0.5) in one instruction (saturating): round-half-up keeps the quantisation of a, b unbiased
+__device__ __forceinline__ int cvt_rpi_i32(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ int dpp_row_shr(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);       // row_shr:N, lanes shifted in read 0
+}
+// LDS traffic of one wave is processed in order; the fence only keeps the compiler from moving accesses across it
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 #endif
+
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(readlane_i32(__float_as_int(v), l)); }
 
 }  // namespace les

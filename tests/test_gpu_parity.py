@@ -164,13 +164,93 @@ def test_full_size_linearity_in_cost(full):
     the half-way plane c=k+0.5 satisfy q(k+.5) = (q(k)+q(k+1))/2."""
     pr = full
     planes = np.array([[0, 0, 4, 0], [0, 0, 5, 0], [0, 0, 4.5, 0]], np.float32)
-    # costs U[0,1) truncated at 0.5 are not linear; use a context with a high threshold
+    # costs U[0,1) truncated at 0.5 are not linear; use a context whose threshold is never reached.  (th_col = 1: the
+    # fixed-point march kernel resolves (th_col - min vol) / 2^22 = 2.4e-7 of cost; a threshold far above the data, e.g. 10,
+    # would coarsen that to 2.4e-6 -- see DESIGN.md "Numerics" -- while the property under test stays the same.)
     from localexpstereo_amd import api, synth
-    e = api.HipCostVolumeEnergy(synth.make_guide(pr.H, pr.W, 1234), None, synth.make_volume(8, pr.H, pr.W, 42), None, th_col=10.0)
+    e = api.HipCostVolumeEnergy(synth.make_guide(pr.H, pr.W, 1234), None, synth.make_volume(8, pr.H, pr.W, 42), None, th_col=1.0)
     p2 = type("P", (), {"e": e, "H": pr.H, "W": pr.W, "D": 8})()
     out = pc.run_slabs(p2, planes)
     assert np.max(np.abs(out[2] - 0.5 * (out[0] + out[1]))) <= 5e-7
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Which kernel serves what: the fixed-point march kernel (csrc/les_march.h) takes every LayerManager cell batch and every
+# whole-image hypothesis slab; everything outside its preconditions runs the fp64 strip kernel (csrc/les_kernels.h).
+# ---------------------------------------------------------------------------------------------------
+def test_gpu_kernel_dispatch(mid, oracle_mod):
+    from localexpstereo_amd import api, synth
+    e = mid.e
+    for unit in (5, 15, 25):
+        layer = pc.om.Layer(mid.W, mid.H, 20, unit)
+        for cells in (layer.sets[0], layer.sets[len(layer.sets) - 1]):
+            b = api.Batch(e, layer.filter[cells], layer.shared[cells])
+            assert b.kernel_kind(0) == 1 and b.kernel_kind(1) == 1, "LayerManager cells must run the march kernel"
+            b.destroy()
+    full = [(0, 0, mid.W, mid.H)] * 3
+    b = api.Batch(e, full, full, out_slabs=True)
+    assert b.kernel_kind(0) == 1
+    b.destroy()
+    # a target closer than windR to a filterRect border that is not an image border: the bound on |a| does not hold -> strip kernel
+    b = api.Batch(e, [(40, 40, 120, 120)], [(45, 60, 60, 60)])
+    assert b.kernel_kind(0) == 0
+    b.destroy()
+    # non-finite costs, a cost range far above the threshold, another radius: strip kernel
+    H, W, D = 80, 120, 6
+    im = synth.make_guide(H, W, 3)
+    vol = synth.make_volume(D, H, W, 5)
+    cells = [(0, 0, W, H)]
+    for v, kw, kind in ((vol, {}, 1), (np.where(vol > 0.999, np.nan, vol).astype(np.float32), {}, 0), (vol - 9.0, {}, 0), (vol, {"windR": 8}, 0)):
+        ee = api.HipCostVolumeEnergy(im, None, v, None, **kw)
+        bb = api.Batch(ee, cells, cells)
+        assert bb.kernel_kind(0) == kind
+        bb.destroy()
+        ee.close()
+
+
+@pytest.fixture()
+def strip_only(monkeypatch):
+    monkeypatch.setenv("LES_HIP_KERNEL", "strip")       # read when a context is created
+
+
+def test_gpu_strip_kernel_still_matches(strip_only, oracle_mod):
+    """The fp64 strip kernel remains the path for everything the march kernel declines: keep it under the same parity cases."""
+    pr = pc.synth_pair(None, 200, 260, 16)
+    try:
+        layer = pc.om.Layer(pr.W, pr.H, 20, 15)
+        b = pc.api.Batch(pr.e, layer.filter[layer.sets[0]], layer.shared[layer.sets[0]])
+        assert b.kernel_kind(0) == 0
+        b.destroy()
+        pc.case_cell_batches(pr, unit=15, sets=(0, 5), mode=0)
+        pc.case_cell_batches(pr, unit=45, sets=(1,), mode=1)
+        assert pc.case_single_calls(pr) <= pc.TIGHT
+        pc.case_plane_slabs(pr, n=3, mode=0)
+    finally:
+        pr.close()
+
+
+def test_gpu_march_vs_strip_kernel(oracle_mod, monkeypatch):
+    """Both kernels on the same inputs: whole-image slanted and fronto-parallel planes, both views; they agree to the sum of
+    their individual distances from the oracle."""
+    from localexpstereo_amd import api, synth
+    H, W, D = 300, 700, 12
+    imL, imR = synth.make_guide(H, W, 11), synth.make_guide(H, W, 12)
+    volL, volR = synth.make_volume(D, H, W, 13), synth.make_volume(D, H, W, 14)
+    planes = np.concatenate([synth.fronto_planes(D)[2:5], synth.slanted_planes(3, H, W, D - 1, seed=3)])
+    outs = []
+    for force in (None, "strip"):
+        if force:
+            monkeypatch.setenv("LES_HIP_KERNEL", force)
+        e = api.HipCostVolumeEnergy(imL, imR, volL, volR)
+        pr = type("P", (), {"e": e, "H": H, "W": W, "D": D})()
+        outs.append([pc.run_slabs(pr, planes, mode=m, check=True) for m in (0, 1)])
+        e.close()
+    for m in (0, 1):
+        a, b = outs[0][m], outs[1][m]
+        assert np.array_equal(a == np.float32(1e6), b == np.float32(1e6))
+        v = a != np.float32(1e6)
+        assert np.max(np.abs(a[v] - b[v])) <= 1e-6
 
 
 def test_gpu_proposers(mid):

@@ -48,6 +48,52 @@ def test_sim_cell_batch_multi_strip(sim_lib, oracle_mod):
         pr.close()
 
 
+def test_sim_kernel_dispatch_and_strip_kernel(sim_lib, oracle_mod, monkeypatch):
+    """The march kernel (csrc/les_march.h) serves LayerManager cells and whole-image slabs; targets hugging a filterRect border
+    and contexts created with LES_HIP_KERNEL=strip run the fp64 strip kernel -- both against the oracle."""
+    pr = pc.synth_pair(sim_lib, 100, 140, 6)
+    try:
+        layer = pc.om.Layer(pr.W, pr.H, 20, 15)
+        cells = layer.sets[3]
+        b = pc.api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+        assert b.kernel_kind(0) == 1
+        b.destroy()
+        b = pc.api.Batch(pr.e, [(20, 20, 100, 70)], [(25, 40, 40, 30)])
+        assert b.kernel_kind(0) == 0
+        b.destroy()
+        planes = pc.random_planes(len(cells), pr.D, pr.H, pr.W, 31)
+        ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+        got_march = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+        pc.compare_maps(got_march, ref)
+    finally:
+        pr.close()
+    monkeypatch.setenv("LES_HIP_KERNEL", "strip")
+    pr = pc.synth_pair(sim_lib, 100, 140, 6)
+    try:
+        b = pc.api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+        assert b.kernel_kind(0) == 0
+        b.destroy()
+        got_strip = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
+        pc.compare_maps(got_strip, ref)
+    finally:
+        pr.close()
+
+
+def test_sim_march_wide_jobs_and_fronto_planes(sim_lib, oracle_mod):
+    """Whole-image slabs wider than one wide march job (216 columns): several strips, fronto-parallel (per-job taps) and slanted
+    planes, interpolated and integer disparities, both views."""
+    pr = pc.synth_pair(sim_lib, 64, 470, 5)
+    try:
+        planes = np.array([[0, 0, 2, 0], [0, 0, 1.25, 0], [0, 0, -3, 0], [0, 0, 9, 0], [0.004, -0.01, 1.5, 0]], np.float32)
+        for mode in (0, 1):
+            out = pc.run_slabs(pr, planes, mode=mode, check=True)
+            for i in range(len(planes)):
+                ref = pr.o.unary((0, 0, pr.W, pr.H), (0, 0, pr.W, pr.H), tuple(planes[i]), mode=mode, check=True)
+                pc.compare_maps(out[i], ref)
+    finally:
+        pr.close()
+
+
 def test_sim_plane_slabs(cones):
     pc.case_plane_slabs(cones, n=3)
 
