@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the matching-cost hot path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on; BASELINE.md "H1"):
+Workload at N = 1 (BASELINE.json configs[2], the configuration the metric is quoted on; BASELINE.md "H1"):
 whole-image guided-filter cost aggregation of 256 fronto-parallel hypothesis planes (c = k) against a
 synthetic 1500 x 1000 x 256 float32 U[0,1) cost volume, windR = 20 (guided-filter radius 10),
 eps = 1e-4, th_col = 0.5.  One "step" = one pass over all 256 hypotheses = W*H*D = 384 M cost
-evaluations (gather 2 volume taps -> truncate -> colour guided filter), inputs resident in HBM.
+evaluations (gather the volume taps -> truncate -> colour guided filter), inputs resident in HBM.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): hypotheses are
-independent, so they are sharded across ranks with no data-path collective ("weak" scaling: every
-rank aggregates its own 256 hypotheses of a N*256-slice volume; guide statistics are replicated).
+Multi-GPU (--gpus N > 1, launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[4],
+the synthetic 3000 x 2000 x 512 volume: hypotheses (disparity slices) are independent, so the 512 slices are
+split into 512/N per rank with no data-path collective, guide statistics replicated (at N = 8 every rank
+aggregates 64 slices of 3000 x 2000 = the evaluation count of the 1-GPU workload).  The total is fixed, so the
+N > 1 lines are "strong" scaling of configs[4]; N = 1 stays on configs[2].
+
+At N = 1 the JSON line also carries the H2 (slanted planes, two volume taps) and H3 (LayerManager cell batches, the
+optimiser's geometry) measurements of the same build as sub-records (`h2`, `h3`).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,18 +31,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4-copy ceiling of the same guide (79 % of peak)
+
+
+def kernel_source_hash():
+    """sha1 over the kernel sources: profiles/traffic.json is only quoted when it was collected for this very code."""
+    h = hashlib.sha1()
+    for f in ("les_march.h", "les_kernels.h", "les_hip.hip", "les_simt.h"):
+        h.update(open(os.path.join(ROOT, "localexpstereo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3"])
-    ap.add_argument("--height", type=int, default=1000)
-    ap.add_argument("--width", type=int, default=1500)
-    ap.add_argument("--ndisp", type=int, default=256)
+    ap.add_argument("--height", type=int, default=0, help="default: 1000 at N = 1 (configs[2]), 2000 at N > 1 (configs[4])")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 512 / N at N > 1")
+    ap.add_argument("--sub-steps", type=int, default=20, help="steps of the H2 / H3 sub-records at N = 1 (0: skip them)")
     ap.add_argument("--cpu-planes", type=int, default=-1, help="planes of the CPU-baseline sample (-1: auto, 0: skip)")
     args = ap.parse_args()
 
@@ -58,116 +74,112 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    H, W, D = args.height, args.width, args.ndisp
+    multi = world > 1
+    H = args.height or (2000 if multi else 1000)
+    W = args.width or (3000 if multi else 1500)
+    D = args.ndisp or (max(1, 512 // world) if multi else 256)       # slices of this rank
     P = H * W
-    # ---- synthetic inputs (seeded); the volume is generated directly in HBM
+    # ---- synthetic inputs (seeded); the volume shard is generated directly in HBM
     guide = synth.make_guide(H, W, 1234)
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     vol = torch.rand((D, H, W), device=dev, dtype=torch.float32, generator=gen)
-    if args.workload == "h1":
-        planes = synth.fronto_planes(D)
-        bytes_per_eval = 8.0          # 4 B raw cost read + 4 B aggregated cost written
-    else:
-        planes = synth.slanted_planes(D, H, W, D - 1, seed=7 + rank)
-        bytes_per_eval = 12.0         # two volume taps + write
-    d_planes = torch.from_numpy(planes).to(dev)
-    out = torch.empty((D, H, W) if args.workload != "h3" else (1, H, W), device=dev, dtype=torch.float32)
-
     e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1,
                                 device=local_rank, volumes_on_device=True, shape=(D, H, W))
     stream = torch.cuda.current_stream(dev)
     e.set_stream(stream.cuda_stream)
-    if args.workload == "h3":
-        # H3: the optimiser's geometry -- LayerManager cells of units 1 % / 3 % / 9 % of the width, one
-        # random plane per cell and proposal slot (9 / 3 / 3 per cell), one launch per disjoint set and slot; the contract
-        # number counts filter-domain pixels x hypotheses
-        from localexpstereo_amd import pm
-        rng = np.random.default_rng(7 + rank)
-        batches, evals = [], 0
-        for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
-            units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
-            for cells in sets:
-                b = api.Batch(e, filt[cells], shared[cells])
-                pl = np.zeros((slots, len(cells), 4), np.float32)
-                pl[..., 0] = rng.uniform(-0.05, 0.05, pl.shape[:2]); pl[..., 1] = rng.uniform(-0.05, 0.05, pl.shape[:2])
-                cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
-                pl[..., 2] = rng.uniform(0.2, 0.8, pl.shape[:2]) * (D - 1) - pl[..., 0] * cx - pl[..., 1] * cy
-                batches.append((b, [torch.from_numpy(pl[k]).to(dev) for k in range(slots)]))
-                evals += slots * int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
-        batch = batches[0][0]
-        evals_per_step_h3 = evals
-
-        def step():
-            for b, pls in batches:
-                for p in pls:
-                    b.run(p.data_ptr(), out.data_ptr(), mode=0, check=True, planes_on_device=True)
-    else:
-        full = [(0, 0, W, H)] * D
-        batch = api.Batch(e, full, full, out_slabs=True)
-
-        def step():
-            batch.run(d_planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
+    out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    kern_ms = float(kern_ms.item())
+    def make_workload(name):
+        """-> (step function, evaluations per step of this rank, algorithmic bytes per evaluation, representative batch,
+        description, planes or None)"""
+        if name == "h3":
+            # H3 (SURVEY.md 8(d)): the optimiser's geometry -- LayerManager cells of units 1 % / 3 % / 9 % of the width, one
+            # random plane per cell and proposal slot (9 / 3 / 3 per cell), one launch per disjoint set and slot; the contract
+            # number counts filter-domain pixels x hypotheses
+            from localexpstereo_amd import pm
+            rng = np.random.default_rng(7 + rank)
+            batches, evals = [], 0
+            for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
+                units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
+                for cells in sets:
+                    b = api.Batch(e, filt[cells], shared[cells])
+                    pl = np.zeros((slots, len(cells), 4), np.float32)
+                    pl[..., 0] = rng.uniform(-0.05, 0.05, pl.shape[:2]); pl[..., 1] = rng.uniform(-0.05, 0.05, pl.shape[:2])
+                    cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
+                    pl[..., 2] = rng.uniform(0.2, 0.8, pl.shape[:2]) * (D - 1) - pl[..., 0] * cx - pl[..., 1] * cy
+                    batches.append((b, [torch.from_numpy(pl[k]).to(dev) for k in range(slots)]))
+                    evals += slots * int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
+            nl = sum(len(p) for _, p in batches)
 
-    # measured device-copy ceiling on this box (quote both denominators): dword-per-lane copy of the volume
-    # shard through the library's calibration kernel, 2 x bytes moved / time
-    import ctypes as C
-    copy_gbs = None
-    try:
-        nn = int(vol.numel())
-        tmp = torch.empty_like(vol)
-        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        L = api.load()
-        L.les_hip_calib_copy(C.c_void_p(vol.data_ptr()), C.c_void_p(tmp.data_ptr()), C.c_size_t(nn), local_rank, C.c_void_p(stream.cuda_stream))
-        ca.record(stream)
-        for _ in range(3):
-            L.les_hip_calib_copy(C.c_void_p(vol.data_ptr()), C.c_void_p(tmp.data_ptr()), C.c_size_t(nn), local_rank, C.c_void_p(stream.cuda_stream))
-        cb.record(stream)
+            def step():
+                for b, pls in batches:
+                    for p in pls:
+                        b.run(p.data_ptr(), out.data_ptr(), mode=0, check=True, planes_on_device=True)
+            desc = (f"H3: LayerManager cells (units 1/3/9 % of W={W}), 9/3/3 random planes per cell, one launch per disjoint set and "
+                    f"slot ({nl} launches per step), filter-domain evaluations counted; volume {W}x{H}x{D} f32 U[0,1)")
+            return step, float(evals), 12.0, batches[0][0], desc, None
+        if name == "h1":
+            planes = synth.fronto_planes(D)
+            bpe = 8.0             # SURVEY.md 8(d): 4 B raw cost read + 4 B aggregated cost written
+        else:
+            planes = synth.slanted_planes(D, H, W, D - 1, seed=7 + rank)
+            bpe = 12.0            # two volume taps + write
+        d_planes = torch.from_numpy(planes).to(dev)
+        full = [(0, 0, W, H)] * D
+        batch = api.Batch(e, full, full, out_slabs=True)
+
+        def step():
+            batch.run(d_planes.data_ptr(), out.data_ptr(), mode=0, check=False, planes_on_device=True)
+        desc = (f"{name.upper()}: {D} {'fronto-parallel' if name == 'h1' else 'slanted'} planes x {W}x{H} image, volume {W}x{H}x{D} f32 "
+                f"U[0,1) per GPU, windR=20 (GF radius 10), eps=1e-4, th_col=0.5")
+        return step, float(P) * D, bpe, batch, desc, planes
+
+    def measure(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record(stream)
+            step()
+            b.record(stream)
         torch.cuda.synchronize(dev)
-        copy_gbs = 3 * 2.0 * nn * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
-        del tmp
-    except Exception:
-        copy_gbs = None
+        t1 = time.perf_counter()
+        barrier()
+        elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+        kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in evs) / max(1, steps)], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+            dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+        return float(elapsed.item()), float(kern_ms.item())
 
-    evals_rank = float(evals_per_step_h3) if args.workload == "h3" else float(P) * D
+    step, evals_rank, bytes_per_eval, batch, desc, planes = make_workload(args.workload)
+    elapsed, kern_ms = measure(step, args.steps, args.warmup)
+    kind = batch.kernel_kind(0)
+    kernel_name = ("les_march_kernel<R=10> (gather + guided filter fused: exact integer box sums, wave-specialised pipeline)" if kind == 1
+                   else "les_strip_kernel<R=10> (gather + guided filter fused, fp64 running sums)")
+
     evals_per_step = evals_rank * world
     value = evals_per_step * args.steps / elapsed / 1e6
     alg_bytes = evals_rank * bytes_per_eval + float(P) * 48.0        # per step and rank (H1 / H2: one launch)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
-    # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate
-    # passes; see profiles/): cannot be collected live inside this process, so the committed measurement is quoted.
+    # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate passes,
+    # tools/collect_profiles.sh): cannot be collected live inside this process, so the committed measurement is quoted --
+    # only when it was taken on exactly these kernel sources and this shape.
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf)).get(args.workload)
-            if t and t.get("strip_width") == e.strip_width() and (H, W, D) == tuple(t.get("shape", ())):
+            if t and t.get("kernel_source_sha1") == kernel_source_hash() and [H, W, D] == list(t.get("shape", ())):
                 traffic = t["bytes_per_launch"]
         except Exception:
             traffic = None
@@ -181,20 +193,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if multi else "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "i32/i64 fixed-point box sums (exact), f32 3x3 algebra, f64 final combine" if kind == 1 else "f64 sums / f32 algebra",
         "data": "synthetic",
         "config": {
-            "workload": (f"{args.workload.upper()}: {D} {'fronto-parallel' if args.workload == 'h1' else 'slanted'} planes x "
-                         f"{W}x{H} image, volume {W}x{H}x{D} f32 U[0,1) per GPU, windR=20 (GF radius 10), eps=1e-4, th_col=0.5")
-                        if args.workload != "h3" else
-                        (f"H3: LayerManager cells (units 1/3/9 % of W={W}), 9/3/3 random planes per cell, one launch per disjoint set and "
-                         f"slot ({len(batches) and sum(len(p) for _, p in batches)} launches per step), filter-domain evaluations counted; "
-                         f"volume {W}x{H}x{D} f32 U[0,1)"),
+            "workload": desc + (f"; BASELINE configs[4]: 3000x2000x512 split into {D} slices per rank" if multi else "; BASELINE configs[2]"),
             "evals_per_step_per_gpu": int(evals_rank),
             "sharding": "hypotheses (disparity slices) split across ranks, no data-path collective",
-            "strip_width": e.strip_width(),
             "workgroups_per_launch": batch.num_jobs,
         },
         "roofline": {
@@ -203,20 +209,39 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            # second denominator: device copy measured on this box in this run, one dword per lane like the
-            # strip kernel's accesses (a float4 copy reaches ~6.3 TB/s on MI355X, MI355X_MICROARCH.md)
-            "measured_dword_copy": None if copy_gbs is None else round(copy_gbs, 1),
-            "frac_of_measured_dword_copy": None if not copy_gbs else round(achieved / copy_gbs, 5),
+            "peak_achievable": HBM_ACHIEVABLE_GBS,       # float4-copy ceiling measured on MI355X (MI355X_MICROARCH.md)
+            "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
             "traffic": traffic,
-            "kernel": "les_strip_kernel<R=10> (gather + guided filter fused; strip width %d)" % e.strip_width(),
+            "kernel": kernel_name,
             "kernel_ms": round(kern_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_source_sha1": kernel_source_hash(),
         },
     }
 
+    # ---- sub-records: the other two workloads of SURVEY.md 8(d) on the same context
+    if world == 1 and args.sub_steps > 0 and args.workload == "h1":
+        for name in ("h2", "h3"):
+            st, ev, bpe, bt, ds, _ = make_workload(name)
+            el, km = measure(st, args.sub_steps, 2)
+            ab = ev * bpe + float(P) * 48.0
+            result[name] = {
+                "workload": ds,
+                "ms_per_step": round(el / args.sub_steps * 1e3, 4),
+                "value": round(ev * args.sub_steps / el / 1e6, 2),
+                "unit": "Mcost-evals/s",
+                "steps": args.sub_steps,
+                "algorithmic_GBps": round(ab / (km * 1e-3) / 1e9, 2),
+                "frac": round(ab / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "kernel": "march" if bt.kernel_kind(0) == 1 else "strip",
+                "workgroups_first_launch": bt.num_jobs,
+            }
+        step()                        # the H1 result buffer is compared with the oracle below
+        torch.cuda.synchronize(dev)
+
     # ---- CPU baseline: the oracle (CPU restatement, double guided filter like the reference default),
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.
-    if rank == 0 and world == 1 and args.cpu_planes != 0 and args.workload != "h3":
+    if rank == 0 and world == 1 and args.cpu_planes != 0 and planes is not None:
         from oracle import oracle as om
         cores = os.cpu_count() or 1
         ns = args.cpu_planes if args.cpu_planes > 0 else max(cores, min(D - 1, 4 * cores, 96))

@@ -1,20 +1,53 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence for the headline bench (run on the GPU box through gpurun):
 #   kernel-trace stats of `python bench.py`, FETCH_SIZE / WRITE_SIZE in separate --pmc passes (no trace domains mixed
-#   in), and the same two counters on a known-byte-count dword copy for calibration.  Summaries land in gpurun_out/prof/.
+#   in), the same two counters on a known-byte-count dword copy for calibration, and the SQ counters.
+# Summaries land in gpurun_out/prof/ ; traffic.json (HBM bytes per launch + the sha1 of the kernel sources it was taken on)
+# is what bench.py quotes as roofline.traffic.  Usage: bash tools/collect_profiles.sh [tag]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=${1:-round2}
 O=gpurun_out/prof; mkdir -p $O
-B="python bench.py --steps 5 --warmup 1 --cpu-planes 0"
+B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -- $B > $O/stats.log 2>&1
-python tools/prof_summary.py $O/stats --md > $O/stats.md
+python tools/prof_summary.py $O/stats --md > $O/${TAG}_kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_$c -- $B > $O/pmc_$c.log 2>&1
-  python tools/prof_summary.py $O/pmc_$c les_strip --md > $O/pmc_$c.md
+  python tools/prof_summary.py $O/pmc_$c les_march_kernel --md > $O/pmc_$c.md
   rocprofv3 --pmc $c -d $O/cal_$c -- python tools/calib_copy.py > $O/cal_$c.log 2>&1
   python tools/prof_summary.py $O/cal_$c les_calib --md > $O/cal_$c.md
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
-python tools/prof_summary.py $O/pmc_sq les_strip --md > $O/pmc_sq.md
-rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/cal_FETCH_SIZE $O/cal_WRITE_SIZE $O/pmc_sq
-cat $O/stats.md | head -8; grep -h "FETCH_SIZE\|WRITE_SIZE" $O/pmc_*.md $O/cal_*.md; grep -h "SQ_" $O/pmc_sq.md
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
+python tools/prof_summary.py $O/pmc_sq les_march_kernel --md > $O/pmc_sq.md
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $O/pmc_lds -- $B > $O/pmc_lds.log 2>&1
+python tools/prof_summary.py $O/pmc_lds les_march_kernel --md > $O/pmc_lds.md
+rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/cal_FETCH_SIZE $O/cal_WRITE_SIZE $O/pmc_sq $O/pmc_lds
+python - "$O" "$TAG" <<'PY'
+import json, re, sys, os
+sys.path.insert(0, os.getcwd())
+O, tag = sys.argv[1], sys.argv[2]
+def counter(path, name):
+    for l in open(path):
+        m = re.match(r"\|\s*%s\s*\|\s*([0-9.eE+-]+)\s*\|" % name, l)
+        if m: return float(m.group(1))
+    return None
+fetch, write = counter(f"{O}/pmc_FETCH_SIZE.md", "FETCH_SIZE"), counter(f"{O}/pmc_WRITE_SIZE.md", "WRITE_SIZE")
+cf, cw = counter(f"{O}/cal_FETCH_SIZE.md", "FETCH_SIZE"), counter(f"{O}/cal_WRITE_SIZE.md", "WRITE_SIZE")
+known = 384_000_000 * 4.0                           # tools/calib_copy.py: bytes read = bytes written per launch
+# counters are in KiB; the calibration factor (known bytes / counted bytes of the dword copy) corrects the gfx950 unit quirks
+kf, kw = known / (cf * 1024.0), known / (cw * 1024.0)
+bytes_per_launch = fetch * 1024.0 * kf + write * 1024.0 * kw
+import bench
+rec = {"h1": {"shape": [1000, 1500, 256], "kernel_source_sha1": bench.kernel_source_hash(), "bytes_per_launch": bytes_per_launch,
+              "fetch_bytes": fetch * 1024.0 * kf, "write_bytes": write * 1024.0 * kw,
+              "source": f"profiles/{tag}_pmc.md: FETCH_SIZE {fetch:.4g} KiB x {kf:.3f} + WRITE_SIZE {write:.4g} KiB x {kw:.3f} per launch "
+                        f"(factors = known bytes / counted bytes of a 1.536 GB dword copy in the same profile run), separate --pmc passes"}}
+json.dump(rec, open(f"{O}/traffic.json", "w"), indent=1)
+with open(f"{O}/{tag}_pmc.md", "w") as f:
+    f.write(f"# {tag}: PMC counters of les_march_kernel on `python bench.py` (H1, 1500x1000x256), per launch\n\n")
+    for name in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "cal_FETCH_SIZE", "cal_WRITE_SIZE", "pmc_sq", "pmc_lds"):
+        f.write(f"## {name}\n" + open(f"{O}/{name}.md").read() + "\n")
+    f.write(f"\nHBM traffic per launch: {bytes_per_launch / 1e9:.3f} GB (fetch {fetch * 1024 * kf / 1e9:.3f} + write {write * 1024 * kw / 1e9:.3f}); algorithmic 3.144 GB\n")
+print(open(f"{O}/traffic.json").read())
+PY
+head -12 $O/${TAG}_kernel_stats.md
