@@ -137,6 +137,7 @@ struct les_hip_ctx {
     int R;
     const StripEntry* strip;
     const MarchEntry* march = nullptr;   // null: radius not instantiated (or LES_HIP_KERNEL=strip)
+    int ncu = 256;                       // compute units of the device (job cutting of the march kernel)
     hipStream_t stream;
     les::Geom geom;
     ViewData v[2];
@@ -241,35 +242,55 @@ bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, cons
     ok = false;
     entry = nullptr;
     if (!c->march) return true;
-    // narrow targets (at most the narrow geometry's job width, e.g. layer-0 cells) take two jobs per workgroup
-    const MarchEntry* narrow = find_march(c->R, 0);
-    int widest = 0;
-    for (int i = 0; i < n; i++) widest = std::max(widest, trs[i].w);
-    if (const char* e = getenv("LES_HIP_MARCH_WIDE")) widest = atoi(e) ? (1 << 30) : 0;
-    const MarchEntry* m = (narrow && widest <= narrow->TW) ? narrow : c->march;
-    entry = m;
-    const int TW = m->TW, R = c->R, NJ = m->NJ, W = c->p.W, H = c->p.H;
+    const int R = c->R, W = c->p.W, H = c->p.H;
     const long long P = (long long)H * W;
     ok = true;
-    long long strips = 0;
-    int tallest = 0;
     for (int i = 0; i < n; i++) {
         const les_hip_rect &f = frs[i], &t = trs[i];
         if (t.w <= 0 || t.h <= 0) continue;
         if ((f.x > 0 && t.x - f.x < 2 * R) || (f.x + f.w < W && (f.x + f.w) - (t.x + t.w) < 2 * R) ||
             (f.y > 0 && t.y - f.y < 2 * R) || (f.y + f.h < H && (f.y + f.h) - (t.y + t.h) < 2 * R)) ok = false;
-        strips += (t.w + TW - 1) / TW;
-        tallest = std::max(tallest, t.h);
     }
     if (!ok) return true;
-    // row chunking as in build_jobs: few strips -> split tall targets so that every CU gets several workgroups
+    // Cut: geometry (wide jobs, one per workgroup / narrow jobs, two per workgroup) and rows per job.  A workgroup fills a CU
+    // (12 waves, 130 KB LDS) and runs one 7-row block per ~3.4 us tick with a 2-tick pipeline fill and 4R halo rows per job, so
+    // the launch time is about rounds(workgroups / CUs) x ticks(rows per job): pick the cut that minimises it.  (Layer-1/2 sets
+    // have only 5..50 cells: whole cells would leave most CUs idle -- measured 13 and 8 G evaluations/s against 55 at layer 0.)
+    const int ncu = c->ncu;
+    const MarchEntry* cands[2] = {c->march, find_march(c->R, 0)};
+    const MarchEntry* m = c->march;
     int max_rows = 1 << 30;
-    const long long want_jobs = 1536ll * NJ;
-    if (strips > 0 && strips < want_jobs) {
-        const long long want = (want_jobs + strips - 1) / strips;
-        max_rows = (int)std::max<long long>(std::max(16 * R, 128), (tallest + want - 1) / want);
+    {
+        double best = 1e300;
+        const int row_opts[] = {1 << 30, 1024, 512, 384, 256, 192, 128, 96, 64, 48, 32};
+        for (int g = 0; g < 2; g++) {
+            const MarchEntry* e = cands[g];
+            if (!e || (g == 1 && e == cands[0])) continue;
+            if (const char* w = getenv("LES_HIP_MARCH_WIDE")) if ((atoi(w) != 0) != (g == 0)) continue;
+            for (int ro : row_opts) {
+                long long njobs = 0;
+                int rows = 0, useful = 0;
+                for (int i = 0; i < n; i++) {
+                    const les_hip_rect& t = trs[i];
+                    if (t.w <= 0 || t.h <= 0) continue;
+                    const int ns = (t.w + e->TW - 1) / e->TW;
+                    const int nr = (t.h + ro - 1) / ro, sh = (t.h + nr - 1) / nr;
+                    njobs += (long long)ns * nr;
+                    rows = std::max(rows, sh);
+                    useful = std::max(useful, (t.w + ns - 1) / ns);
+                }
+                if (njobs == 0) continue;
+                const long long wgs = (njobs + e->NJ - 1) / e->NJ;
+                const double ticks = (double)((rows + 4 * R + 6) / 7 + 2);
+                // a partially filled last round costs as much as a full one; narrow jobs that leave most lanes idle cost the same tick
+                const double cost = (double)((wgs + ncu - 1) / ncu) * ticks * (1.0 + 1e-3 * (double)wgs / ncu) + (ro == (1 << 30) ? 0.0 : 1e-6);
+                if (cost < best) { best = cost; m = e; max_rows = ro; }
+            }
+        }
     }
     if (const char* e = getenv("LES_HIP_MARCH_ROWS")) max_rows = std::max(1, atoi(e));
+    entry = m;
+    const int TW = m->TW, NJ = m->NJ;
     for (int i = 0; i < n; i++) {
         const les_hip_rect &f = frs[i], &t = trs[i];
         if (t.w <= 0 || t.h <= 0) continue;
@@ -478,6 +499,12 @@ static int create_common(les_hip_ctx** out, const les_hip_params* params, const 
     c->R = p.windR / 2;
     c->strip = strip;
     c->march = naive ? nullptr : find_march(p.windR / 2);
+#if !defined(LES_SIM)
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && v > 0) c->ncu = v;
+    }
+#endif
     c->stream = nullptr;
     c->geom.H = p.H; c->geom.W = p.W; c->geom.D = p.D;
     c->geom.D0 = (int)(-p.min_disparity);                       // LES/CostVolumeEnergy.h:67

@@ -178,6 +178,15 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int pcX = cross ? Cfg::pcol((cP >> 6) * 64 - 1) : 0;           // element 0 is the constant zero
     const int pcS = Cfg::pcol(ci);
 
+#ifndef LES_MARCH_PRIO_C
+#define LES_MARCH_PRIO_C 0
+#define LES_MARCH_PRIO_D 0
+#endif
+#if defined(LES_SIM)
+#define LES_MARCH_SETPRIO(n) ((void)0)
+#else
+#define LES_MARCH_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 #ifndef LES_MARCH_ROLE_MASK
 #define LES_MARCH_ROLE_MASK 7
 #endif
@@ -296,6 +305,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         LES_TICK_END(0);
     } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
         // ================================================= role C =================================================
+        LES_MARCH_SETPRIO(LES_MARCH_PRIO_C);
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
         const float rnx_f = (float)s_rtab[nx];
         const int sx3 = sx * 3;
@@ -369,6 +379,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         LES_TICK_END(1);
     } else if (LES_MARCH_ROLE_MASK & 4) {
         // ================================================= role D =================================================
+        LES_MARCH_SETPRIO(LES_MARCH_PRIO_D);
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
         const double c_lane = view.qscale * s_rtab[nx];                    // 1 / (255 scale count_x)
         int ring2[4][KS];                // horizontal box sums of (a_0, a_1, a_2, b) of the last 2R+1 stage-1 rows

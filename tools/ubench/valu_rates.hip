@@ -24,7 +24,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
         unsigned long long t0 = __builtin_amdgcn_s_memtime();                                       \
         for (int i = 0; i < ITER; i++) {                                                            \
             asm volatile(REP8(ASM(%0) ASM(%1) ASM(%2) ASM(%3)) REP8(ASM(%4) ASM(%5) ASM(%6) ASM(%7)) \
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc", "s10", "s11", "s12"); \
         }                                                                                           \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                                       \
         if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;            \
@@ -75,6 +75,20 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #define A_ADD_DPP(r) "v_add_f32_dpp " #r ", " #r ", %8 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n"
 #define A_MIN_F32(r) "v_min_f32 " #r ", " #r ", %8\n"
 #define A_CNDMASK(r) "v_cndmask_b32 " #r ", " #r ", %8, vcc\n"
+#define A_CNDMASK64(r) "v_cndmask_b32_e64 " #r ", " #r ", %8, s[10:11]\n"
+#define A_CMP_CND(r) "v_cmp_lt_f32 vcc, " #r ", %8\n v_cndmask_b32 " #r ", " #r ", %9, vcc\n"
+#define A_MOV_B32(r) "v_mov_b32 " #r ", %8\n"
+#define A_AND_B32(r) "v_and_b32 " #r ", " #r ", %8\n"
+#define A_SUB_U32(r) "v_sub_u32 " #r ", " #r ", %8\n"
+#define A_ASHR(r) "v_ashrrev_i32 " #r ", 3, " #r "\n"
+#define A_LSHL_ADD_U32(r) "v_lshl_add_u32 " #r ", " #r ", 2, %8\n"
+#define A_ALIGNBIT(r) "v_alignbit_b32 " #r ", " #r ", %8, 9\n"
+#define A_CVT_RPI(r) "v_cvt_rpi_i32_f32 " #r ", " #r "\n"
+#define A_CVT_I32_F32(r) "v_cvt_i32_f32 " #r ", " #r "\n"
+#define A_FMAC_F32(r) "v_fmac_f32 " #r ", %8, %9\n"
+#define A_MIN3(r) "v_min3_f32 " #r ", " #r ", %8, %9\n"
+#define A_CMP_ONLY(r) "v_cmp_lt_f32 vcc, " #r ", %8\n"
+#define A_READLANE(r) "v_readlane_b32 s12, " #r ", 3\n"
 
 #define A_ADD_F64(r) "v_add_f64 " #r ", " #r ", %8\n"
 #define A_FMA_F64(r) "v_fma_f64 " #r ", " #r ", %8, %9\n"
@@ -103,6 +117,20 @@ KERNEL32(k_dpp, A_DPP)
 KERNEL32(k_add_dpp, A_ADD_DPP)
 KERNEL32(k_min_f32, A_MIN_F32)
 KERNEL32(k_cndmask, A_CNDMASK)
+KERNEL32(k_cndmask64, A_CNDMASK64)
+KERNEL32(k_cmp_cnd, A_CMP_CND)
+KERNEL32(k_mov_b32, A_MOV_B32)
+KERNEL32(k_and_b32, A_AND_B32)
+KERNEL32(k_sub_u32, A_SUB_U32)
+KERNEL32(k_ashr, A_ASHR)
+KERNEL32(k_lshl_add_u32, A_LSHL_ADD_U32)
+KERNEL32(k_alignbit, A_ALIGNBIT)
+KERNEL32(k_cvt_rpi, A_CVT_RPI)
+KERNEL32(k_cvt_i32_f32, A_CVT_I32_F32)
+KERNEL32(k_fmac_f32, A_FMAC_F32)
+KERNEL32(k_min3, A_MIN3)
+KERNEL32(k_cmp_only, A_CMP_ONLY)
+KERNEL32(k_readlane, A_READLANE)
 KERNEL64(k_add_f64, A_ADD_F64)
 KERNEL64(k_fma_f64, A_FMA_F64)
 KERNEL64(k_mul_f64, A_MUL_F64)
@@ -185,7 +213,10 @@ int main(int argc, char** argv)
     std::vector<unsigned long long> h(grid * 4);
     Entry es[] = {
         {"v_add_f32", k_add_f32, 64}, {"v_fma_f32", k_fma_f32, 64}, {"v_mul_f32", k_mul_f32, 64}, {"v_min_f32", k_min_f32, 64},
-        {"v_cndmask_b32", k_cndmask, 64},
+        {"v_cndmask_b32 (vcc)", k_cndmask, 64}, {"v_cndmask_b32_e64 (sgpr mask)", k_cndmask64, 64}, {"v_cmp_lt_f32 + v_cndmask (pair)", k_cmp_cnd, 64},
+        {"v_cmp_lt_f32 vcc", k_cmp_only, 64}, {"v_mov_b32", k_mov_b32, 64}, {"v_and_b32", k_and_b32, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_ashrrev_i32", k_ashr, 64},
+        {"v_lshl_add_u32", k_lshl_add_u32, 64}, {"v_alignbit_b32", k_alignbit, 64}, {"v_cvt_rpi_i32_f32", k_cvt_rpi, 64}, {"v_cvt_i32_f32", k_cvt_i32_f32, 64},
+        {"v_fmac_f32", k_fmac_f32, 64}, {"v_min3_f32", k_min3, 64}, {"v_readlane_b32", k_readlane, 64},
         {"v_add_u32", k_add_u32, 64}, {"v_mad_u32_u24", k_mad_u24, 64}, {"v_mul_lo_u32", k_mul_lo, 64}, {"v_bfe_i32", k_bfe, 64},
         {"v_cvt_f32_i32", k_cvt_f32_i32, 64}, {"v_mov_b32_dpp", k_dpp, 64}, {"v_add_f32_dpp", k_add_dpp, 64},
         {"v_add_f64", k_add_f64, 64}, {"v_fma_f64", k_fma_f64, 64}, {"v_mul_f64", k_mul_f64, 64},
