@@ -90,6 +90,10 @@ class PMRunner:
     def __init__(self, energy, layer_units, proposer_table, seed=1, rank=0, world=1, device="cuda", mode=0):
         self.e, self.rank, self.world, self.mode = energy, rank, world, mode
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            # the torch ops of this class (exchange index_copy_, label / mask copies) run on torch's current stream: bind the
+            # library's launches to the same stream so that their order is the program order under any stream context
+            energy.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.H, self.W = energy.H, energy.W
         self.table = proposer_table
         self.maxd, self.mind = float(energy.max_disp), float(energy.params.min_disparity)

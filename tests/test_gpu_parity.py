@@ -118,9 +118,27 @@ def test_gpu_repeatable(mid):
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def full(oracle_mod):
-    pr = pc.synth_pair(None, 1000, 1500, 24)
+    # BASELINE configs[2] shape with all 256 slices resident on the device; the oracle gets host copies of the slices a test
+    # touches (cut by full_oracle below), as test_max_size_volume_32bit_offsets does
+    import torch
+    from localexpstereo_amd import api, synth
+    H, W, D = 1000, 1500, 256
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    vol = torch.rand((D, H, W), device="cuda", dtype=torch.float32, generator=gen)
+    imL = synth.make_guide(H, W, 1234)
+    e = api.HipCostVolumeEnergy(imL, None, vol.data_ptr(), None, volumes_on_device=True, shape=(D, H, W), max_disp=D - 1)
+    pr = type("P", (), {"e": e, "H": H, "W": W, "D": D, "vol": vol, "imL": imL})()
     yield pr
-    pr.close()
+    e.close()
+    del vol
+    torch.cuda.empty_cache()
+
+
+def full_oracle(pr, lo, n):
+    """Oracle over host copies of slices lo .. lo+n-1 of the full fixture's volume; planes passed to it are shifted by -lo."""
+    sub = pr.vol[lo:lo + n].cpu().numpy()
+    return pc.om.Oracle(pr.imL, None, sub, None, max_disp=n - 1.0)
 
 
 def test_full_size_constant_volume_is_fixed_point():
@@ -143,18 +161,23 @@ def test_full_size_cells_equal_whole_image_and_oracle(full):
     exactness, LES/GuidedFilter.h:298-300), for all cells of one disjoint set of every layer of the
     1500x1000 geometry; (b) sampled cells against the oracle."""
     pr = full
-    plane = np.array([[0.004, -0.006, 9.25, 0.0]], np.float32)
-    whole = pc.run_slabs(pr, plane, check=True)[0]
+    plane = np.array([[0.004, -0.006, 209.25, 0.0]], np.float32)       # disparities 203.3 .. 215.2 over the image: slices 200..219
+    lo, n = 200, 20
+    o = full_oracle(pr, lo, n)
+    plane_o = plane.copy()
+    plane_o[0, 2] -= lo
+    whole = pc.run_slabs(pr, plane, check=False)[0]
     for unit in (15, 45, 135):                                           # LES/main.cpp:395-397 at w = 1500
         layer = pc.om.Layer(pr.W, pr.H, 20, unit)
         cells = layer.sets[len(layer.sets) // 2]
         planes = np.repeat(plane, len(cells), axis=0)
-        got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, check=True)
+        got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, check=False)
         m = ~np.isnan(got)
         assert m.sum() == int(sum(int(r["w"]) * int(r["h"]) for r in layer.shared[cells]))
         assert np.max(np.abs(got[m] - whole[m])) <= 3e-7
         pick = cells[:: max(1, len(cells) // 6)]
-        ref = pr.o.unary_batch(layer.filter[pick], layer.shared[pick], np.repeat(plane, len(pick), axis=0), check=True)
+        # (the validity rule depends on MAX_DISPARITY, which differs between the 256-slice context and the 20-slice oracle: no check)
+        ref = o.unary_batch(layer.filter[pick], layer.shared[pick], np.repeat(plane_o, len(pick), axis=0), check=False)
         mm = ~np.isnan(ref)
         pc.compare_maps(np.where(mm, got, np.nan).astype(np.float32), ref)
 
@@ -355,6 +378,142 @@ def test_gpu_quality_on_cones_crop_naive_energy():
 def test_gpu_quality_on_cones_crop():
     hist = pc.case_quality_cones(None, "cuda", iters=3)
     print("bad1.0 %, energy per iteration:", hist)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[1]: the Adirondack-H shape 1436 x 992, ndisp 256 (synthetic volume generated on the device; the data set
+# itself is not in the container).  Layers 14 / 43 / 129 = 1 % / 3 % / 9 % of the width (LES/main.cpp:395-397).
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def adirondack(oracle_mod):
+    import torch
+    from localexpstereo_amd import api, synth
+    H, W, D = 992, 1436, 256
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    vol = torch.rand((D, H, W), device="cuda", dtype=torch.float32, generator=gen)
+    host = vol.cpu().numpy()                                            # 1.46 GB: the oracle reads the same volume
+    guide = synth.make_guide(H, W, 77)
+    e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, volumes_on_device=True, shape=(D, H, W), max_disp=D - 1)
+    o = pc.om.Oracle(guide, None, host, None, max_disp=D - 1.0)
+    pr = type("P", (), {"e": e, "o": o, "H": H, "W": W, "D": D, "vol": vol, "guide": guide})()
+    yield pr
+    e.close()
+    del vol
+    torch.cuda.empty_cache()
+
+
+def test_adirondack_shape_cells_of_every_layer_vs_oracle(adirondack):
+    """Sampled cells of a disjoint set of every layer (image-border cells included) with random slanted planes over the full
+    256-slice disparity range, D = 256 gathers, validity sentinels: device == oracle; the SURVEY section 8 geometry table holds."""
+    from localexpstereo_amd import api
+    pr = adirondack
+    expect = {14: (103 * 71, 82), 43: (33 * 23, 169), 129: (11 * 8, 427)}
+    for unit in (14, 43, 129):
+        layer = pc.om.Layer(pr.W, pr.H, 20, unit)
+        assert len(layer.unit) == expect[unit][0] and int(layer.filter["w"].max()) == expect[unit][1]
+        for s in (0, len(layer.sets) // 2, len(layer.sets) - 1):
+            cells = layer.sets[s]
+            b = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+            assert b.kernel_kind(0) == 1
+            b.destroy()
+            pick = cells[:: max(1, len(cells) // 5)][:6]
+            planes = pc.random_planes(len(pick), pr.D, pr.H, pr.W, 100 + unit + s, slant=0.15)
+            got = pr.e.unary_batch(layer.filter[pick], layer.shared[pick], planes, check=True)
+            ref = pr.o.unary_batch(layer.filter[pick], layer.shared[pick], planes, check=True)
+            pc.compare_maps(got, ref)
+
+
+def test_adirondack_shape_full_patchmatch_iteration(adirondack):
+    """One full PatchMatch iteration (init + 240 lock-steps, device-resident) at the configs[1] shape: properties that do not need
+    the oracle at this size -- every pixel ends with a finite cost below the invalid sentinel, the WTA update never raises a
+    pixel's cost, labels reproduce their own costs through a fresh evaluation, and the run is deterministic."""
+    import torch
+    from localexpstereo_amd import api, pm
+    pr = adirondack
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)],
+             [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]]                                     # LES/main.cpp:391-397
+    runs = []
+    for rep in range(2):
+        r = pm.PMRunner(pr.e, (14, 43, 129), table, seed=9, device="cuda")
+        r.init_labels()
+        cur0 = r.cur.clone()
+        r.iteration(0)
+        labels, cur = r.labels, r.cur
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(cur).all()) and float(cur.max()) < 1e5
+        assert bool((cur <= cur0).all()), "a winner-take-all update raised a cost"
+        runs.append((labels.cpu().numpy().copy(), cur.cpu().numpy().copy()))
+        r.close()
+    assert runs[0][0].tobytes() == runs[1][0].tobytes() and runs[0][1].tobytes() == runs[1][1].tobytes()
+    # a pixel's stored cost is the aggregated cost of its label at the time it won: re-evaluate the winning label of a few cells
+    labels, cur = runs[0]
+    layer = pc.om.Layer(pr.W, pr.H, 20, 14)
+    cells = layer.sets[5][::60]
+    hit = 0
+    for c in cells:
+        sh, fr = layer.shared[c], layer.filter[c]
+        x, y = int(sh["x"]) + int(sh["w"]) // 2, int(sh["y"]) + int(sh["h"]) // 2
+        plane = labels[y, x]
+        got = pr.e.unary_batch([fr], [sh], plane[None], check=True)
+        ref = pr.o.unary_batch([fr], [sh], plane[None], check=True)
+        pc.compare_maps(got, ref)
+        hit += int(abs(float(got[y, x]) - float(cur[y, x])) <= 2e-6)
+    assert hit >= 1          # later fusions of overlapping cells may have re-assigned the pixel with the same label from another cell
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_adirondack_shape_midv3_end_to_end(dual):
+    """BASELINE configs[1] / [3] substitute: the MidV3 loop of LES/main.cpp:330-420 at 1436 x 992 x 256 on a synthetic scene with
+    ground truth (pmIterations 2, iterations 5, smooth_weight 0.5), unary costs / proposals / graph capacities on the MI355X and
+    the cuts on the host.  The Evaluator row must improve on the PatchMatch-only row, the energy must not increase, and the
+    wall-clock is recorded against north_star's 10 s (single view: asserted; two views on ONE GPU: reported, the 8-GPU cell
+    sharding of configs[3] is what the target is quoted for)."""
+    import os
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    import time
+    from localexpstereo_amd import stereo
+    from localexpstereo_amd.synth import make_scene, ad_volume
+    H, W, D = 992, 1436, 256
+    imL, imR, gt = make_scene(H, W, D)
+    volL = ad_volume(imL, imR, D, "cuda").cpu().numpy()
+    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    t0 = time.perf_counter()
+    st, lab, raw = stereo.MidV3(data, volL, None, iterations=5, pmIterations=2, doDual=dual, smooth_weight=0.5, mc_threshold=0.5,
+                                error_threshold=1.0, device="cuda")
+    wall = time.perf_counter() - t0
+    rows = [(r["index"], round(r["time"], 2), round(r["energy"]), round(r["all"], 2), round(r["nonocc"], 2)) for r in st.log]
+    print(f"Adirondack-H shape, dual={dual}: wall {wall:.2f} s (optimiser {st.seconds:.2f} s), rows (idx, t, E, all, nonocc): {rows}")
+    assert st.log[0]["all"] > 90.0
+    pm_row, last = st.log[2], st.log[-1]
+    assert last["all"] < pm_row["all"] + 0.5 and last["all"] < 20.0
+    en = [r["energy"] for r in st.log[3:8]]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(en, en[1:]))
+    if not dual:
+        assert wall < 10.0, f"single-view Adirondack-shape run took {wall:.1f} s"
+
+
+def test_two_ranks_rccl_equal_one_rank(tmp_path):
+    """SURVEY.md 8(e) on hardware: pm.PMRunner with backend nccl (= RCCL) and the HIP build on 2 GPUs reproduces the 1-rank labels
+    and costs bit for bit.  Needs 2 visible GPUs (the round-end GPU box has one: the test then skips; it runs on the 8-GPU node)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dist_worker.py")
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / f"w{world}.npz")
+        args = [out, "hip", "200", "260", "24", "1", "0"]
+        cmd = ([sys.executable, worker] if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                "--master-port", "29531", worker]) + args
+        subprocess.run(cmd, check=True, timeout=900, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        outs.append(np.load(out))
+    assert int(outs[1]["bytes_exchanged"]) > 0
+    assert outs[0]["labels"].tobytes() == outs[1]["labels"].tobytes() and outs[0]["cur"].tobytes() == outs[1]["cur"].tobytes()
 
 
 def test_max_size_volume_32bit_offsets(oracle_mod):
