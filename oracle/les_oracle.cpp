@@ -1007,3 +1007,159 @@ extern "C" void les_post_process(les_plane* labelsL, les_plane* labelsR, const u
         }
     }
 }
+
+
+// =====================================================================================================================
+// Pairwise terms + graph construction of one expansion move (see les_oracle.h).  Written the way the reference computes
+// it: padded whole-image coefficient maps, padded coordinate / label maps, one matrix per forward neighbour, then the
+// graph in the reference's loop order.  Deliberately NOT the per-node fused form of the product (csrc/les_pairwise.h,
+// host/ExpansionMove.h): the two are compared node by node in tests/.
+// =====================================================================================================================
+namespace {
+
+struct OGraph {                       // the part of Graph<float,float,double> the construction touches [recollection: maxflow-v3.01 graph.h]
+    std::vector<float> tr;            // tr_cap of every node: source capacity - sink capacity
+    double flow = 0.0;
+    explicit OGraph(int n) : tr((size_t)n, 0.0f) {}
+    void add_tweights(int i, float cap_source, float cap_sink)
+    {
+        float delta = tr[(size_t)i];
+        if (delta > 0) cap_source += delta;
+        else cap_sink -= delta;
+        flow += (cap_source < cap_sink) ? cap_source : cap_sink;
+        tr[(size_t)i] = cap_source - cap_sink;
+    }
+};
+
+struct Vec4 { float v[4]; };
+
+// cvutils::channelDot / channelSum: element-wise product, then cv::reduce(REDUCE_SUM) over the 4 channels (LES/Utilities.hpp:215-229)
+inline float channel_dot(const Vec4& a, const Vec4& b)
+{
+    float m[4] = {a.v[0] * b.v[0], a.v[1] * b.v[1], a.v[2] * b.v[2], a.v[3] * b.v[3]};
+    float s = m[0];
+    s += m[1]; s += m[2]; s += m[3];
+    return s;
+}
+
+}  // namespace
+
+extern "C" void les_oracle_expansion_graph(const uint8_t* img, int H, int W, const les_plane* labels, const float* cur, const float* prop,
+                                            les_rect region, les_plane label1, float lambda, float th_smooth, float omega, float epsilon,
+                                            float* payload, double* flow_out)
+{
+    const int M = 1;                                                        // LES/StereoEnergy.h:87
+    const int nbx[8] = {-1, +1, 0, 0, -1, +1, -1, +1}, nby[8] = {0, 0, -1, +1, -1, -1, +1, +1};   // :99-110
+    enum { NB_LE = 0, NB_GE = 1, NB_EL = 2, NB_EG = 3, NB_LL = 4, NB_GL = 5, NB_LG = 6, NB_GG = 7 };
+    const int Wm = W + 2 * M, Hm = H + 2 * M;
+    // ---- initSmoothnessCoeff (:131-163): I is the image as float, padded with a zero border
+    std::vector<float> Im((size_t)Hm * Wm * 3, 0.0f);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < 3; c++) Im[((size_t)(y + M) * Wm + x + M) * 3 + c] = (float)img[((size_t)y * W + x) * 3 + c];
+    std::vector<std::vector<float>> coeff(8, std::vector<float>((size_t)Hm * Wm, 0.0f));     // padded again with zeros (:158-160)
+    for (int i = 0; i < 8; i++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float* ee = &Im[((size_t)(y + M) * Wm + x + M) * 3];
+                const float* nb = &Im[((size_t)(y + M + nby[i]) * Wm + x + M + nbx[i]) * 3];
+                float s = std::fabs(nb[0] - ee[0]);                          // absdiff, then channelSum
+                s += std::fabs(nb[1] - ee[1]); s += std::fabs(nb[2] - ee[2]);
+                float w = std::exp(-s / omega);
+                w = std::max(epsilon, w);                                    // cv::max(params.epsilon, .)
+                // "set invalid pairwise terms to zero" (:147-155)
+                if (nbx[i] < 0 && x < -nbx[i]) w = 0.0f;
+                if (nbx[i] > 0 && x >= W - nbx[i]) w = 0.0f;
+                if (nby[i] < 0 && y < -nby[i]) w = 0.0f;
+                if (nby[i] > 0 && y >= H - nby[i]) w = 0.0f;
+                coeff[i][(size_t)(y + M) * Wm + x + M] = w;
+            }
+    // ---- coordinates_m (zeros in the margin, (x, y, 1, 0) inside, :88-116) and labeling_m (zero margin, LES/PMStereoBase.h:44-47)
+    std::vector<Vec4> coord((size_t)Hm * Wm, Vec4{{0, 0, 0, 0}}), lab((size_t)Hm * Wm, Vec4{{0, 0, 0, 0}});
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            coord[(size_t)(y + M) * Wm + x + M] = Vec4{{(float)x, (float)y, 1.0f, 0.0f}};
+            const les_plane& l = labels[(size_t)y * W + x];
+            lab[(size_t)(y + M) * Wm + x + M] = Vec4{{l.a, l.b, l.c, l.v}};
+        }
+    const Vec4 sc{{label1.a, label1.b, label1.c, label1.v}};                // label1.toScalar()
+    // ---- computeSmoothnessTermsExpansion(labeling_m, label1, region, ..., onlyForward = true) (:398-453)
+    const int rw = region.w, rh = region.h, N = rw * rh;
+    auto at = [&](int x, int y) { return (size_t)(y + M + region.y) * Wm + (x + M + region.x); };   // rect_ee element
+    std::vector<float> d0_ee_at_ee((size_t)N), d1_at_ee((size_t)N);
+    for (int y = 0; y < rh; y++)
+        for (int x = 0; x < rw; x++) {
+            d0_ee_at_ee[(size_t)y * rw + x] = channel_dot(lab[at(x, y)], coord[at(x, y)]);
+            d1_at_ee[(size_t)y * rw + x] = channel_dot(coord[at(x, y)], sc);                   // channelSum(coord_ee.mul(sc))
+        }
+    std::vector<std::vector<float>> cost00(8), cost01(8), cost10(8);
+    for (int i = 0; i < 8; i++) {
+        if (nby[i] * W + nbx[i] <= 0) continue;                             // onlyForward
+        cost00[i].resize((size_t)N); cost01[i].resize((size_t)N); cost10[i].resize((size_t)N);
+        for (int y = 0; y < rh; y++)
+            for (int x = 0; x < rw; x++) {
+                const size_t ee = at(x, y), le = at(x + nbx[i], y + nby[i]);
+                const float d0_le_at_ee = channel_dot(lab[le], coord[ee]);
+                const float d0_ee_at_le = channel_dot(lab[ee], coord[le]);
+                const float d0_le_at_le = channel_dot(lab[le], coord[le]);
+                const float d1_at_le = channel_dot(coord[le], sc);
+                const float w = coeff[i][ee];
+                const size_t k = (size_t)y * rw + x;
+                float c;
+                c = std::fabs(d0_ee_at_ee[k] - d0_le_at_ee) + std::fabs(d0_ee_at_le - d0_le_at_le);
+                c = (c > th_smooth) ? th_smooth : c;                         // cv::threshold(THRESH_TRUNC)
+                cost00[i][k] = c * w * lambda;                               // .mul(coeff, lambda): saturate_cast<float>(a * b * scale)
+                c = std::fabs(d0_ee_at_ee[k] - d1_at_ee[k]) + std::fabs(d0_ee_at_le - d1_at_le);
+                c = (c > th_smooth) ? th_smooth : c;
+                cost01[i][k] = c * w * lambda;
+                c = std::fabs(d1_at_ee[k] - d0_le_at_ee) + std::fabs(d1_at_le - d0_le_at_le);
+                c = (c > th_smooth) ? th_smooth : c;
+                cost10[i][k] = c * w * lambda;
+            }
+    }
+    // computeSmoothnessTerm(ls, lt, ps, neighborId) (:225-230) with Plane::GetZ (LES/Plane.h:51-58)
+    auto getz = [](const les_plane& l, int x, int y) { return l.a * (float)x + l.b * (float)y + l.c; };
+    auto term = [&](const les_plane& ls, const les_plane& lt, int px, int py, int k) {
+        const int tx = px + nbx[k], ty = py + nby[k];
+        const float d = std::fabs(getz(ls, px, py) - getz(lt, px, py)) + std::fabs(getz(ls, tx, ty) - getz(lt, tx, ty));
+        return coeff[k][(size_t)(py + M) * Wm + px + M] * std::min(d, th_smooth) * lambda;
+    };
+    // ---- graph construction (LES/FastGCStereo.h:425-551)
+    OGraph graph(N);
+    std::vector<float> cap((size_t)N * 4, 0.0f);                            // arcs i -> j per forward direction GE, EG, LG, GG
+    for (int y = 0; y < rh; y++)
+        for (int x = 0; x < rw; x++) {
+            const int s = y * rw + x;
+            const int X = region.x + x, Y = region.y + y;
+            graph.add_tweights(s, cur[(size_t)Y * W + X], prop[(size_t)Y * W + X]);          // :433
+            if (x == 0 || x == rw - 1 || y == 0 || y == rh - 1) {
+                for (int k = 0; k < 8; k++) {                                                 // :455-474
+                    const int tx = X + nbx[k], ty = Y + nby[k];
+                    if (tx >= region.x && tx < region.x + rw && ty >= region.y && ty < region.y + rh) continue;
+                    if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+                    const les_plane& lps = labels[(size_t)Y * W + X];
+                    const les_plane& lpt = labels[(size_t)ty * W + tx];
+                    graph.add_tweights(s, term(lps, lpt, X, Y, k), term(label1, lpt, X, Y, k));
+                }
+            }
+        }
+    auto link = [&](int nb, int slot, int x0, int x1, int y1, int jdx, int jdy) {
+        for (int y = 0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int i = y * rw + x, j = (y + jdy) * rw + x + jdx;
+                const float B = cost10[nb][(size_t)i], C = cost01[nb][(size_t)i], D = cost00[nb][(size_t)i];
+                cap[(size_t)i * 4 + slot] += std::max(0.f, B + C - D);       // add_edge(i, j, max(0, B + C - D), 0)
+                graph.add_tweights(i, C, 0);
+                graph.add_tweights(j, D - C, 0);
+            }
+    };
+    link(NB_GE, 0, 0, rw - 1, rh, +1, 0);                                   // :481-492
+    link(NB_EG, 1, 0, rw, rh - 1, 0, +1);                                   // :498-509
+    link(NB_LG, 2, 1, rw, rh - 1, -1, +1);                                  // :517-528
+    link(NB_GG, 3, 0, rw - 1, rh - 1, +1, +1);                              // :534-545
+    for (int s = 0; s < N; s++) {
+        payload[(size_t)s * 5] = graph.tr[(size_t)s];
+        for (int d = 0; d < 4; d++) payload[(size_t)s * 5 + 1 + d] = cap[(size_t)s * 4 + d];
+    }
+    if (flow_out) *flow_out = graph.flow;
+}

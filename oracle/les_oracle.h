@@ -151,6 +151,22 @@ void les_consistency_check(const float* dispL, const float* dispR, int H, int W,
 void les_post_process(les_plane* labelsL, les_plane* labelsR, const uint8_t* imL, const uint8_t* imR, int H, int W, int windR,
                       float threshold, float omega);
 
+/* ---------------- pairwise terms and graph construction of one expansion move ("next" row N1) ----------------
+ * Restates, in the reference's own shape (whole-matrix passes, then the graph built in the reference's loop order):
+ *   StereoEnergy::initSmoothnessCoeff           LES/StereoEnergy.h:131-163   (8 coefficient maps with a 1-pixel zero margin)
+ *   StereoEnergy::computeSmoothnessTerm         LES/StereoEnergy.h:225-230
+ *   StereoEnergy::computeSmoothnessTermsExpansion (onlyForward)  LES/StereoEnergy.h:398-453
+ *   FastGCStereo::expansionMoveBK, graph part   LES/FastGCStereo.h:422-551
+ * img: H x W x 3 BGR uint8 of the view; labels: H x W planes (the current labelling); cur / prop: H x W current and proposal
+ * cost maps; region: the cell's shared region; label1: the proposal.  Output: 5 floats per node, row-major over the region:
+ * { terminal residual (source - sink) after all add_tweights calls, capacity of the arcs i -> j towards GE, EG, LG, GG } and
+ * the flow the t-links already routed.  The BK library is absent from /root/reference: Graph::add_tweights / add_edge are
+ * restated from the published maxflow-v3 semantics [recollection], cv::reduce sums the 4 channels in order in float and
+ * cv::exp is taken as expf [recollection]: this part of the oracle is unpinned like the rest. */
+void les_oracle_expansion_graph(const uint8_t* img, int H, int W, const les_plane* labels, const float* cur, const float* prop,
+                                les_rect region, les_plane label1, float lambda, float th_smooth, float omega, float epsilon,
+                                float* payload, double* flow);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,7 @@ def lib():
         "les_convert_volume_l2r": (None, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "les_consistency_check": (None, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
         "les_post_process": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
+        "les_oracle_expansion_graph": (None, [vp, C.c_int, C.c_int, vp, vp, vp, Rect, Plane, C.c_float, C.c_float, C.c_float, C.c_float, vp, dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -295,3 +296,20 @@ def convert_volume_l2r(vol):
     D, H, W = src.shape
     lib().les_convert_volume_l2r(_ptr(src), _ptr(dst), D, H, W)
     return dst
+
+
+def expansion_graph(img, labels, cur, prop, region, label1, lambda_=1.0, th_smooth=1.0, omega=10.0, epsilon=0.01):
+    """Pairwise terms + graph construction of one expansion move (LES/StereoEnergy.h:131-163, 225-230, 398-453;
+    LES/FastGCStereo.h:422-551) in the reference's own shape.  Returns (payload [N][5] float32, flow)."""
+    L = lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    lab = np.ascontiguousarray(labels, np.float32).reshape(H, W, 4)
+    cur = np.ascontiguousarray(cur, np.float32)
+    prop = np.ascontiguousarray(prop, np.float32)
+    r = Rect(*region)
+    out = np.zeros((r.w * r.h, 5), np.float32)
+    flow = C.c_double(0.0)
+    L.les_oracle_expansion_graph(_ptr(img), H, W, _ptr(lab), _ptr(cur), _ptr(prop), r, Plane(*label1), lambda_, th_smooth, omega, epsilon,
+                                 _ptr(out), C.byref(flow))
+    return out, flow.value

@@ -850,6 +850,17 @@ def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
         diff = got.view(np.uint32) != ref_payload.view(np.uint32)
         assert not diff.any(), f"graph payload differs in {int(diff.sum())} of {diff.size} values (mode {mode}, set {si})"
         assert np.allclose(flow0, ref_flow0, rtol=1e-12, atol=1e-9)
+        # both against the oracle's restatement of LES/StereoEnergy.h:131-163,225-230,398-453 + LES/FastGCStereo.h:422-551 (whole-
+        # matrix passes and the reference's loop order -- not the per-node fused form of the product): bit for bit, every cell
+        img = pr.e.imL if mode == 0 else pr.e.imR
+        for ci in range(len(cells)):
+            r = regions[ci]
+            o_pay, o_flow = om.expansion_graph(img, lab4, cur, prop, (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), tuple(planes[ci]),
+                                               lambda_=lambda_, th_smooth=1.0, omega=10.0, epsilon=0.01)
+            lo, n = int(off[ci]) * 5, int(r["w"]) * int(r["h"]) * 5
+            assert np.array_equal(got[lo:lo + n].view(np.uint32), o_pay.reshape(-1).view(np.uint32)), f"device graph != oracle (cell {ci}, mode {mode})"
+            assert np.array_equal(ref_payload[lo:lo + n].view(np.uint32), o_pay.reshape(-1).view(np.uint32)), f"host graph != oracle (cell {ci}, mode {mode})"
+            assert abs(float(flow0[ci]) - o_flow) <= 1e-9 * max(1.0, abs(o_flow)) and abs(float(ref_flow0[ci]) - o_flow) <= 1e-9 * max(1.0, abs(o_flow))
         assert (got.reshape(-1, 5)[:, 1:] > 0).mean() > 0.2            # the instance has real pairwise structure
         # moves on device-built graphs == moves with the host construction
         flows = g.expansion_moves_prebuilt(regions, planes, prop, got, off, flow0=flow0, mode=mode)
