@@ -18,7 +18,8 @@ from tests.util import GOLDEN, load_cones_crop
 
 RTOL = 1e-4
 ATOL = 1e-6
-TIGHT = 2e-6      # what the fp64-accumulating kernels actually achieve (absolute); regression guard
+TIGHT = 2e-6      # what the kernels actually achieve (absolute, costs in [0, 0.5]); regression guard
+NAIVE_TIGHT = 2e-5  # the image-based matching cost (config 1) lives in [0, 2.8] (th_col 10, th_grad 2, alpha 0.9): achieved 1.1e-5 absolute = 4e-6 of the range
 
 
 def compare_maps(got, ref, tight=True):
@@ -32,7 +33,8 @@ def compare_maps(got, ref, tight=True):
     err = np.abs(got[v].astype(np.float64) - ref[v])
     assert np.all(err <= RTOL * np.abs(ref[v]) + ATOL), f"parity: max abs err {err.max():.3e}"
     if tight:
-        assert err.max() <= TIGHT, f"accuracy regression: max abs err {err.max():.3e}"
+        bound = TIGHT if tight is True else float(tight)
+        assert err.max() <= bound, f"accuracy regression: max abs err {err.max():.3e} > {bound:.1e}"
     return float(err.max())
 
 
@@ -87,14 +89,14 @@ def case_naive(lib, windR=20, pm=True):
         for check in (True, False):
             ref = pr.o.unary(fr, tr, pl, mode=mode, check=check)
             got = pr.e.ComputeUnaryPotential(fr, tr, np.full((H, W), np.nan, np.float32), pl, mode=mode, check=check)
-            worst = max(worst, compare_maps(got, ref, tight=False))
+            worst = max(worst, compare_maps(got, ref, tight=NAIVE_TIGHT))
     layer = om.Layer(W, H, windR, 9)
     for s, mode in ((0, 0), (7, 1)):
         cells = layer.sets[s]
         planes = random_planes(len(cells), 32, H, W, 17 + s, slant=0.2)
         ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
         got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
-        worst = max(worst, compare_maps(got, ref, tight=False))
+        worst = max(worst, compare_maps(got, ref, tight=NAIVE_TIGHT))
     pr.close()
     return worst
 
@@ -402,9 +404,11 @@ def case_proposers(pr, unit=14, set_index=5, seed=11):
                         blk = lab_after[u["y"]:u["y"] + u["h"], u["x"]:u["x"] + u["w"]]
                         assert np.all(blk == got[i])
             else:
-                same = np.all(np.abs(g4 - r4) <= 1e-4 * np.maximum(1, np.abs(r4)), axis=1)
-                assert same.mean() >= 0.95, f"ransac agreement {same.mean()}"
-                assert np.mean(st == rst) >= 0.95
+                # RANSAC has no trigonometry: the defined accumulation order of the eigen-solve makes device and oracle proposals
+                # bit-identical on the MI355X as in the simulator (630 / 630 cells over three layers and noise levels,
+                # tools/ransac_agreement.py), generator states included
+                assert got.tobytes() == ref.tobytes(), f"ransac proposals differ in {int((~np.all(g4 == r4, axis=1)).sum())} of {n} cells"
+                assert np.array_equal(st, rst)
     finally:
         for d in (d_lab, d_rng, d_pl):
             d.free()
@@ -536,9 +540,11 @@ def case_pm_iteration(pr, layers_units=(12, 36), seed=21, plane_exact=True):
                     if plane_exact:
                         assert gp.tobytes() == planes.tobytes(), f"proposals differ (kind {kind})"
                         assert np.array_equal(d_rng.download((n,), np.uint64), new_st)
+                    elif kind != api.PROPOSE_RANDOM:
+                        assert gp.tobytes() == planes.tobytes(), f"proposals differ (kind {kind})"      # no trigonometry: exact on hardware too
                     else:
                         ok = np.all(np.abs(g4 - r4) <= 1e-4 * np.maximum(1, np.abs(r4)), axis=1)
-                        assert ok.mean() >= 0.9, f"proposal agreement {ok.mean()} (kind {kind})"
+                        assert ok.all(), f"proposal agreement {ok.mean()} (kind {kind})"
                     if gp.tobytes() == planes.tobytes():
                         gprop = d_prop.download((H, W), np.float32)
                         worst = max(worst, compare_maps(np.where(np.isnan(prop), np.nan, gprop).astype(np.float32), prop))
