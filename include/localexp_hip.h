@@ -82,6 +82,18 @@ int les_hip_synchronize(les_hip_ctx* ctx);
 int les_hip_unary_one(les_hip_ctx* ctx, int mode, const les_hip_rect* filterRect, const les_hip_rect* targetRect,
                       const les_hip_plane* plane, float* costs, int row_stride, int check);
 
+/* The re-entrant form of the same operator: `scratch` is the caller-owned per-cell scratch of the reference (struct Reusable,
+ * LES/StereoEnergy.h:616-623: one per OpenMP thread / cell visit, LES/FastGCStereo.h:40).  It owns a HIP stream, a device tile
+ * and pinned staging for the target rect, and the prepared job tables of the last 16 (filterRect, targetRect) pairs, so that
+ * calls with distinct scratch objects may run concurrently from distinct host threads on one context (the method is `const`
+ * and is called from an OpenMP team in the reference, LES/FastGCStereo.h:30-49) and nothing is allocated once a rect pair has
+ * been seen.  les_hip_unary_one() itself uses one hidden scratch per calling thread, released with the context. */
+typedef struct les_hip_scratch les_hip_scratch;
+int les_hip_scratch_create(les_hip_ctx* ctx, les_hip_scratch** out);
+void les_hip_scratch_destroy(les_hip_scratch* scratch);
+int les_hip_unary_one_scratch(les_hip_ctx* ctx, les_hip_scratch* scratch, int mode, const les_hip_rect* filterRect,
+                              const les_hip_rect* targetRect, const les_hip_plane* plane, float* costs, int row_stride, int check);
+
 /* The same for n independent calls (one proposal index of one disjoint set of cells:
  * LES/FastGCStereo.h:30-49 run in lock-step) writing into one H x W map.  cost_map: HOST H*W floats;
  * only the target rects are written.  Synchronous. */

@@ -18,7 +18,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 # every symbol include/localexp_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
-    "les_hip_unary_one", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
+    "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
     "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
@@ -78,6 +78,9 @@ def load(path=None):
         "les_hip_synchronize": (ci, [vp]),
         "les_hip_unary_one": (ci, [vp, ci, vp, vp, vp, vp, ci, ci]),
         "les_hip_unary_batch": (ci, [vp, ci, ci, vp, vp, vp, vp, ci]),
+        "les_hip_unary_one_scratch": (ci, [vp, vp, ci, vp, vp, vp, vp, ci, ci]),
+        "les_hip_scratch_create": (ci, [vp, C.POINTER(vp)]),
+        "les_hip_scratch_destroy": (None, [vp]),
         "les_hip_batch_create": (ci, [vp, ci, vp, vp, ci, C.POINTER(vp)]),
         "les_hip_batch_destroy": (None, [vp]),
         "les_hip_batch_num_jobs": (ci, [vp]),
@@ -331,6 +334,23 @@ class HipCostVolumeEnergy:
         pl = _planes([plane])
         origin = costs_map.ctypes.data + 4 * (int(fr["y"][0]) * self.W + int(fr["x"][0]))
         self._chk(self.L.les_hip_unary_one(self.h, mode, _ptr(fr), _ptr(tr), _ptr(pl), C.c_void_p(origin), self.W, int(check)))
+        return costs_map
+
+    def scratch(self):
+        """A caller-owned scratch handle (struct Reusable of the reference): calls through distinct handles may run concurrently."""
+        h = C.c_void_p()
+        self._chk(self.L.les_hip_scratch_create(self.h, C.byref(h)))
+        return h
+
+    def scratch_free(self, h):
+        self.L.les_hip_scratch_destroy(h)
+
+    def ComputeUnaryPotentialScratch(self, scratch, filterRect, targetRect, costs_map, plane, mode=0, check=True):
+        """les_hip_unary_one_scratch: the re-entrant operator (ctypes releases the GIL during the call)."""
+        fr, tr = _rects([filterRect]), _rects([targetRect])
+        pl = _planes([plane])
+        origin = costs_map.ctypes.data + 4 * (int(fr["y"][0]) * self.W + int(fr["x"][0]))
+        self._chk(self.L.les_hip_unary_one_scratch(self.h, scratch, mode, _ptr(fr), _ptr(tr), _ptr(pl), C.c_void_p(origin), self.W, int(check)))
         return costs_map
 
     def ComputeUnaryPotentialWithoutCheck(self, filterRect, targetRect, costs_map, plane, mode=0):

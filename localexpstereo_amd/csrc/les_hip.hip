@@ -152,6 +152,7 @@ struct les_hip_ctx {
     // smoothness-coefficient table of the pairwise terms, cached per (omega, epsilon)
     float* d_pw_tab = nullptr; float pw_omega = -1.f, pw_epsilon = -1.f;
     std::mutex mu;                       // guards the lazily built tables when two host threads (the two views) share the context
+    std::vector<les_hip_scratch*> own_scratch;   // scratch objects created behind les_hip_unary_one (one per calling thread), freed with the context
 };
 
 struct les_hip_batch {
@@ -175,6 +176,20 @@ struct les_hip_batch {
     long long graph_nodes = 0;
     long long* d_graph_off = nullptr;
     double* d_flow0 = nullptr;           // n * wta_chunks partial sums
+};
+
+// Caller-owned scratch of the one-call operator (the reference's `Reusable`, LES/StereoEnergy.h:616-623): its own stream, a
+// compact device tile for the target rect, pinned host staging, and the job tables of the (filterRect, targetRect) pairs it has
+// seen -- a cell visit calls the operator ~10 times with the same rects (LES/FastGCStereo.h:40-49).  Distinct scratch objects
+// may be used concurrently from distinct host threads on one context; nothing is allocated once a rect pair is known.
+struct les_hip_scratch {
+    les_hip_ctx* c = nullptr;
+    hipStream_t stream = nullptr;
+    float* d_tile = nullptr; float* h_tile = nullptr; size_t tile_cap = 0;        // floats
+    float4* d_plane = nullptr; float4* h_plane = nullptr;
+    struct Entry { les_hip_rect f, t; int want_march; const void* march; int njobs, ngroups; les::Job* d_jobs; unsigned long long stamp; };
+    std::vector<Entry> cache;
+    unsigned long long clock = 0;
 };
 
 namespace {
@@ -332,22 +347,23 @@ int ensure_planes(les_hip_ctx* c, size_t n)
     return LES_HIP_OK;
 }
 
-int launch_march(les_hip_ctx* c, const MarchEntry* m, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check)
+int launch_march(les_hip_ctx* c, const MarchEntry* m, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check,
+                 hipStream_t stream)
 {
     if (ngroups <= 0) return LES_HIP_OK;
-    hipLaunchKernelGGL(m->fn, dim3(ngroups), dim3(m->NT), 0, c->stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
+    hipLaunchKernelGGL(m->fn, dim3(ngroups), dim3(m->NT), 0, stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
 
-int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, const float4* d_planes, float* d_out, int check)
+int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, const float4* d_planes, float* d_out, int check, hipStream_t stream)
 {
     if (njobs <= 0) return LES_HIP_OK;
     if (mode < 0 || mode > 1 || !c->v[mode].stats || (c->naive ? !c->v[1 - mode].feat : !c->v[mode].vol))
         return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
     les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, c->v[mode].ipk10, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
     if (c->naive) { view.feat_self = c->v[mode].feat; view.feat_other = c->v[1 - mode].feat; }
-    hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, c->stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
+    hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -554,6 +570,8 @@ void les_hip_destroy(les_hip_ctx* c)
         if (c->v[m].ipk8) (void)hipFree(c->v[m].ipk8);
         if (c->v[m].mstats) (void)hipFree(c->v[m].mstats);
     }
+    for (les_hip_scratch* sc : c->own_scratch) les_hip_scratch_destroy(sc);
+    c->own_scratch.clear();
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_wta) (void)hipFree(c->d_wta);
@@ -818,8 +836,8 @@ int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const le
         d_planes = c->d_planes;
     }
     if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok)
-        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check);
-    return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check);
+        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, c->stream);
+    return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check, c->stream);
 }
 
 int les_hip_unary_batch(les_hip_ctx* c, int mode, int n, const les_hip_rect* frs, const les_hip_rect* trs,
@@ -846,25 +864,129 @@ int les_hip_unary_batch(les_hip_ctx* c, int mode, int n, const les_hip_rect* frs
     return rc;
 }
 
+int les_hip_scratch_create(les_hip_ctx* c, les_hip_scratch** out)
+{
+    if (!c || !out) return fail(LES_HIP_ERR_ARG, "null argument");
+    *out = nullptr;
+    HIPCHECK(hipSetDevice(c->p.device));
+    les_hip_scratch* s = new les_hip_scratch();
+    s->c = c;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&s->d_plane, sizeof(float4)) != hipSuccess || hipHostMalloc((void**)&s->h_plane, sizeof(float4), hipHostMallocDefault) != hipSuccess) {
+        les_hip_scratch_destroy(s);
+        return fail(LES_HIP_ERR_DEVICE, "scratch allocation failed");
+    }
+    *out = s;
+    return LES_HIP_OK;
+}
+
+void les_hip_scratch_destroy(les_hip_scratch* s)
+{
+    if (!s) return;
+    if (s->c) (void)hipSetDevice(s->c->p.device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    for (auto& e : s->cache) if (e.d_jobs) (void)hipFree(e.d_jobs);
+    if (s->d_tile) (void)hipFree(s->d_tile);
+    if (s->h_tile) (void)hipHostFree(s->h_tile);
+    if (s->d_plane) (void)hipFree(s->d_plane);
+    if (s->h_plane) (void)hipHostFree(s->h_plane);
+    delete s;
+}
+
+int les_hip_unary_one_scratch(les_hip_ctx* c, les_hip_scratch* s, int mode, const les_hip_rect* fr, const les_hip_rect* tr,
+                              const les_hip_plane* plane, float* costs, int row_stride, int check)
+{
+    if (!c || !s || !fr || !tr || !plane || !costs) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (s->c != c) return fail(LES_HIP_ERR_ARG, "scratch belongs to another context");
+    if (mode < 0 || mode > 1 || !c->v[mode].stats || (c->naive ? !c->v[1 - mode].feat : !c->v[mode].vol))
+        return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
+    HIPCHECK(hipSetDevice(c->p.device));                  // HIP's current device is per host thread
+    int rc = check_rects(c, *fr, *tr);
+    if (rc) return rc;
+    if (tr->w <= 0 || tr->h <= 0) return LES_HIP_OK;
+    // ---- job table of this rect pair (built and uploaded the first time it is seen; 16 pairs are remembered)
+    const int want_march = (c->march && c->v[mode].march_ok) ? 1 : 0;      // per view: the march kernel needs a finite, bounded volume
+    les_hip_scratch::Entry* e = nullptr;
+    for (auto& x : s->cache)
+        if (x.want_march == want_march && !memcmp(&x.f, fr, sizeof *fr) && !memcmp(&x.t, tr, sizeof *tr)) { e = &x; break; }
+    if (!e) {
+        std::vector<les::Job> jobs;
+        bool mok = false;
+        const MarchEntry* me = nullptr;
+        if (want_march) build_march_jobs(c, 1, fr, tr, 0, jobs, mok, me);
+        const bool use_march = want_march && mok && !jobs.empty();
+        if (!use_march) {
+            rc = build_jobs(c, 1, fr, tr, 0, jobs);
+            if (rc) return rc;
+            me = nullptr;
+        }
+        for (auto& j : jobs) {                           // compact tile: row stride = target width, origin = target corner
+            j.out_off = (long long)(j.ty0 - tr->y) * tr->w + (j.tx0 - tr->x);
+            j.out_stride = tr->w;
+        }
+        les_hip_scratch::Entry ne{*fr, *tr, want_march, me, (int)jobs.size(), me ? (int)(jobs.size() / me->NJ) : 0, nullptr, 0};
+        if (s->cache.size() >= 16) {                     // evict the least recently used pair
+            size_t k = 0;
+            for (size_t i = 1; i < s->cache.size(); i++) if (s->cache[i].stamp < s->cache[k].stamp) k = i;
+            HIPCHECK(hipStreamSynchronize(s->stream));
+            if (s->cache[k].d_jobs) HIPCHECK(hipFree(s->cache[k].d_jobs));
+            s->cache.erase(s->cache.begin() + (long)k);
+        }
+        HIPCHECK(hipMalloc((void**)&ne.d_jobs, jobs.size() * sizeof(les::Job)));
+        if (hipMemcpy(ne.d_jobs, jobs.data(), jobs.size() * sizeof(les::Job), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(ne.d_jobs);
+            return fail(LES_HIP_ERR_DEVICE, "upload of the job table failed");
+        }
+        s->cache.push_back(ne);
+        e = &s->cache.back();
+    }
+    e->stamp = ++s->clock;
+    const size_t need = (size_t)tr->w * tr->h;
+    if (need > s->tile_cap) {
+        HIPCHECK(hipStreamSynchronize(s->stream));
+        if (s->d_tile) HIPCHECK(hipFree(s->d_tile));
+        if (s->h_tile) HIPCHECK(hipHostFree(s->h_tile));
+        s->d_tile = nullptr; s->h_tile = nullptr; s->tile_cap = 0;
+        const size_t cap = std::max(need, (size_t)256 * 256);
+        HIPCHECK(hipMalloc((void**)&s->d_tile, cap * sizeof(float)));
+        HIPCHECK(hipHostMalloc((void**)&s->h_tile, cap * sizeof(float), hipHostMallocDefault));
+        s->tile_cap = cap;
+    }
+    *s->h_plane = make_float4(plane->a, plane->b, plane->c, plane->v);
+    HIPCHECK(hipMemcpyAsync(s->d_plane, s->h_plane, sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    if (e->march) rc = launch_march(c, static_cast<const MarchEntry*>(e->march), mode, e->d_jobs, e->ngroups, s->d_plane, s->d_tile, check, s->stream);
+    else rc = launch_strips(c, mode, e->d_jobs, e->njobs, s->d_plane, s->d_tile, check, s->stream);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(s->h_tile, s->d_tile, need * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHECK(hipStreamSynchronize(s->stream));
+    // costs(targetRect - filterRect.tl()), LES/CostVolumeEnergy.h:169
+    float* dst = costs + (size_t)(tr->y - fr->y) * row_stride + (tr->x - fr->x);
+    for (int y = 0; y < tr->h; y++) memcpy(dst + (size_t)y * row_stride, s->h_tile + (size_t)y * tr->w, (size_t)tr->w * sizeof(float));
+    return LES_HIP_OK;
+}
+
 int les_hip_unary_one(les_hip_ctx* c, int mode, const les_hip_rect* fr, const les_hip_rect* tr, const les_hip_plane* plane,
                       float* costs, int row_stride, int check)
 {
     if (!c || !fr || !tr || !plane || !costs) return fail(LES_HIP_ERR_ARG, "null argument");
-    les_hip_batch* b = nullptr;
-    int rc = les_hip_batch_create(c, 1, fr, tr, 0, &b);
-    if (rc) return rc;
-    rc = les_hip_batch_run(c, b, mode, plane, 0, c->d_map, check);
-    if (rc == LES_HIP_OK && tr->w > 0 && tr->h > 0) {
-        // costs(targetRect - filterRect.tl()), LES/CostVolumeEnergy.h:169
-        float* dst = costs + (size_t)(tr->y - fr->y) * row_stride + (tr->x - fr->x);
-        const float* src = c->d_map + (size_t)tr->y * c->p.W + tr->x;
-        hipError_t e = hipMemcpy2DAsync(dst, (size_t)row_stride * sizeof(float), src, (size_t)c->p.W * sizeof(float),
-                                        (size_t)tr->w * sizeof(float), (size_t)tr->h, hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
-        else if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "stream synchronize failed");
+    // one scratch per (calling thread, context), created on the thread's first call and owned by the context
+    thread_local std::vector<std::pair<les_hip_ctx*, les_hip_scratch*>> mine;
+    les_hip_scratch* s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);            // (the context may have been destroyed and its address reused: its registry is the truth)
+        for (auto it = mine.begin(); it != mine.end();) {
+            if (it->first == c && std::find(c->own_scratch.begin(), c->own_scratch.end(), it->second) != c->own_scratch.end()) { s = it->second; break; }
+            if (it->first == c) it = mine.erase(it); else ++it;
+        }
     }
-    les_hip_batch_destroy(b);
-    return rc;
+    if (!s) {
+        int rc = les_hip_scratch_create(c, &s);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->own_scratch.push_back(s);
+        mine.emplace_back(c, s);
+    }
+    return les_hip_unary_one_scratch(c, s, mode, fr, tr, plane, costs, row_stride, check);
 }
 
 int les_hip_wta_update(les_hip_ctx* c, int n, const les_hip_rect* rects, const les_hip_plane* planes, int planes_on_device,

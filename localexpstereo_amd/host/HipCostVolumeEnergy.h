@@ -77,7 +77,7 @@ public:
                                     const std::vector<Plane>& planes, float* cost_map, int mode = 0, bool check = true) const
     {
         static_assert(sizeof(Rect) == sizeof(les_hip_rect) && sizeof(Plane) == sizeof(les_hip_plane), "ABI layout");
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<std::mutex> lk(mu_);               // the batched form uses the context's own stream and scratch map
         if (les_hip_unary_batch(ctx_, mode, (int)filterRects.size(), reinterpret_cast<const les_hip_rect*>(filterRects.data()),
                                 reinterpret_cast<const les_hip_rect*>(targetRects.data()),
                                 reinterpret_cast<const les_hip_plane*>(planes.data()), cost_map, check ? 1 : 0) != LES_HIP_OK)
@@ -91,13 +91,9 @@ private:
     {
         const les_hip_rect f{fr.x, fr.y, fr.width, fr.height}, t{tr.x, tr.y, tr.width, tr.height};
         const les_hip_plane p{plane.a, plane.b, plane.c, plane.v};
-        int rc;
-        {
-            // the context owns one stream and one scratch map: concurrent callers are serialised here (the
-            // batched form is the one meant for throughput)
-            std::lock_guard<std::mutex> lk(mu_);
-            rc = les_hip_unary_one(ctx_, mode, &f, &t, &p, costs, row_stride, check);
-        }
+        // re-entrant: the library keeps one scratch (stream, device tile, pinned staging, job tables of the recent rect pairs) per
+        // calling thread, so the OpenMP threads of the reference loop (LES/FastGCStereo.h:30-49) run their cells concurrently
+        const int rc = les_hip_unary_one(ctx_, mode, &f, &t, &p, costs, row_stride, check);
         if (rc != LES_HIP_OK) {
             fprintf(stderr, "HipCostVolumeEnergy: %s\n", les_hip_last_error());
             for (int y = 0; y < tr.height; y++)

@@ -13,6 +13,7 @@
 // the unary costs still come from the GPU; the graph cuts of the cells of a set run on the host cores (OpenMP) and
 // the updated label map goes back to the device after every lock-step.
 #pragma once
+#include <stdexcept>
 
 #include <omp.h>
 
@@ -138,7 +139,6 @@ public:
                 StereoEnergy::Reusable reusable;
                 for (const ProposerSpec& spec : layerProposers[li]) {
                     std::unique_ptr<IProposer> prop(makeHostProposer(spec));
-                    if (!prop) continue;                       // RANSAC: device-only in this framework
                     prop->startIterations(currentLabeling, unitRegion, iteration, &rng);
                     while (prop->isContinued()) {
                         const Plane label = prop->getNextProposal();
@@ -389,7 +389,8 @@ private:
     {
         if (s.kind == LES_HIP_PROPOSE_EXPANSION) return new ExpansionProposer(s.K);
         if (s.kind == LES_HIP_PROPOSE_RANDOM) return new RandomProposer(s.K, MAX_DISPARITY, MIN_DISPARITY);
-        return nullptr;
+        if (s.kind == LES_HIP_PROPOSE_RANSAC) return new RansacProposer(s.K);                        // MAX_SAM 500, conf 0.95, LES/Proposer.h:265
+        throw std::runtime_error("PMStereo: unknown proposer kind in the layer table");
     }
 
     const int width, height;

@@ -78,15 +78,15 @@ static int cmd_run(int argc, char** argv)
         auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
         st->setSeed(seed);
         st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp));
-        // LES/main.cpp:391-397 layer set-up (RANSAC only exists on the device side)
         return st;
     };
     int fail = 0;
     // (a) drop-in operator called per cell from OpenMP threads (reference loop shape)
     {
         auto st = build(7);
-        st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
-        st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}});
+        // the reference's own proposer table (LES/main.cpp:391-397), RANSAC included, through the host proposers
+        st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
         st->initCurrentFast(0);
         double e_prev = st->totalCost(0);
         printf("drop-in   iter 0  E=%.1f  bad1.0=%.2f%%\n", e_prev, bad_pixels(st->computeDisparities(0), s, 1.0f));
@@ -163,6 +163,50 @@ static int cmd_run(int argc, char** argv)
         printf("two views iter %d + post-processing: %.2f%% of the left labels replaced, bad1.0=%.2f%%  (%.3f s)\n", iters,
                100.0 * changed / st->rawLabeling0.data.size(), bad, sec);
         if (changed == 0) { printf("FAIL: post-processing changed nothing\n"); fail = 1; }
+    }
+    // (e) host RansacProposer == device RANSAC kernels: same label map, same generator states -> identical planes and states
+    {
+        auto st = build(11);
+        LabelMap lab(H, W);
+        RNG g0(99);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const int by = y / 23, bx = x / 31;                                          // piecewise planes + noise on c
+                lab.at(y, x) = Plane{0.01f * (float)(bx % 3 - 1), 0.02f * (float)(by % 3 - 1), 3.0f + (float)((bx * 7 + by * 5) % 20) + g0.uniform(-0.4f, 0.4f), 0.0f};
+            }
+        std::vector<les_hip_rect> units;
+        for (int y = 0; y + 15 <= H; y += 37)
+            for (int x = 0; x + 14 <= W; x += 29) units.push_back(les_hip_rect{x, y, 14, 15});
+        units.push_back(les_hip_rect{W - 40, H - 33, 40, 33});
+        const int n = (int)units.size();
+        std::vector<uint64_t> seeds((size_t)n), dev_states((size_t)n);
+        for (int i = 0; i < n; i++) seeds[(size_t)i] = 0x1234567ULL * (uint64_t)(i + 1) + 77;
+        std::vector<Plane> host_planes((size_t)n), dev_planes((size_t)n);
+        std::vector<uint64_t> host_states((size_t)n);
+        for (int i = 0; i < n; i++) {
+            RNG r(seeds[(size_t)i]);
+            RansacProposer prop(1);
+            prop.startIterations(lab, Rect{units[(size_t)i].x, units[(size_t)i].y, units[(size_t)i].w, units[(size_t)i].h}, 0, &r);
+            host_planes[(size_t)i] = prop.getNextProposal();
+            host_states[(size_t)i] = r.state;
+        }
+        les_hip_ctx* c = static_cast<const HipCostVolumeEnergy&>(st->getEnergyInstance()).handle();
+        les_hip_batch* b = nullptr;
+        void *d_lab = nullptr, *d_rng = nullptr, *d_pl = nullptr;
+        int rc = les_hip_batch_create(c, n, units.data(), units.data(), 0, &b);
+        rc |= les_hip_batch_set_units(c, b, units.data());
+        rc |= les_hip_malloc(c, &d_lab, (size_t)H * W * 16) | les_hip_malloc(c, &d_rng, (size_t)n * 8) | les_hip_malloc(c, &d_pl, (size_t)n * 16);
+        rc |= les_hip_memcpy_h2d(c, d_lab, lab.data.data(), (size_t)H * W * 16) | les_hip_memcpy_h2d(c, d_rng, seeds.data(), (size_t)n * 8);
+        rc |= les_hip_batch_propose(c, b, LES_HIP_PROPOSE_RANSAC, 0, (les_hip_plane*)d_lab, (uint64_t*)d_rng, (les_hip_plane*)d_pl);
+        rc |= les_hip_synchronize(c);
+        rc |= les_hip_memcpy_d2h(c, dev_planes.data(), d_pl, (size_t)n * 16) | les_hip_memcpy_d2h(c, dev_states.data(), d_rng, (size_t)n * 8);
+        int diff = 0;
+        for (int i = 0; i < n; i++)
+            diff += memcmp(&host_planes[(size_t)i], &dev_planes[(size_t)i], 16) != 0 || host_states[(size_t)i] != dev_states[(size_t)i];
+        printf("RANSAC proposer host vs device: %d cells, %d differences (rc %d)\n", n, diff, rc);
+        if (rc || diff) { printf("FAIL: host RansacProposer differs from the device kernels\n"); fail = 1; }
+        les_hip_free(c, d_lab); les_hip_free(c, d_rng); les_hip_free(c, d_pl);
+        les_hip_batch_destroy(b);
     }
     printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
     return fail;

@@ -276,6 +276,48 @@ def test_gpu_march_vs_strip_kernel(oracle_mod, monkeypatch):
         assert np.max(np.abs(a[v] - b[v])) <= 1e-6
 
 
+def test_gpu_unary_one_reentrant_16_threads(mid):
+    """The operator is const and is called from an OpenMP team in the reference (LES/FastGCStereo.h:30-49, one Reusable per
+    thread): 16 host threads, each with its own scratch handle, evaluate disjoint cells concurrently (ctypes releases the GIL),
+    several proposals per cell like a cell visit (the job table of a rect pair is built once); every result equals the batch path
+    bit for bit.  A second round goes through les_hip_unary_one itself (the library's hidden per-thread scratch)."""
+    import threading
+    e = mid.e
+    layer = pc.om.Layer(mid.W, mid.H, 20, 15)
+    cells = layer.sets[3][:48]
+    props = [pc.random_planes(len(cells), mid.D, mid.H, mid.W, 300 + k, slant=0.1) for k in range(3)]
+    refs = [e.unary_batch(layer.filter[cells], layer.shared[cells], p, check=True) for p in props]
+    for hidden in (False, True):
+        outs = [np.full((mid.H, mid.W), np.nan, np.float32) for _ in props]
+        errs = []
+
+        def work(tid):
+            try:
+                h = None if hidden else e.scratch()
+                for ci in range(tid, len(cells), 16):
+                    fr = tuple(int(v) for v in layer.filter[cells[ci]])
+                    tr = tuple(int(v) for v in layer.shared[cells[ci]])
+                    for k, p in enumerate(props):
+                        if hidden:
+                            e.ComputeUnaryPotential(fr, tr, outs[k], tuple(p[ci]), mode=0, check=True)
+                        else:
+                            e.ComputeUnaryPotentialScratch(h, fr, tr, outs[k], tuple(p[ci]), mode=0, check=True)
+                if h is not None:
+                    e.scratch_free(h)
+            except Exception as ex:           # pragma: no cover
+                errs.append(ex)
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        for got, ref in zip(outs, refs):
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            m = ~np.isnan(ref)
+            assert got[m].tobytes() == ref[m].tobytes(), "one-call operator differs from the batch path"
+
+
 def test_gpu_proposers(mid):
     pc.case_proposers(mid, unit=15, set_index=5)
 
