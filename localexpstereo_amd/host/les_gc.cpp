@@ -37,11 +37,14 @@ int defaultThreads(int requested, int n)
 
 // Row bands of the parallel first max-flow phase: only for large regions (the coarsest layer: 4-6 cells of ~400 x 400 nodes per
 // lock-step, which leave most of the host idle), up to 8 bands and never more threads in total than the machine has.
-int bandsFor(const Rect& region, int cells_in_lockstep)
+// The band count is a function of the region size ONLY (not of the machine or of how many cells a rank happens to cut in the
+// lock-step): the search order inside a cut -- and with float capacities possibly a tie between equal-energy cuts -- must not
+// depend on the host or on the world size.
+int bandsFor(const Rect& region, int /*cells_in_lockstep*/)
 {
-    if ((long long)region.width * region.height < 40000) return 1;
-    const int spare = omp_get_max_threads() / std::max(1, cells_in_lockstep);
-    return std::max(1, std::min(8, spare));
+    const long long nodes = (long long)region.width * region.height;
+    if (nodes < 40000) return 1;
+    return (int)std::max<long long>(2, std::min<long long>(8, nodes / 20000));
 }
 
 // the pairwise half of StereoEnergy; the unary operator lives on the GPU and is never called through this object
@@ -157,6 +160,12 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
                           double* flows)
 {
     if (n < 0 || (n > 0 && (!regions || !payload || !offsets || !masks))) return fail("les_gc_solve_prebuilt: bad argument");
+    // the payload / mask buffers are indexed through offsets[]: they must describe disjoint node ranges in call order
+    for (int i = 0; i < n; i++) {
+        if (regions[i].w < 0 || regions[i].h < 0 || offsets[i] < 0) return fail("les_gc_solve_prebuilt: negative region size or offset (call %d)", i);
+        if (i > 0 && offsets[i] < offsets[i - 1] + (long long)regions[i - 1].w * regions[i - 1].h)
+            return fail("les_gc_solve_prebuilt: offsets[%d] overlaps the nodes of call %d", i, i - 1);
+    }
     nthreads = defaultThreads(nthreads, n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int i = 0; i < n; i++) {
@@ -173,6 +182,13 @@ int les_gc_build_graphs(les_gc_ctx* c, int mode, int n, const les_hip_rect* regi
 {
     if (!c || mode < 0 || mode > 1 || n < 0 || (n > 0 && (!regions || !planes || !proposal_cost || !payload || !offsets))) return fail("les_gc_build_graphs: bad argument");
     if (!c->E->hasImages(mode)) return fail("les_gc_build_graphs: view %d has no image", mode);
+    for (int i = 0; i < n; i++) {
+        const les_hip_rect& r = regions[i];
+        if (r.w < 0 || r.h < 0 || (r.w > 0 && r.h > 0 && (r.x < 0 || r.y < 0 || r.x + r.w > c->W || r.y + r.h > c->H)))
+            return fail("les_gc_build_graphs: region %d outside the image", i);
+        if (offsets[i] < 0 || (i > 0 && offsets[i] < offsets[i - 1] + (long long)regions[i - 1].w * regions[i - 1].h))
+            return fail("les_gc_build_graphs: offsets[%d] overlaps the nodes of call %d", i, i - 1);
+    }
     const CostView prop(proposal_cost, c->W);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int i = 0; i < n; i++) {

@@ -42,7 +42,7 @@ def read_pfm(path):
     w*h*channels floats of the file (the reference seeks from the end); rows are stored bottom-up."""
     with open(path, "rb") as f:
         data = f.read()
-    m = re.match(rb"^(P[fF])\s+(\d+)\s+(\d+)\s+(-?[0-9.eE+]+)\s", data)
+    m = re.match(rb"^(P[fF])\s+(\d+)\s+(\d+)\s+([-+]?(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][-+]?[0-9]+)?)\s", data)    # %lf of the reference: 1e-05, -3.9e-03, ...
     if not m:
         raise ValueError(f"{path}: not a 1/3 channel PFM file")
     ch = 1 if m.group(1) == b"Pf" else 3

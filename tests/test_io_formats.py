@@ -77,3 +77,15 @@ def test_load_data_cones():
     assert np.isinf(gt).any() and np.nanmax(gt[np.isfinite(gt)]) <= 64
     ev = lio.Evaluator(gt, d["nonocc"], 0.5)
     assert ev.evaluate(np.where(np.isfinite(gt), gt, 0))[0] == 0.0
+
+
+def test_read_pfm_accepts_exponent_scales(tmp_path):
+    """The reference parses the scale with fscanf %lf (LES/Utilities.hpp:20-82): 1e-05, -3.9e-03, +1.E+0 are valid headers."""
+    from localexpstereo_amd import io as lio
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    for scale, dt in (("-1e-05", "<f4"), ("-3.9e-03", "<f4"), ("1.5E+2", ">f4"), ("-.5", "<f4")):
+        p = tmp_path / f"s{scale}.pfm"
+        with open(p, "wb") as f:
+            f.write(f"Pf\n4 3\n{scale}\n".encode("ascii"))
+            f.write(np.ascontiguousarray(a[::-1]).astype(dt).tobytes())
+        assert np.array_equal(lio.read_pfm(str(p)), a)
