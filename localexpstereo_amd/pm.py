@@ -284,6 +284,63 @@ class PMRunner:
                         cur_host.copy_(self.cur)
         self._sync()
 
+    @staticmethod
+    def gc_iteration_joint(runners, iteration, nthreads=0):
+        """Graph-cut iteration of SEVERAL views in lock-step (two-view runs, LES/FastGCStereo.h:172-185: the views are independent
+        until the post-processing).  Every lock-step evaluates the proposals of all views on the GPU, moves ONE payload to the host,
+        cuts the cells of all views in ONE OpenMP team (twice the cells per fork/join, and for the coarsest layer twice the
+        otherwise scarce parallelism) and applies the masks per view.  Same results as gc_iteration per view: the cuts of
+        different views touch disjoint state.  Single rank, device-built graphs."""
+        import time
+        from . import gc as lgc
+        r0 = runners[0]
+        assert all(r.world == 1 and r.device_graph for r in runners)
+        p = r0.gc.params
+        if getattr(r0, "_joint", None) is None:
+            pin = (lambda t: t.pin_memory()) if r0.device.type == "cuda" else (lambda t: t)
+            n = max([1] + [sum(r.shards[li][si].graph_nodes for r in runners) for li in range(len(r0.shards)) for si in range(len(r0.shards[li]))])
+            r0._joint = dict(payload=torch.empty(n * 5, dtype=torch.float32, device=r0.device), payload_host=pin(torch.empty(n * 5, dtype=torch.float32)),
+                             masks=torch.empty(n, dtype=torch.uint8, device=r0.device), masks_host=pin(torch.zeros(n, dtype=torch.uint8)))
+        J = r0._joint
+        for li in range(len(r0.shards)):
+            for si in range(len(r0.shards[li])):
+                shs = [r.shards[li][si] for r in runners]
+                if not any(sh.n for sh in shs):
+                    continue
+                base = np.cumsum([0] + [sh.graph_nodes for sh in shs])
+                regions = np.concatenate([sh.regions for sh in shs])
+                offsets = np.concatenate([sh.graph_off + int(base[v]) for v, sh in enumerate(shs)]).astype(np.int64)
+                total = int(base[-1])
+                for kind, K in r0.table[li]:
+                    for it in range(K):
+                        mm = iteration + it
+                        if kind == api.PROPOSE_RANDOM and (r0.maxd - r0.mind) * 0.5 ** (mm + 1) < 0.1:
+                            break
+                        t0 = time.perf_counter()
+                        for v, (r, sh) in enumerate(zip(runners, shs)):
+                            if not sh.n:
+                                continue
+                            sh.batch.propose(kind, r.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=mm)
+                            sh.batch.run(sh.planes.data_ptr(), r.prop.data_ptr(), mode=r.mode, check=True, planes_on_device=True)
+                            sh.batch.expansion_graph(sh.planes.data_ptr(), r.labels.data_ptr(), r.cur.data_ptr(), r.prop.data_ptr(),
+                                                     J["payload"].data_ptr() + 20 * int(base[v]), mode=r.mode, lambda_=p["lambda_"], th_smooth=p["th_smooth"],
+                                                     omega=p["omega"], epsilon=p["epsilon"])
+                        r0._sync()
+                        J["payload_host"][: total * 5].copy_(J["payload"][: total * 5])
+                        t1 = time.perf_counter()
+                        lgc.solve_prebuilt(regions, J["payload_host"].numpy()[: total * 5], offsets, J["masks_host"].numpy()[:total], nthreads=nthreads)
+                        t2 = time.perf_counter()
+                        J["masks"][:total].copy_(J["masks_host"][:total])
+                        for v, (r, sh) in enumerate(zip(runners, shs)):
+                            if sh.n:
+                                sh.batch.apply_masks(sh.planes.data_ptr(), J["masks"].data_ptr() + int(base[v]), r.cur.data_ptr(), r.prop.data_ptr(), r.labels.data_ptr())
+                        t3 = time.perf_counter()
+                        r0.gc_seconds["device"] += t1 - t0
+                        r0.gc_seconds["host_cuts"] += t2 - t1
+                        r0.gc_seconds[f"host_cuts_layer{li}"] += t2 - t1
+                        r0.gc_seconds["h2d"] += t3 - t2
+        r0._sync()
+
     def run(self, pm_iterations, iterations=0, graph_cut=None):
         """FastGCStereo::run for one view (LES/FastGCStereo.h:133-199): init, pmInit winner-take-all iterations, then
         `iterations` graph-cut iterations (their counter restarts at 0)."""

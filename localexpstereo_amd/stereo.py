@@ -24,10 +24,13 @@ class FastGCStereo:
         self.log = []
         self.check_flow_energy = False
         # two-view runs: graph-cut iterations of the two views in parallel host threads.  Pays when the host cuts dominate
-        # (1436 x 992: 14.2 -> 11.6 s); on small images the shared stream's synchronisations cost more (cones: 2.3 -> 3.1 s)
+        # (1436 x 992: 14.2 -> 11.3 s); on small images the shared stream's synchronisations cost more (cones: 2.3 -> 3.1 s)
         # (never with several ranks: the per-set all-gathers of the two views would be issued from two threads in an order
-        # that differs between ranks)
+        # that differs between ranks).  joint_views: the alternative -- both views advance in lock-step and ONE host team cuts
+        # the cells of both (pm.PMRunner.gc_iteration_joint); measured 12.4 s at 1436 x 992 because the right view's cuts are the
+        # slow ones (7-8 s of the 10 s of cuts) and then sit on the critical path of every lock-step, so it is not the default.
         self.concurrent_views = world == 1 and int(np.asarray(imL).shape[0]) * int(np.asarray(imL).shape[1]) >= 500_000
+        self.joint_views = False
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
 
     def addLayer(self, unit_region_size, proposers):
@@ -97,9 +100,11 @@ class FastGCStereo:
                     torch.cuda.set_device(dev.index if dev.index is not None else main_device)   # current device is per host thread
                 runners[m].gc_iteration(it, check=self.check_flow_energy, nthreads=self.host_threads)
             for it in range(maxIteration):
-                if len(viewModes) == 2 and self.concurrent_views:
-                    # the two views are independent until the post-processing (LES/FastGCStereo.h:172-185): their graph-cut
-                    # iterations run in two host threads (the C calls release the GIL) sharing the GPU stream
+                if len(viewModes) == 2 and self.joint_views and self.world == 1 and not self.check_flow_energy:
+                    # the two views are independent until the post-processing (LES/FastGCStereo.h:172-185)
+                    pm.PMRunner.gc_iteration_joint([runners[m] for m in viewModes], it, nthreads=self.host_threads)
+                elif len(viewModes) == 2 and self.concurrent_views:
+                    # their graph-cut iterations run in two host threads (the C calls release the GIL) sharing the GPU stream
                     import threading
                     errors = []
 

@@ -821,6 +821,28 @@ def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     return rows
 
 
+def case_joint_views(lib, device, units=(16,), pmInit=1, maxIteration=1):
+    """Two-view graph-cut iterations with both views in lock-step and one host team per lock-step (pm.PMRunner.gc_iteration_joint)
+    give exactly the labels of the view-after-view run: the cuts of different views touch disjoint state."""
+    from localexpstereo_amd import stereo
+    z = np.load(os.path.join(GOLDEN, "cones_crop.npz"))
+    imL, imRw = z["imL"], np.ascontiguousarray(z["imR_wide"])
+    imLw = np.concatenate([np.repeat(imL[:, :1], 64, axis=1), imL], axis=1)
+    ex, ra, rn = api.PROPOSE_EXPANSION, api.PROPOSE_RANSAC, api.PROPOSE_RANDOM
+    tabs = [[(ex, 1), (ra, 1), (rn, 3)], [(ex, 2), (ra, 1)]]
+    out = []
+    for joint in (False, True):
+        e = api.HipCostVolumeEnergy.naive(imLw, imRw, max_disp=63.0, lib=lib)
+        st = stereo.FastGCStereo(e, imLw, imRw, dict(lambda_=1.0), device=device, seed=3)
+        st.joint_views, st.concurrent_views = joint, False
+        for u, t in zip(units, tabs):
+            st.addLayer(u, t)
+        lab, raw = st.run(maxIteration, (0, 1), pmInit)
+        out.append((lab, raw))
+        e.close()
+    assert out[0][1].tobytes() == out[1][1].tobytes() and out[0][0].tobytes() == out[1][0].tobytes()
+
+
 def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
     """Pairwise terms on the device (N1): the graph capacities of a lock-step computed by les_hip_batch_expansion_graph
     must be bit-identical to the host construction (liblocalexp_host.so: les_gc_build_graphs), and the moves on the

@@ -20,10 +20,12 @@ def test_python_layer_geometry_matches_oracle(oracle_mod):
         assert len(sets) == len(L.sets) and all(np.array_equal(a, b) for a, b in zip(sets, L.sets))
 
 
-def _run(world, out, H=64, W=88, D=10, iters=1, gc_iters=0):
+def _run(world, out, H=64, W=88, D=10, iters=1, gc_iters=0, kernel=None):
     from localexpstereo_amd import build
     lib = build.build_sim()
     env = dict(os.environ, OMP_NUM_THREADS="2")
+    if kernel:
+        env["LES_HIP_KERNEL"] = kernel       # "strip": the fiber simulator runs the 256-thread strip kernel ~4x faster than the 768-thread march kernel
     worker = os.path.join(ROOT, "tests", "dist_worker.py")
     args = [out, lib, str(H), str(W), str(D), str(iters), str(gc_iters)]
     if world == 1:
@@ -50,8 +52,9 @@ def test_two_ranks_equal_one_rank_graph_cut(tmp_path, oracle_mod):
     all-gather keeps the replicas coherent -> same labels as one rank."""
     from localexpstereo_amd import build
     build.build_host_lib()
-    one = _run(1, str(tmp_path / "one.npz"), H=48, W=64, iters=1, gc_iters=1)
-    two = _run(2, str(tmp_path / "two.npz"), H=48, W=64, iters=1, gc_iters=1)
+    # (the sharding / exchange logic is what is under test here; the march kernel runs in the test above)
+    one = _run(1, str(tmp_path / "one.npz"), H=48, W=64, iters=1, gc_iters=1, kernel="strip")
+    two = _run(2, str(tmp_path / "two.npz"), H=48, W=64, iters=1, gc_iters=1, kernel="strip")
     assert one["labels"].tobytes() == two["labels"].tobytes()
     assert one["cur"].tobytes() == two["cur"].tobytes()
     assert one["host_labels"].tobytes() == one["labels"].tobytes()

@@ -352,6 +352,10 @@ def test_gpu_stereo_driver_two_views(oracle_mod):
     print("FastGCStereo mirror, cones crop, two views:", rows)
 
 
+def test_gpu_two_views_joint_lock_steps(oracle_mod):
+    pc.case_joint_views(None, "cuda", units=(8, 24))
+
+
 def test_gpu_config1_cones_end_to_end():
     """BASELINE configs[0]: MiddV2 cones 450x375, ndisp 64, NaiveStereoEnergy, pmIterations 2, then graph-cut iterations
     (2 here instead of the default 5 to bound the host time) -- the whole loop of LES/main.cpp:270-328 with the unary
