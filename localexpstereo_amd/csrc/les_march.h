@@ -215,7 +215,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const int modes = readfirstlane_i32(gpc.mode);
         // row scalars of block b (lane i < BY computes those of p-row b*BY + i; v_readlane hands them to the wave as scalars) and the
         // loads of its BY rows
-        auto issue = [&](int b) {
+        auto issue = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy = job.ty0 - 2 * R + t;
             const int sy = min(max(gy, job.cy0), cy1m);
@@ -312,7 +312,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         float4 st[BY][3];
         uint32_t keepbits = 0;                                            // bit i: stage-1 row i of the block in flight is inside the clip and primed
         float rny[BY];                                                    // 1 / count_y of its rows (wave-uniform: scalar registers)
-        auto issue = [&](int b) {
+        auto issue = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy1 = job.ty0 - 3 * R + t;                          // centre of the vertical window that ends at p-row t
             const float my_rny = (float)s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
@@ -389,7 +389,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         uint32_t gq[BY];
         float rny2[BY];                                                   // 1 / count_y of the block's output rows
         uint32_t okbits = 0;
-        auto issue = [&](int b) {
+        auto issue = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy2 = job.ty0 - 4 * R + t;
             const float my_rny = (float)s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
