@@ -381,6 +381,10 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // ================================================= role D =================================================
         LES_MARCH_SETPRIO(LES_MARCH_PRIO_D);
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
+        // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
+        // ds +- 5a +- 5b must all lie in [MIN, MAX]  <=>  min of the five >= MIN and max <= MAX (a NaN only arises next to an
+        // infinity, which fails the range test; an all-NaN set fails the comparison itself)
+        const float vl_xa = (float)gx * plane.x, vl_c = 1.0f * plane.z, vl_zv = 0.0f * plane.w, vl_a5 = plane.x * 5, vl_b5 = plane.y * 5;
         const double c_lane = view.qscale * s_rtab[nx];                    // 1 / (255 scale count_x)
         int ring2[4][KS];                // horizontal box sums of (a_0, a_1, a_2, b) of the last 2R+1 stage-1 rows
 #pragma unroll
@@ -440,8 +444,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                     const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
                                     // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
                                     float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
-                                    const int gy2 = job.ty0 + t - 4 * R;
-                                    if (check && !label_valid(g, plane.x, plane.y, plane.z, plane.w, gx, gy2)) q = LES_COST_INVALID;
+                                    if (check) {
+                                        const int gy2 = job.ty0 + t - 4 * R;
+                                        const float ds = ((vl_xa + (float)gy2 * plane.y) + vl_c) + vl_zv;
+                                        const float dp = ds + vl_a5, dm = ds - vl_a5;
+                                        const float d1 = dp + vl_b5, d2 = dp - vl_b5, d3 = dm + vl_b5, d4 = dm - vl_b5;
+                                        const float mn = fmin3(fmin3(ds, d1, d2), d3, d4), mx = fmax3(fmax3(ds, d1, d2), d3, d4);
+                                        if (!(mn >= g.mind && mx <= g.maxd)) q = LES_COST_INVALID;
+                                    }
                                     out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
                                 }
                             });

@@ -61,6 +61,9 @@ __device__ inline int dpp_row_shr(int v)
     return l >= N ? o[l - N] : 0;
 }
 __device__ inline void wave_sync() { hipsim::group_sync(6); }
+// v_min3_f32 / v_max3_f32: IEEE minNum / maxNum of three (a NaN operand is ignored unless all are NaN)
+__device__ inline float fmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ inline float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 // value of `v` in lane `l` of this wave (every lane of the wave must call it)
 __device__ inline int readlane_i32(int v, int l) { return hipsim::wave_readlane(v, l); }
 
@@ -143,6 +146,8 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }    // folds to v_min3_f32
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 #endif
 

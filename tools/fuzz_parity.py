@@ -22,9 +22,12 @@ RADII = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15]
 
 
 def one_case(rng, lib, stats):
-    R = int(rng.choice(RADII))
+    # half of the configurations are shaped for the fixed-point march kernel (radius 10, targets at least windR away from
+    # filterRect borders that are not image borders -- LayerManager-like cells -- or whole-image slabs), the others roam freely
+    march_shaped = rng.random() < 0.5
+    R = 10 if march_shaped else int(rng.choice(RADII))
     windR = 2 * R + int(rng.integers(0, 2))                       # windR / 2 == R
-    H, W = int(rng.integers(8, 150)), int(rng.integers(8, 200))
+    H, W = (int(rng.integers(30, 260)), int(rng.integers(30, 520))) if march_shaped else (int(rng.integers(8, 150)), int(rng.integers(8, 200)))
     D = int(rng.integers(2, 24))
     mind = float(rng.choice([0.0, 0.0, -3.0]))
     maxd = float(D - 1 + mind)
@@ -32,6 +35,9 @@ def one_case(rng, lib, stats):
     if rng.random() < 0.2:
         imL[:] = imL[0, 0]                                          # constant guide: Sigma = eps I
     volL, volR = synth.make_volume(D, H, W, int(rng.integers(1 << 30))), synth.make_volume(D, H, W, int(rng.integers(1 << 30)))
+    if rng.random() < 0.3:                                          # other cost ranges: negative costs, costs far above the threshold
+        sc, sh = float(rng.choice([1.0, 3.0, 0.2])), float(rng.choice([0.0, -0.4, 0.3]))
+        volL, volR = (volL * sc + sh).astype(np.float32), (volR * sc + sh).astype(np.float32)
     eps = float(rng.choice([1e-4, 1e-2, 1e-6]))
     th = float(rng.choice([0.5, 0.12, 2.0]))
     o = om.Oracle(imL, imR, volL, volR, windR=windR, eps=eps, th_col=th, max_disp=maxd, min_disp=mind)
@@ -41,10 +47,19 @@ def one_case(rng, lib, stats):
     occupied = np.zeros((H, W), bool)
     k = 0
     for _ in range(n * 4):
-        fw, fh = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
-        fx, fy = int(rng.integers(0, W - fw + 1)), int(rng.integers(0, H - fh + 1))
-        tw, th_ = int(rng.integers(1, fw + 1)), int(rng.integers(1, fh + 1))
-        tx, ty = fx + int(rng.integers(0, fw - tw + 1)), fy + int(rng.integers(0, fh - th_ + 1))
+        if march_shaped:
+            tw, th_ = int(rng.integers(1, min(W, 300) + 1)), int(rng.integers(1, min(H, 120) + 1))
+            tx, ty = int(rng.integers(0, W - tw + 1)), int(rng.integers(0, H - th_ + 1))
+            m = [windR + int(rng.integers(0, 6)) for _ in range(4)]                       # margins >= windR, clipped at the image like LayerManager.h:129-132
+            fx, fy = max(0, tx - m[0]), max(0, ty - m[1])
+            fw, fh = min(W, tx + tw + m[2]) - fx, min(H, ty + th_ + m[3]) - fy
+            if rng.random() < 0.15:
+                fx, fy, fw, fh, tx, ty, tw, th_ = 0, 0, W, H, 0, 0, W, H                # whole-image slab
+        else:
+            fw, fh = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+            fx, fy = int(rng.integers(0, W - fw + 1)), int(rng.integers(0, H - fh + 1))
+            tw, th_ = int(rng.integers(1, fw + 1)), int(rng.integers(1, fh + 1))
+            tx, ty = fx + int(rng.integers(0, fw - tw + 1)), fy + int(rng.integers(0, fh - th_ + 1))
         if occupied[ty:ty + th_, tx:tx + tw].any():
             continue                                                 # targets of one batch are disjoint (one disjoint set)
         occupied[ty:ty + th_, tx:tx + tw] = True
@@ -57,6 +72,9 @@ def one_case(rng, lib, stats):
     planes[:, 2] += mind
     if rng.random() < 0.15:
         planes[0, :3] = rng.choice([np.nan, np.inf, -np.inf, 1e30])
+    bq = api.Batch(e, frs, trs)
+    stats["march"] = stats.get("march", 0) + int(bq.kernel_kind(0) == 1)
+    bq.destroy()
     for mode in (0, 1):
         for check in (True, False):
             ref = o.unary_batch(frs, trs, planes, mode=mode, check=check)
@@ -160,7 +178,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
-          f"{stats.get('graphs', 0)} expansion-graph lock-steps, {stats.get('naive', 0)} image-based energies, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps, {stats.get('naive', 0)} image-based energies, {stats.get('march', 0)} configurations on the march kernel, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
