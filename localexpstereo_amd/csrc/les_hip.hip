@@ -296,7 +296,7 @@ bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, cons
                 }
                 if (njobs == 0) continue;
                 const long long wgs = (njobs + e->NJ - 1) / e->NJ;
-                const double ticks = (double)((rows + 4 * R + 6) / 7 + 2);
+                const double ticks = (double)((rows + 4 * R + 6) / 7 + 3);
                 // a partially filled last round costs as much as a full one; narrow jobs that leave most lanes idle cost the same tick
                 const double cost = (double)((wgs + ncu - 1) / ncu) * ticks * (1.0 + 1e-3 * (double)wgs / ncu) + (ro == (1 << 30) ? 0.0 : 1e-6);
                 if (cost < best) { best = cost; m = e; max_rows = ro; }

@@ -62,7 +62,7 @@ struct MarchCfg {
     static constexpr int SEGL = 8;                         // columns per prefix segment
     static constexpr int PCOLS = 1 + WGC + WGC / SEGL;     // physical columns: leading zero element (P(-1)) + one pad per segment
     static_assert(KS % BY == 0, "the block height must divide the ring length (compile-time ring slots)");
-    static_assert(KS / BY == 1 || KS / BY == 3, "unsupported ring / block ratio");
+    static_assert(KS / BY == 3, "three blocks per ring: the ring slots and the stage-2 buffer of a block are compile-time constants in a loop unrolled by 3");
     static_assert(WGC % 64 == 0, "a job slot is a whole number of waves");
     static_assert(BY * (64 / SEGL) <= 64, "one wave prefixes its own tile");
     static_assert(TW > 0, "job too narrow for this radius");
@@ -72,36 +72,36 @@ struct MarchCfg {
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-specialised pipeline.  A workgroup owns NJ jobs; each job slot has 3 x (WGC/64) waves:
-//   role A (wave = 64 columns of the job)   block k   : gather, fixed point, vertical sums -> T1[k&1], prefix of its own tile
-//   role C                                   block k-1 : box sums from T1, algebra -> T2[(k-1)&1], prefix of its own tile
-//   role D                                   block k-2 : box sums from T2, vertical sums, output
+//   role A (wave = 64 columns of the job)   block k   : gather, fixed point, vertical sums -> T1[k&1], prefix of its own tile;
+//                                            block k-2 : prefix of its tile of T2 (this role has the shortest row loop)
+//   role C                                   block k-1 : box sums from T1, algebra -> T2[(k-1)%3]
+//   role D                                   block k-3 : box sums from T2, vertical sums, output
 // and ONE workgroup barrier per block ("tick").  Every role issues the global loads of its next block before it waits at
 // the barrier, so memory latency is covered by the other two roles' work; role A / D keep their rings in registers, role C
 // has no state and can hold the 12 statistics words of all BY rows in flight.  The prefix sums are wave-local (each wave
 // prefixes the 64 columns it wrote, no cross-wave synchronisation): a window that crosses a wave boundary adds the total of
 // the left neighbour's tile (its last prefix element).
 // ---------------------------------------------------------------------------------------------------
-// prefix sums along x of the BY x 64 tile this wave wrote (rows i, physical columns of ci0 .. ci0+63), in place, modulo 2^32
+// prefix sums along x of the BY x 64 tile this wave wrote (rows i, physical columns of ci0 .. ci0+63), in place, modulo 2^32.
+// A lane owns one 8-column segment of one row.  The two rows that share a DPP row of 16 lanes are INTERLEAVED (lane = 16 (row / 2)
+// + 2 seg + (row & 1)), so the scan of the segment totals shifts by 2, 4, 8 lanes, never crosses from one image row into the other,
+// and the zero fill of row_shr is exactly the scan boundary: three v_add_u32_dpp per component, no masks.
 template <int BY, int PCOLS>
 __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int lane)
 {
     constexpr int SEGL = 8;
-    const int row = lane >> 3, seg = lane & 7;
+    const int row = 2 * (lane >> 4) + (lane & 1), seg = (lane & 15) >> 1;
     const bool act = row < BY;
-    int4* p = &T[act ? row : 0][1 + (ci0 / SEGL + seg) * (SEGL + 1)];
+    int4* p = &T[act ? row : 0][1 + (ci0 / SEGL + seg) * (SEGL + 1)];       // (the lanes of the unused 8th row read row 0 and write nothing)
     int4 v[SEGL];
 #pragma unroll
-    for (int j = 0; j < SEGL; j++) v[j] = act ? p[j] : int4{0, 0, 0, 0};
+    for (int j = 0; j < SEGL; j++) v[j] = p[j];
 #pragma unroll
     for (int j = 1; j < SEGL; j++) { v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w; }
-    // exclusive scan of the segment totals over the 8 lanes of the row (two rows share a DPP row of 16 lanes: masked steps)
+    // inclusive scan of the segment totals over the 8 lanes of the row
     int4 inc = v[SEGL - 1];
-#define LES_SCAN_STEP(N)                                                                                        \
-    {                                                                                                           \
-        const int tx = dpp_row_shr<N>(inc.x), ty = dpp_row_shr<N>(inc.y), tz = dpp_row_shr<N>(inc.z), tw = dpp_row_shr<N>(inc.w); \
-        if (seg >= N) { inc.x += tx; inc.y += ty; inc.z += tz; inc.w += tw; }                                   \
-    }
-    LES_SCAN_STEP(1) LES_SCAN_STEP(2) LES_SCAN_STEP(4)
+#define LES_SCAN_STEP(N) { inc.x += dpp_row_shr<N>(inc.x); inc.y += dpp_row_shr<N>(inc.y); inc.z += dpp_row_shr<N>(inc.z); inc.w += dpp_row_shr<N>(inc.w); }
+    LES_SCAN_STEP(2) LES_SCAN_STEP(4) LES_SCAN_STEP(8)
 #undef LES_SCAN_STEP
     const int4 off = int4{inc.x - v[SEGL - 1].x, inc.y - v[SEGL - 1].y, inc.z - v[SEGL - 1].z, inc.w - v[SEGL - 1].w};
     if (act) {
@@ -111,15 +111,49 @@ __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int
 }
 
 // -DLES_PHASE_TIMING: lane 0 of every wave accumulates the cycles it computes per tick and the cycles it waits at the tick
-// barrier: les_dbg[2 role] += compute, les_dbg[2 role + 1] += wait, les_dbg[6 + role] += ticks (tools/phase_probe.py)
+// barrier: les_dbg[2 role] += compute, les_dbg[2 role + 1] += wait, les_dbg[6 + role] += ticks, les_dbg[9 + role] += the part of
+// `compute` before LES_TICK_MARK (the row loop; the rest is the prefix pass of the tile)            (tools/phase_probe.py)
 #if defined(LES_PHASE_TIMING) && !defined(LES_SIM)
-#define LES_TICK_BEGIN() unsigned long long tk_c_ = 0, tk_w_ = 0, tk_n_ = 0, tk_t_ = clock64()
-#define LES_TICK_BARRIER() do { const unsigned long long a_ = clock64(); __syncthreads(); const unsigned long long b_ = clock64(); tk_c_ += a_ - tk_t_; tk_w_ += b_ - a_; tk_t_ = b_; tk_n_++; } while (0)
-#define LES_TICK_END(role_) do { if (lane == 0) { atomicAdd(&les_dbg[2 * (role_)], tk_c_); atomicAdd(&les_dbg[2 * (role_) + 1], tk_w_); atomicAdd(&les_dbg[6 + (role_)], tk_n_); } } while (0)
+#define LES_TICK_BEGIN() unsigned long long tk_c_ = 0, tk_w_ = 0, tk_n_ = 0, tk_r_ = 0, tk_m_ = 0, tk_t_ = clock64()
+#define LES_TICK_MARK() (tk_m_ = clock64())
+#define LES_TICK_BARRIER() do { const unsigned long long a_ = clock64(); __syncthreads(); const unsigned long long b_ = clock64(); tk_c_ += a_ - tk_t_; tk_r_ += (tk_m_ > tk_t_ ? tk_m_ : a_) - tk_t_; tk_w_ += b_ - a_; tk_t_ = b_; tk_n_++; } while (0)
+#define LES_TICK_END(role_) do { if (lane == 0) { atomicAdd(&les_dbg[2 * (role_)], tk_c_); atomicAdd(&les_dbg[2 * (role_) + 1], tk_w_); atomicAdd(&les_dbg[6 + (role_)], tk_n_); atomicAdd(&les_dbg[9 + (role_)], tk_r_); } } while (0)
 #else
 #define LES_TICK_BEGIN() ((void)0)
+#define LES_TICK_MARK() ((void)0)
 #define LES_TICK_BARRIER() __syncthreads()
 #define LES_TICK_END(role_) ((void)0)
+#endif
+
+// wave-uniform base + unsigned 32-bit per-lane byte offset: compiles to the `saddr` form of global_load / global_store, i.e. no
+// 64-bit address arithmetic on the VALU.  (The empty asm pins the offset as a 32-bit value in the block of the access; otherwise its
+// zero-extension is hoisted out of the loops and instruction selection falls back to a 64-bit VGPR address + v_lshl_add_u64.)
+#if defined(LES_SIM)
+#define LES_PIN_U32(x) ((void)0)
+#else
+#define LES_PIN_U32(x) asm volatile("" : "+v"(x))
+#endif
+template <class T>
+__device__ __forceinline__ T ld_sbase(const T* base, uint32_t byte_off) { LES_PIN_U32(byte_off); return *(const T*)((const char*)base + byte_off); }
+template <class T>
+__device__ __forceinline__ void st_sbase(T* base, uint32_t byte_off, T v) { LES_PIN_U32(byte_off); *(T*)((char*)base + byte_off) = v; }
+
+// The statistics rows of role C are loop-carried 16-byte register tuples that are reloaded in place, one row at a time, while
+// the rest of the block is still being consumed.  Written as plain C++ loads, the register allocator lands every reload in a
+// fresh tuple and copies it to the loop-carried one right away, i.e. waits for the load it has just issued.  The loads are
+// therefore issued as inline assembly with the destination TIED to the variable, and the vmcnt bookkeeping for them is done
+// by hand (this role issues no other vector-memory instruction): LES_STATS_WAIT(n, rows...) waits until at most n of this
+// wave's loads are outstanding and, by naming the rows as read-write operands, keeps their uses behind the wait.
+#if defined(LES_SIM)
+typedef float4 mstat4;
+#define LES_STATS_LOAD(dst, base, off, IMM) ((dst) = *(const float4*)((const char*)(base) + (off) + (IMM)))
+#define LES_STATS_WAIT3(n, r) ((void)0)
+#define LES_STATS_WAIT6(n, r, q) ((void)0)
+#else
+typedef float mstat4 __attribute__((ext_vector_type(4)));
+#define LES_STATS_LOAD(dst, base, off, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "+v"(dst) : "v"(off), "s"(base))
+#define LES_STATS_WAIT3(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]))
+#define LES_STATS_WAIT6(n, r, q) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]))
 #endif
 
 template <int R, int WGC, int NJ, int BY>
@@ -131,7 +165,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     constexpr int KS = Cfg::KS, NT = Cfg::NT, HWV = Cfg::HWV, NW = Cfg::NW, PCOLS = Cfg::PCOLS;
 
     __shared__ int4 s_T1[2][NJ][BY][PCOLS];  // stage 1: vertical sums, then (in place) their prefix sums along x; double buffered over blocks
-    __shared__ int4 s_T2[2][NJ][BY][PCOLS];  // stage 2: quantised (a_0, a_1, a_2, b), then their prefix sums
+    __shared__ int4 s_T2[3][NJ][BY][PCOLS];  // stage 2: quantised (a_0, a_1, a_2, b), then their prefix sums; three blocks in flight (written, prefixed, consumed)
     __shared__ double s_rtab[KS + 1];        // 1/n, n = 0..2R+1
 
     // XCD-aware group order (cf. les_strip_kernel): consecutive groups (same strip, consecutive planes) share an XCD's L2
@@ -145,23 +179,32 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = readfirstlane_i32(tid >> 6);
-    const int slot = wave / (3 * HWV), role = (wave % (3 * HWV)) / HWV, half = wave % HWV;
+#ifndef LES_MARCH_ROLE_ORDER
+#define LES_MARCH_ROLE_ORDER 5
+#endif
+    // Which role gets the oldest waves of a job slot.  The SIMD arbiter strictly prefers older waves (tools/ubench/mix_issue.hip),
+    // so the youngest role only fills the issue slots the other two leave.  Measured on the headline workload (ms per pass, roles
+    // listed oldest first): A D C 2.53 | D A C 2.58 | A C D 3.00 | C A D 3.20 | C D A 3.29 | D C A 3.40 -- the two roles that are
+    // chains of LDS round trips (A, D) want the priority, the role with the most arithmetic per row (C) fills the gaps.
+    constexpr int kRoleOf[6][3] = {{0, 1, 2}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {1, 0, 2}, {0, 2, 1}};
+    const int slot = wave / (3 * HWV), role = kRoleOf[LES_MARCH_ROLE_ORDER][(wave % (3 * HWV)) / HWV], half = wave % HWV;
     const int ci0 = half * 64, ci = ci0 + lane;
     const Job job = jobs[grp * NJ + slot];
     int th_max = 0;
 #pragma unroll
     for (int s = 0; s < NJ; s++) th_max = max(th_max, jobs[grp * NJ + s].th);
     const int nblk = (th_max + 4 * R + BY - 1) / BY;
-    const int nticks = nblk + 2;
+    const int nticks = nblk + 3;
     const int Ttot = job.th > 0 ? job.th + 4 * R : 0;     // an empty slot (padding of the last group) never passes a row test
     const float4 plane = planes[job.plane_idx];
     const int cy1m = max(job.cy1 - 1, job.cy0);
 
     if (tid <= KS) s_rtab[tid] = tid > 0 ? 1.0 / (double)tid : 0.0;
-    // zero the LDS tiles once: element 0 of every row is P(-1) = 0 and stays untouched; the pads are never read
-    for (int k = tid; k < 2 * NJ * BY * PCOLS; k += NT) {
-        (&s_T1[0][0][0][0])[k] = int4{0, 0, 0, 0};
-        (&s_T2[0][0][0][0])[k] = int4{0, 0, 0, 0};
+    // element 0 of every row is P(-1) = 0 and stays untouched; every other element is written before it is read (a block is
+    // written for all its columns before the next role reads it), the pads are never read
+    for (int k = tid; k < 3 * NJ * BY; k += NT) {
+        if (k < 2 * NJ * BY) (&s_T1[0][0][0][0])[k * PCOLS] = int4{0, 0, 0, 0};
+        (&s_T2[0][0][0][0])[k * PCOLS] = int4{0, 0, 0, 0};
     }
     __syncthreads();
 
@@ -169,6 +212,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int gx = job.tx0 - 2 * R + ci;                                  // image column of this lane (p, stage-1 and output column alike)
     const bool col_in = gx >= job.cx0 && gx < job.cx1 && job.th > 0;
     const int sx = min(max(gx, job.cx0), max(job.cx1 - 1, job.cx0));      // clamped: addresses stay inside the image
+    const uint32_t sx4 = (uint32_t)sx * 4u;                               // its byte offset in a row of floats / packed pixels
     const int nx = window_count(gx, R, job.cx0, job.cx1);                 // the same count serves stage 1 and stage 2 (same column)
     // physical columns of P(x+R), P(x-R-1) and, when the window crosses a wave boundary, of the left neighbour's tile total
     const int cP = min(ci + R, WGC - 1), cM = ci - R - 1;
@@ -204,55 +248,61 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         for (int k = 0; k < KS; k++) { ringP[k] = 0; ringG[k] = 0u; }
         int Sp = 0;
         long long Sc[3] = {1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
-        // Per-row load state of the block in flight.  General planes: taps / weight / mode per lane and row.  Fronto-parallel
-        // planes: everything but the clip test is per-job, the row bases are scalars and the loads need no address arithmetic.
+        const uint32_t i0s = (uint32_t)readfirstlane_i32((int)gpc.i0), i1s = (uint32_t)readfirstlane_i32((int)gpc.i1);
+        const float f1s = __int_as_float(readfirstlane_i32(__float_as_int(gpc.f1)));
+        const int modes = readfirstlane_i32(gpc.mode);
+        const float pbias = fmaf(-view.vmin, view.sp, 0.5f);             // pi = trunc(p * sp + (0.5 - vmin * sp))
+        const float f0s = 1.0f - f1s;
+        const bool inv_job = modes == 2;
+        // The march itself exists in three specialisations, selected once per job (a wave-uniform test per row costs the wave a
+        // taken branch and splits the row code into blocks the scheduler cannot interleave):
+        //   KIND 0  fronto-parallel plane, one volume tap  (integer disparity, clamped or invalid label)
+        //   KIND 1  fronto-parallel plane, two taps
+        //   KIND 2  general plane: taps / weight / mode per lane and row
+        // For fronto-parallel planes everything but the clip test is per-job, the row bases are scalars and the loads need no
+        // address arithmetic.
+        auto march_a = [&](auto kind_tag) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_tag)::value;
         GatherPrep gp[BY];
         float v0[BY], v1[BY];
         uint32_t gw[BY];
         uint32_t rowbits = 0;            // fronto path: bit i = p-row i of the block is inside the clip and the march
-        const uint32_t i0s = (uint32_t)readfirstlane_i32((int)gpc.i0), i1s = (uint32_t)readfirstlane_i32((int)gpc.i1);
-        const float f1s = __int_as_float(readfirstlane_i32(__float_as_int(gpc.f1)));
-        const int modes = readfirstlane_i32(gpc.mode);
-        // row scalars of block b (lane i < BY computes those of p-row b*BY + i; v_readlane hands them to the wave as scalars) and the
-        // loads of its BY rows
-        auto issue = [&](int b) __attribute__((always_inline)) {
+        // Row scalars of block b: lane i < BY computes those of p-row b*BY + i, v_readlane hands them to the wave as scalars.
+        // Loads are issued one row at a time, right after the same row of the previous block has been consumed ("rolling"
+        // prefetch: a whole tick of latency cover without a second set of registers).  Rows beyond the march are clamped to a
+        // valid address and flagged off, so the issue needs no branch.
+        int nx_rowpx = 0;
+        float nx_dbase = 0.0f;
+        auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy = job.ty0 - 2 * R + t;
             const int sy = min(max(gy, job.cy0), cy1m);
-            const int my_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
-            if (fronto) {
-                rowbits = 0;
-#pragma unroll
-                for (int i = 0; i < BY; i++) {
-                    const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
-                    rowbits |= (rowpx >> 31) << i;
-                    const uint32_t ro = rowpx & 0x7fffffffu;
-                    const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
-                    v0[i] = r0[sx];
-                    if (f1s != 0.0f) { const float* r1 = view.vol + (size_t)(i1s + ro); v1[i] = r1[sx]; }
-                    const uint32_t* rg = view.ipk8 + (size_t)ro;
-                    gw[i] = rg[sx];
-                }
-            } else {
-                const float my_dbase = plane.y * (float)sy + plane.z;   // b*y + c, LES/CostVolumeEnergy.h:73
-#pragma unroll
-                for (int i = 0; i < BY; i++) {
-                    const uint32_t rowpx = (uint32_t)readlane_i32(my_rowpx, i);
-                    const float d_base = readlane_f32(my_dbase, i);
-                    const bool inside = col_in && (rowpx >> 31);
-                    const uint32_t ro = rowpx & 0x7fffffffu;
-                    gp[i] = gather_prepare(g, g_ax, d_base, ro + (uint32_t)sx, HWu, inside);
-                    if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
-                    v0[i] = view.vol[gp[i].i0];
-                    v1[i] = view.vol[gp[i].i1];
-                    const uint32_t* rg = view.ipk8 + (size_t)ro;
-                    gw[i] = rg[sx];
-                }
-            }
+            nx_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
+            nx_dbase = plane.y * (float)sy + plane.z;                   // b*y + c, LES/CostVolumeEnergy.h:73
         };
-        issue(0);
+        auto issue_row = [&](auto itag) __attribute__((always_inline)) {
+            constexpr int i = decltype(itag)::value;
+            const uint32_t rowpx = (uint32_t)readlane_i32(nx_rowpx, i);
+            const uint32_t ro = rowpx & 0x7fffffffu;
+            if constexpr (KIND < 2) {
+                rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
+                const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
+                v0[i] = ld_sbase(r0, sx4);
+                if constexpr (KIND == 1) { const float* r1 = view.vol + (size_t)(i1s + ro); v1[i] = ld_sbase(r1, sx4); }
+            } else {
+                const float d_base = readlane_f32(nx_dbase, i);
+                const bool inside = col_in && (rowpx >> 31);
+                gp[i] = gather_prepare(g, g_ax, d_base, ro + (uint32_t)sx, HWu, inside);
+                if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
+                v0[i] = view.vol[gp[i].i0];
+                v1[i] = view.vol[gp[i].i1];
+            }
+            const uint32_t* rg = view.ipk8 + (size_t)ro;
+            gw[i] = ld_sbase(rg, sx4);
+        };
+        prep(0);
+        static_for<BY>([&](auto itag) { issue_row(itag); });
         LES_TICK_BEGIN();
-        const float pbias = fmaf(-view.vmin, view.sp, 0.5f);             // pi = trunc(p * sp + (0.5 - vmin * sp))
         // three ticks per loop iteration: the ring slot of a block's first row, (k * BY) mod KS, is then a compile-time constant
         // and the rings stay in fixed registers (a branch per block on the slot base made the allocator spill half of them)
         constexpr int UN = KS / BY;
@@ -263,16 +313,17 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 if (k < nticks) {
                     if (k < nblk) {
                         int4 (*T)[PCOLS] = s_T1[k & 1][slot];
+                        prep(k + 1);
                         static_for<BY>([&](auto itag) {
                             constexpr int i = decltype(itag)::value;
                             constexpr int SLOT = BASE + i;       // ring slot of p-row k*BY + i; it holds the row that leaves the window (2R+1 rows ago)
                             int pi;
-                            if (fronto) {
+                            if constexpr (KIND < 2) {
                                 // LES/CostVolumeEnergy.h:78-96 with per-job taps: clamped / interpolated / invalid, then min(C, th_col)
+                                // (one tap: the weight of the second is zero and the volume is finite, so f0 v0 + 0 v1 = v0)
                                 float C = v0[i];
-                                if (f1s != 0.0f) C = (1.0f - f1s) * v0[i] + f1s * v1[i];
-                                if (modes == 1) C = v0[i];
-                                if (modes == 2) C = LES_COST_INVALID;
+                                if constexpr (KIND == 1) C = f0s * v0[i] + f1s * v1[i];
+                                C = inv_job ? LES_COST_INVALID : C;
                                 const float p = (g.th_col < C) ? g.th_col : C;
                                 pi = (col_in && ((rowbits >> i) & 1u)) ? (int)fmaf(p, view.sp, pbias) : 0;
                             } else {
@@ -293,94 +344,129 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                 Sc[c] += (long long)qo * (long long)npo;
                             }
                             T[i][pcS] = int4{Sp, (int)(Sc[0] >> kMarchSH), (int)(Sc[1] >> kMarchSH), (int)(Sc[2] >> kMarchSH)};
+                            issue_row(itag);                     // the same row of block k + 1
                         });
+                        LES_TICK_MARK();
                         wave_sync();
                         march_prefix_tile<BY, PCOLS>(T, ci0, lane);
-                        if (k + 1 < nblk) issue(k + 1);
                     }
+                    // the prefix sums of stage 2 of block k - 2 (written by the role-C wave of the same tile at the previous tick):
+                    // this role has the shortest row loop, so it does the prefix work of both stages
+                    if (k >= 2 && k < nblk + 2) march_prefix_tile<BY, PCOLS>(s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot], ci0, lane);
                     LES_TICK_BARRIER();
                 }
             });
         }
         LES_TICK_END(0);
+        };
+        if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
+        else if (fronto) march_a(std::integral_constant<int, 1>{});
+        else march_a(std::integral_constant<int, 2>{});
     } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
         // ================================================= role C =================================================
         LES_MARCH_SETPRIO(LES_MARCH_PRIO_C);
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
-        const float rnx_f = (float)s_rtab[nx];
-        const int sx3 = sx * 3;
-        float4 st[BY][3];
-        uint32_t keepbits = 0;                                            // bit i: stage-1 row i of the block in flight is inside the clip and primed
-        float rny[BY];                                                    // 1 / count_y of its rows (wave-uniform: scalar registers)
-        auto issue = [&](int b) __attribute__((always_inline)) {
+        // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
+        // normalisation factors, the row part into the row's 1/count_y (0 * finite = 0, and v_cvt_rpi(+-0) = 0)
+        const float kap_x = s1_col ? view.kapS * (float)s_rtab[nx] : 0.0f;
+        const float up_x = s1_col ? view.upS * (float)s_rtab[nx] : 0.0f;
+        const uint32_t sx48 = (uint32_t)sx * 48u;
+        mstat4 st[BY][3];
+#pragma unroll
+        for (int i = 0; i < BY; i++) st[i][0] = st[i][1] = st[i][2] = mstat4{0.0f, 0.0f, 0.0f, 0.0f};
+        float rny[BY];                                                    // 1 / count_y of the rows of the block in flight, 0 for rows outside the clip or before the march is primed (wave-uniform: scalar registers)
+        int nx_srow = 0;
+        float nx_rny = 0.0f;
+        auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy1 = job.ty0 - 3 * R + t;                          // centre of the vertical window that ends at p-row t
-            const float my_rny = (float)s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
-            const int my_srow = (int)(((uint32_t)min(max(gy1, job.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot) ? 0x80000000u : 0u));
-            keepbits = 0;
-#pragma unroll
-            for (int i = 0; i < BY; i++) {
-                const uint32_t srow = (uint32_t)readlane_i32(my_srow, i);
-                rny[i] = readlane_f32(my_rny, i);
-                keepbits |= (srow >> 31) << i;
-                const float4* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * 3;      // scalar row base + the lane's column
-                st[i][0] = sp[sx3]; st[i][1] = sp[sx3 + 1]; st[i][2] = sp[sx3 + 2];
-            }
+            nx_rny = (float)s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+            nx_srow = (int)(((uint32_t)min(max(gy1, job.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot) ? 0x80000000u : 0u));
         };
-        issue(0);
+        auto issue_row = [&](auto itag) __attribute__((always_inline)) {      // rolling prefetch, see role A
+            constexpr int i = decltype(itag)::value;
+            const uint32_t srow = (uint32_t)readlane_i32(nx_srow, i);
+            const float r = readlane_f32(nx_rny, i);
+            rny[i] = (srow >> 31) ? r : 0.0f;
+            const float4* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * 3;          // scalar row base + the lane's column
+            mstat4 &d0 = st[i][0], &d1 = st[i][1], &d2 = st[i][2];                    // (named here: operands of an asm statement alone do not capture)
+            const uint32_t off = sx48;
+            LES_STATS_LOAD(d0, sp, off, 0); LES_STATS_LOAD(d1, sp, off, 16); LES_STATS_LOAD(d2, sp, off, 32);
+        };
+        prep(0);
+        static_for<BY>([&](auto itag) { issue_row(itag); });
         LES_TICK_BEGIN();
         for (int k = 0; k < nticks; k++) {
             if (k >= 1 && k <= nblk) {
                 const int b = k - 1;
                 const int4 (*T1)[PCOLS] = s_T1[b & 1][slot];
-                int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
-                constexpr int GC = 4;                           // rows whose prefix reads are in flight together
-                static_for<(BY + GC - 1) / GC>([&](auto gtag) {
-                    constexpr int LO = decltype(gtag)::value * GC;
-                    constexpr int N = (BY - LO) < GC ? (BY - LO) : GC;
-                    int4 pp[N], pm[N], px[N];
+                int4 (*T2)[PCOLS] = s_T2[b % 3][slot];
+                // Rows are processed in stages of GC; the LDS reads of stage s + 1 are issued before the arithmetic of stage s (two
+                // register buffers), so that only the first read of a tick waits for the LDS.  The fences keep the scheduler from
+                // hoisting all reads to the top (the register footprint would be set by that alone).
+                constexpr int GC = 2, NS = (BY + GC - 1) / GC;
+                prep(k);
+                int4 pp[2][GC], pm[2][GC], px[2][GC];
+                auto lds_stage = [&](auto stag) __attribute__((always_inline)) {
+                    constexpr int S = decltype(stag)::value;
 #pragma unroll
-                    for (int j = 0; j < N; j++) { pp[j] = T1[LO + j][pcP]; pm[j] = T1[LO + j][pcM]; px[j] = T1[LO + j][pcX]; }
+                    for (int j = 0; j < GC; j++)
+                        if (S * GC + j < BY) { pp[S & 1][j] = T1[S * GC + j][pcP]; pm[S & 1][j] = T1[S * GC + j][pcM]; px[S & 1][j] = T1[S * GC + j][pcX]; }
+                };
+                lds_stage(std::integral_constant<int, 0>{});
+                static_for<NS>([&](auto gtag) {
+                    constexpr int S = decltype(gtag)::value, CB = S & 1;
+                    constexpr int LO = S * GC;
+                    constexpr int N = (BY - LO) < GC ? (BY - LO) : GC;
+                    if constexpr (S + 1 < NS) lds_stage(std::integral_constant<int, S + 1>{});
+                    LES_MARCH_SCHED_FENCE();
+                    // loads are in flight in issue order: the BY rows of the previous tick (or of the initial issue), then the rows
+                    // of this tick's earlier stages.  Younger than the last row of this stage: 3 loads for each of the other BY - N rows.
+                    static_assert(GC == 2 && BY == 7, "vmcnt bookkeeping below is written for stages of two rows and a block of seven");
+                    {
+                        mstat4 (&ra)[3] = st[LO];
+                        mstat4 (&rb)[3] = st[LO + N - 1];
+                        if constexpr (N == 2) LES_STATS_WAIT6(15, ra, rb);
+                        else LES_STATS_WAIT3(18, ra);
+                    }
                     static_for<N>([&](auto jtag) {
                         constexpr int j = decltype(jtag)::value;
                         constexpr int i = LO + j;
-                        const int s = pp[j].x - pm[j].x + px[j].x;                         // sum of pi over the window (exact)
-                        const int t0c = pp[j].y - pm[j].y + px[j].y, t1c = pp[j].z - pm[j].z + px[j].z, t2c = pp[j].w - pm[j].w + px[j].w;
-                        const float4 q0 = st[i][0], q1 = st[i][1], q2 = st[i][2];
+                        const int s = pp[CB][j].x - pm[CB][j].x + px[CB][j].x;                         // sum of pi over the window (exact)
+                        const int t0c = pp[CB][j].y - pm[CB][j].y + px[CB][j].y, t1c = pp[CB][j].z - pm[CB][j].z + px[CB][j].z, t2c = pp[CB][j].w - pm[CB][j].w + px[CB][j].w;
+                        const mstat4 q0 = st[i][0], q1 = st[i][1], q2 = st[i][2];
                         const int M0 = __float_as_int(q2.y), M1 = __float_as_int(q2.z), M2 = __float_as_int(q2.w);
                         // N cov_c in units of 2^SH (u8 * pi): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
                         const float d0 = (float)(t0c - (int)(((long long)M0 * (long long)s + (1ll << 31)) >> 32));
                         const float d1 = (float)(t1c - (int)(((long long)M1 * (long long)s + (1ll << 31)) >> 32));
                         const float d2 = (float)(t2c - (int)(((long long)M2 * (long long)s + (1ll << 31)) >> 32));
                         // LES/GuidedFilter.h:204-221 with the scale of the integer stage 2 folded into the normalisation
-                        const float rn = rnx_f * rny[i];
-                        const float ka = view.kapS * rn;
+                        const float ka = kap_x * rny[i];
                         const float a0 = fmaf(q0.z, d2, fmaf(q0.y, d1, q0.x * d0)) * ka;     // inv00 inv01 inv02
                         const float a1 = fmaf(q1.x, d2, fmaf(q0.w, d1, q0.y * d0)) * ka;     // inv01 inv11 inv12
                         const float a2 = fmaf(q1.y, d2, fmaf(q1.x, d1, q0.z * d0)) * ka;     // inv02 inv12 inv22
-                        const float mp = (float)s * (view.upS * rn);
+                        const float mp = (float)s * (up_x * rny[i]);
                         const float bb = fmaf(-a2, q2.x, fmaf(-a1, q1.w, fmaf(-a0, q1.z, mp)));
-                        const int km = (s1_col && ((keepbits >> i) & 1u)) ? -1 : 0;      // a, b are zero outside the clip and before the march is primed
                         int4 o;
-                        o.x = cvt_rpi_i32(a0) & km;
-                        o.y = cvt_rpi_i32(a1) & km;
-                        o.z = cvt_rpi_i32(a2) & km;
-                        o.w = cvt_rpi_i32(bb) & km;
+                        o.x = cvt_rpi_i32(a0);
+                        o.y = cvt_rpi_i32(a1);
+                        o.z = cvt_rpi_i32(a2);
+                        o.w = cvt_rpi_i32(bb);
                         T2[i][pcS] = o;
                     });
                     LES_MARCH_SCHED_FENCE();
+                    static_for<N>([&](auto jtag) { issue_row(std::integral_constant<int, LO + decltype(jtag)::value>{}); });   // the same rows of block k
                 });
-                wave_sync();
-                march_prefix_tile<BY, PCOLS>(T2, ci0, lane);
-                if (k < nblk) issue(k);
+                LES_TICK_MARK();
             }
             LES_TICK_BARRIER();
         }
         LES_TICK_END(1);
-    } else if (LES_MARCH_ROLE_MASK & 4) {
+    } else if (role == 2 && (LES_MARCH_ROLE_MASK & 4)) {
         // ================================================= role D =================================================
         LES_MARCH_SETPRIO(LES_MARCH_PRIO_D);
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
+        const uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;           // byte offset of the lane's output column in a row of the output tile
         // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
         // ds +- 5a +- 5b must all lie in [MIN, MAX]  <=>  min of the five >= MIN and max <= MAX (a NaN only arises next to an
         // infinity, which fails the range test; an all-NaN set fails the comparison itself)
@@ -393,45 +479,57 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         uint32_t gq[BY];
         float rny2[BY];                                                   // 1 / count_y of the block's output rows
         uint32_t okbits = 0;
-        auto issue = [&](int b) __attribute__((always_inline)) {
+        int nx_grow = 0;
+        float nx_rny = 0.0f;
+        auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy2 = job.ty0 - 4 * R + t;
-            const float my_rny = (float)s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
-            const int my_grow = (int)(((uint32_t)min(max(gy2, job.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < Ttot) ? 0x80000000u : 0u));
-            okbits = 0;
-#pragma unroll
-            for (int i = 0; i < BY; i++) {
-                const uint32_t grow = (uint32_t)readlane_i32(my_grow, i);
-                rny2[i] = readlane_f32(my_rny, i);
-                okbits |= (grow >> 31) << i;
-                const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
-                gq[i] = rg[sx];
-            }
+            nx_rny = (float)s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
+            nx_grow = (int)(((uint32_t)min(max(gy2, job.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < Ttot) ? 0x80000000u : 0u));
         };
+        auto issue_row = [&](auto itag) __attribute__((always_inline)) {
+            constexpr int i = decltype(itag)::value;
+            const uint32_t grow = (uint32_t)readlane_i32(nx_grow, i);
+            rny2[i] = readlane_f32(nx_rny, i);
+            okbits = (okbits & ~(1u << i)) | ((grow >> 31) << i);
+            const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
+            gq[i] = ld_sbase(rg, sx4);
+        };
+        // two specialisations (label check on / off), selected once per job -- see role A
+        auto march_d = [&](auto check_tag) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(check_tag)::value != 0;
         LES_TICK_BEGIN();
         constexpr int UN = KS / BY;
         for (int k0 = 0; k0 < nticks; k0 += UN) {
             static_for<UN>([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
-                constexpr int BASE = ((U + UN - 2 % UN) % UN) * BY;     // block k - 2: its ring slot base is a compile-time constant (see role A)
+                constexpr int BASE = ((U + UN - 3 % UN) % UN) * BY;     // block k - 3: its ring slot base is a compile-time constant (see role A)
                 const int k = k0 + U;
                 if (k < nticks) {
-                    if (k >= 2) {
-                        const int b = k - 2;
-                        const int4 (*T2)[PCOLS] = s_T2[b & 1][slot];
-                        constexpr int GD = 2;                       // rows whose prefix reads are in flight together (role D lives at the 168-register limit)
-                        static_for<(BY + GD - 1) / GD>([&](auto gtag) {
-                            constexpr int LO = decltype(gtag)::value * GD;
-                            constexpr int N = (BY - LO) < GD ? (BY - LO) : GD;
-                            int4 pp[N], pm[N], px[N];
+                    if (k >= 3) {
+                        const int b = k - 3;
+                        const int4 (*T2)[PCOLS] = s_T2[(U + UN - 3 % UN) % UN][slot];
+                        constexpr int GD = 1, NS = (BY + GD - 1) / GD;   // as in role C: the reads of the next row are in flight during the arithmetic of this one
+                        int4 pp[2][GD], pm[2][GD], px[2][GD];
+                        auto lds_stage = [&](auto stag) __attribute__((always_inline)) {
+                            constexpr int S = decltype(stag)::value;
 #pragma unroll
-                            for (int j = 0; j < N; j++) { pp[j] = T2[LO + j][pcP]; pm[j] = T2[LO + j][pcM]; px[j] = T2[LO + j][pcX]; }
+                            for (int j = 0; j < GD; j++)
+                                if (S * GD + j < BY) { pp[S & 1][j] = T2[S * GD + j][pcP]; pm[S & 1][j] = T2[S * GD + j][pcM]; px[S & 1][j] = T2[S * GD + j][pcX]; }
+                        };
+                        lds_stage(std::integral_constant<int, 0>{});
+                        static_for<NS>([&](auto gtag) {
+                            constexpr int S = decltype(gtag)::value, CB = S & 1;
+                            constexpr int LO = S * GD;
+                            constexpr int N = (BY - LO) < GD ? (BY - LO) : GD;
+                            if constexpr (S + 1 < NS) lds_stage(std::integral_constant<int, S + 1>{});
+                            LES_MARCH_SCHED_FENCE();
                             static_for<N>([&](auto jtag) {
                                 constexpr int j = decltype(jtag)::value;
                                 constexpr int i = LO + j;
                                 constexpr int SLOT = BASE + i;
-                                const int h0 = pp[j].x - pm[j].x + px[j].x, h1 = pp[j].y - pm[j].y + px[j].y;
-                                const int h2 = pp[j].z - pm[j].z + px[j].z, h3 = pp[j].w - pm[j].w + px[j].w;
+                                const int h0 = pp[CB][j].x - pm[CB][j].x + px[CB][j].x, h1 = pp[CB][j].y - pm[CB][j].y + px[CB][j].y;
+                                const int h2 = pp[CB][j].z - pm[CB][j].z + px[CB][j].z, h3 = pp[CB][j].w - pm[CB][j].w + px[CB][j].w;
                                 S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
                                 S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
                                 S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
@@ -444,7 +542,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                     const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
                                     // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
                                     float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
-                                    if (check) {
+                                    if constexpr (CHECK) {
                                         const int gy2 = job.ty0 + t - 4 * R;
                                         const float ds = ((vl_xa + (float)gy2 * plane.y) + vl_c) + vl_zv;
                                         const float dp = ds + vl_a5, dm = ds - vl_a5;
@@ -452,18 +550,24 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                         const float mn = fmin3(fmin3(ds, d1, d2), d3, d4), mx = fmax3(fmax3(ds, d1, d2), d3, d4);
                                         if (!(mn >= g.mind && mx <= g.maxd)) q = LES_COST_INVALID;
                                     }
-                                    out[job.out_off + (long long)(t - 4 * R) * job.out_stride + (ci - 2 * R)] = q;
+                                    st_sbase(out + (job.out_off + (long long)(t - 4 * R) * job.out_stride), oc4, q);
                                 }
                             });
                             LES_MARCH_SCHED_FENCE();
                         });
                     }
-                    if (k >= 1 && k <= nblk) issue(k - 1);        // guide rows of the block this role handles at the next tick
+                    if (k >= 2 && k <= nblk + 1) {                // guide rows of the block this role handles at the next tick (7 dwords per
+                        prep(k - 2);                              // lane; this role is never the last to arrive at the barrier, and it has no
+                        static_for<BY>([&](auto itag) { issue_row(itag); });   // registers to spare for a rolling issue)
+                    }
                     LES_TICK_BARRIER();
                 }
             });
         }
         LES_TICK_END(2);
+        };
+        if (check) march_d(std::integral_constant<int, 1>{});
+        else march_d(std::integral_constant<int, 0>{});
     }
 }
 

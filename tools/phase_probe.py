@@ -9,7 +9,7 @@ if "--build" in sys.argv:
     subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-DLES_PHASE_TIMING", os.path.join(build.CSRC, "les_hip.hip"), "-o", LIB], cwd=build.CSRC)
     print("built", LIB)
     sys.exit(0)
-os.environ["LES_HIP_LIB"] = LIB
+os.environ["LES_HIP_LIB"] = os.environ.get("PHASE_LIB", LIB)
 import torch, numpy as np
 from localexpstereo_amd import api, synth
 H, W, D = 1000, 1500, 256
@@ -34,7 +34,7 @@ for it in range(2):
         v = [buf[i] for i in range(12)]
         for r, name in enumerate("ACD"):
             n = max(1, v[6 + r])
-            print(f"march role {name}: wave-ticks {v[6 + r]}, cycles per tick: compute {v[2 * r] / n:.0f}, barrier wait {v[2 * r + 1] / n:.0f}")
+            print(f"march role {name}: wave-ticks {v[6 + r]}, cycles per tick: compute {v[2 * r] / n:.0f} (row loop {v[9 + r] / n:.0f}), barrier wait {v[2 * r + 1] / n:.0f}")
         continue
     v = [buf[i] for i in range(6)]
     tot = sum(v[:5])
