@@ -593,3 +593,27 @@ def test_max_size_volume_32bit_offsets(oracle_mod):
     e.close()
     del vol
     torch.cuda.empty_cache()
+
+
+def test_multi_gpu_rank_shape_whole_image_planes_vs_oracle(oracle_mod):
+    """The per-rank workload of `bench.py --gpus N` (BASELINE configs[4]: 3000 x 2000 image, slices sharded over ranks): whole-image
+    fronto-parallel and slanted planes through the march kernel (14 strips of 216 columns) against the oracle, full resolution."""
+    import torch
+    from localexpstereo_amd import api, synth
+    H, W, D = 2000, 3000, 6
+    guide = synth.make_guide(H, W, 1234)
+    vol = synth.make_volume(D, H, W, 42)
+    e = api.HipCostVolumeEnergy(guide, None, vol, None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1)
+    o = pc.om.Oracle(guide, guide, vol, vol, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1)
+    planes = np.array([[0, 0, 2.0, 0], [0.0007, -0.0005, 2.3, 0]], np.float32)
+    full = [(0, 0, W, H)] * 2
+    b = api.Batch(e, full, full, out_slabs=True)
+    assert b.kernel_kind(0) == 1
+    out = torch.empty((2, H, W), device="cuda", dtype=torch.float32)
+    b.run(torch.from_numpy(planes).cuda().data_ptr(), out.data_ptr(), mode=0, check=True, planes_on_device=True)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for k in range(2):
+        ref = o.unary_batch([(0, 0, W, H)], [(0, 0, W, H)], planes[k][None], check=True)
+        pc.compare_maps(got[k], ref)
+    e.close()
