@@ -68,11 +68,19 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LES_BENCH_BACKEND=gloo LES_BENCH_ONE_DEVICE=1: functional test of the N > 1 code path on a box with one GPU (all ranks on
+    # cuda:0, rendezvous and reductions over gloo); never the measured configuration
+    backend = os.environ.get("LES_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("LES_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     multi = world > 1
     H = args.height or (2000 if multi else 1000)
@@ -85,7 +93,7 @@ def main():
     gen.manual_seed(42 + rank)
     vol = torch.rand((D, H, W), device=dev, dtype=torch.float32, generator=gen)
     e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1,
-                                device=local_rank, volumes_on_device=True, shape=(D, H, W))
+                                device=dev_index, volumes_on_device=True, shape=(D, H, W))
     stream = torch.cuda.current_stream(dev)
     e.set_stream(stream.cuda_stream)
     out = torch.empty((D, H, W), device=dev, dtype=torch.float32)
@@ -153,8 +161,8 @@ def main():
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         barrier()
-        elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-        kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in evs) / max(1, steps)], device=dev, dtype=torch.float64)
+        elapsed = torch.tensor([t1 - t0], device=red_dev, dtype=torch.float64)
+        kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in evs) / max(1, steps)], device=red_dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
             dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
