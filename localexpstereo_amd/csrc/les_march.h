@@ -60,14 +60,23 @@ struct MarchCfg {
     static constexpr int NW = 3 * HWV * NJ;                // waves per workgroup: roles A, C, D
     static constexpr int NT = 64 * NW;
     static constexpr int SEGL = 8;                         // columns per prefix segment
-    static constexpr int PCOLS = 1 + WGC + WGC / SEGL;     // physical columns: leading zero element (P(-1)) + one pad per segment
+#ifndef LES_MARCH_PADW
+#define LES_MARCH_PADW 16
+#endif
+    // Physical columns: a leading zero element (P(-1)) + one pad element per PADW columns; with PADW = 16 the row length is rounded
+    // up to 4 mod 8 elements.  The prefix pass reads, per 16 lanes, the 8 segments (stride 8 columns = 32 banks, shifted by one
+    // element = 4 banks per pad) of two rows (shifted by +-16 banks when the row length is 4 mod 8): all 64 banks once.  The
+    // consumers' 16 consecutive columns then straddle one pad (one bank collision per 16 lanes) instead of two.
+    static constexpr int PADW = LES_MARCH_PADW;
+    static constexpr int PCOLS0 = 1 + WGC + WGC / PADW;
+    static constexpr int PCOLS = PADW == 16 ? PCOLS0 + ((4 - PCOLS0 % 8) + 8) % 8 : PCOLS0;      // 4 or 12 mod 16: the second row lands 16 banks off either way
     static_assert(KS % BY == 0, "the block height must divide the ring length (compile-time ring slots)");
     static_assert(KS / BY == 3, "three blocks per ring: the ring slots and the stage-2 buffer of a block are compile-time constants in a loop unrolled by 3");
     static_assert(WGC % 64 == 0, "a job slot is a whole number of waves");
     static_assert(BY * (64 / SEGL) <= 64, "one wave prefixes its own tile");
     static_assert(TW > 0, "job too narrow for this radius");
     static_assert(2 * R + 1 < 64, "a window crosses at most one wave boundary");
-    __host__ __device__ static constexpr int pcol(int ci) { return 1 + ci + ci / SEGL; }
+    __host__ __device__ static constexpr int pcol(int ci) { return 1 + ci + ci / PADW; }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -92,7 +101,8 @@ __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int
     constexpr int SEGL = 8;
     const int row = 2 * (lane >> 4) + (lane & 1), seg = (lane & 15) >> 1;
     const bool act = row < BY;
-    int4* p = &T[act ? row : 0][1 + (ci0 / SEGL + seg) * (SEGL + 1)];       // (the lanes of the unused 8th row read row 0 and write nothing)
+    const int c0 = ci0 + seg * SEGL;                                           // first column of the segment; a segment never contains a pad
+    int4* p = &T[act ? row : 0][1 + c0 + c0 / LES_MARCH_PADW];                // (the lanes of the unused 8th row read row 0 and write nothing)
     int4 v[SEGL];
 #pragma unroll
     for (int j = 0; j < SEGL; j++) v[j] = p[j];
