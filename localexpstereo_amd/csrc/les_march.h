@@ -95,6 +95,20 @@ struct MarchCfg {
 // A lane owns one 8-column segment of one row.  The two rows that share a DPP row of 16 lanes are INTERLEAVED (lane = 16 (row / 2)
 // + 2 seg + (row & 1)), so the scan of the segment totals shifts by 2, 4, 8 lanes, never crosses from one image row into the other,
 // and the zero fill of row_shr is exactly the scan boundary: three v_add_u32_dpp per component, no masks.
+// (scan of the 8 elements a lane holds: local inclusive prefix, exclusive scan of the segment totals over the row's 8 lanes, offset)
+__device__ __forceinline__ void march_prefix_scan8(int4 (&v)[8])
+{
+#pragma unroll
+    for (int j = 1; j < 8; j++) { v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w; }
+    int4 inc = v[7];
+#define LES_SCAN_STEP(N) { inc.x += dpp_row_shr<N>(inc.x); inc.y += dpp_row_shr<N>(inc.y); inc.z += dpp_row_shr<N>(inc.z); inc.w += dpp_row_shr<N>(inc.w); }
+    LES_SCAN_STEP(2) LES_SCAN_STEP(4) LES_SCAN_STEP(8)
+#undef LES_SCAN_STEP
+    const int4 off = int4{inc.x - v[7].x, inc.y - v[7].y, inc.z - v[7].z, inc.w - v[7].w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) { v[j].x += off.x; v[j].y += off.y; v[j].z += off.z; v[j].w += off.w; }
+}
+
 template <int BY, int PCOLS>
 __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int lane)
 {
@@ -106,17 +120,43 @@ __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int
     int4 v[SEGL];
 #pragma unroll
     for (int j = 0; j < SEGL; j++) v[j] = p[j];
-#pragma unroll
-    for (int j = 1; j < SEGL; j++) { v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w; }
-    // inclusive scan of the segment totals over the 8 lanes of the row
-    int4 inc = v[SEGL - 1];
-#define LES_SCAN_STEP(N) { inc.x += dpp_row_shr<N>(inc.x); inc.y += dpp_row_shr<N>(inc.y); inc.z += dpp_row_shr<N>(inc.z); inc.w += dpp_row_shr<N>(inc.w); }
-    LES_SCAN_STEP(2) LES_SCAN_STEP(4) LES_SCAN_STEP(8)
-#undef LES_SCAN_STEP
-    const int4 off = int4{inc.x - v[SEGL - 1].x, inc.y - v[SEGL - 1].y, inc.z - v[SEGL - 1].z, inc.w - v[SEGL - 1].w};
+    march_prefix_scan8(v);
     if (act) {
 #pragma unroll
-        for (int j = 0; j < SEGL; j++) { v[j].x += off.x; v[j].y += off.y; v[j].z += off.z; v[j].w += off.w; p[j] = v[j]; }
+        for (int j = 0; j < SEGL; j++) p[j] = v[j];
+    }
+}
+
+// The same for two tiles at once: TB holds data older than a workgroup barrier, TA was written by this wave just now.  The reads
+// of TB are issued before the wave waits for its own stores, the reads of TA are in flight during the arithmetic of TB: one
+// exposed LDS round trip instead of two (costs 32 more registers).
+template <int BY, int PCOLS>
+__device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[PCOLS], int ci0, int lane)
+{
+    constexpr int SEGL = 8;
+    const int row = 2 * (lane >> 4) + (lane & 1), seg = (lane & 15) >> 1;
+    const bool act = row < BY;
+    const int c0 = ci0 + seg * SEGL;
+    const int pc = 1 + c0 + c0 / LES_MARCH_PADW;
+    int4* pa = &TA[act ? row : 0][pc];
+    int4* pb = &TB[act ? row : 0][pc];
+    int4 va[SEGL], vb[SEGL];
+#pragma unroll
+    for (int j = 0; j < SEGL; j++) vb[j] = pb[j];
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < SEGL; j++) va[j] = pa[j];
+    LES_MARCH_SCHED_FENCE();
+    march_prefix_scan8(vb);
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < SEGL; j++) pb[j] = vb[j];
+    }
+    LES_MARCH_SCHED_FENCE();
+    march_prefix_scan8(va);
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < SEGL; j++) pa[j] = va[j];
     }
 }
 
@@ -357,12 +397,21 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             issue_row(itag);                     // the same row of block k + 1
                         });
                         LES_TICK_MARK();
-                        wave_sync();
-                        march_prefix_tile<BY, PCOLS>(T, ci0, lane);
                     }
-                    // the prefix sums of stage 2 of block k - 2 (written by the role-C wave of the same tile at the previous tick):
-                    // this role has the shortest row loop, so it does the prefix work of both stages
-                    if (k >= 2 && k < nblk + 2) march_prefix_tile<BY, PCOLS>(s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot], ci0, lane);
+                    // The prefix sums of this block of stage 1 and of block k - 2 of stage 2 (written by the role-C wave of the same
+                    // tile at the previous tick): this role has the shortest row loop, so it does the prefix work of both stages.
+                    {
+                        int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
+                        const bool da = k < nblk, db = k >= 2 && k < nblk + 2;
+#ifndef LES_MARCH_PREFIX_PAIR
+#define LES_MARCH_PREFIX_PAIR 1
+#endif
+                        if (LES_MARCH_PREFIX_PAIR && KIND < 2 && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
+                        else {
+                            if (da) { wave_sync(); march_prefix_tile<BY, PCOLS>(s_T1[k & 1][slot], ci0, lane); }
+                            if (db) march_prefix_tile<BY, PCOLS>(TB, ci0, lane);
+                        }
+                    }
                     LES_TICK_BARRIER();
                 }
             });
