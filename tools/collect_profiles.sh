@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-round2}
 O=gpurun_out/prof; mkdir -p $O
 B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0"
-rocprofv3 --kernel-trace --stats -d $O/stats -- $B > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --steps 100 --warmup 5 --cpu-planes 0 --sub-steps 0 > $O/stats.log 2>&1     # enough launches that the cold first ones do not weigh on the average
 python tools/prof_summary.py $O/stats --md > $O/${TAG}_kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_$c -- $B > $O/pmc_$c.log 2>&1
