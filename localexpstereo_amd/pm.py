@@ -229,6 +229,7 @@ class PMRunner:
             sh.masks, sh.masks_host = self._gc_masks[:n], self._gc_masks_host[:n]
 
     def gc_iteration(self, iteration, check=False, nthreads=0):
+        import os
         import time
         from . import gc as lgc
         gc, m = self.gc, self.mode
@@ -269,6 +270,15 @@ class PMRunner:
                                 t1 = time.perf_counter()
                                 lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
                                 t2 = time.perf_counter()
+                                dump = os.environ.get("LES_DUMP_GRAPHS")           # tooling: timing log of the lock-steps + the graphs of the slowest one of the coarsest layer
+                                if dump:
+                                    with open(os.path.join(dump, f"cutlog_view{m}.txt"), "a") as f:
+                                        f.write(f"{iteration} {li} {kind} {it} {sh.n} {t2 - t1:.6f}\n")
+                                if dump and li == len(self.shards) - 1 and iteration >= 1 and t2 - t1 > getattr(self, "_dump_worst", 0.012):
+                                    self._dump_worst = t2 - t1
+                                    nn = int(sh.graph_off[-1] + int(sh.regions[-1]["w"]) * int(sh.regions[-1]["h"]))
+                                    np.savez_compressed(os.path.join(dump, f"graphs_view{m}_layer{li}.npz"), regions=sh.regions, offsets=sh.graph_off,
+                                                        payload=sh.payload_host.numpy()[: nn * 5].copy(), seconds=t2 - t1)
                                 sh.masks.copy_(sh.masks_host)
                                 sh.batch.apply_masks(sh.planes.data_ptr(), sh.masks.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
                             t3 = time.perf_counter()
