@@ -11,6 +11,7 @@
 
 #include <thread>
 
+#include "BandPool.h"
 #include "GridMaxFlow.h"
 #include "StereoEnergy.h"
 
@@ -97,10 +98,7 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     // large regions: the node load and the segment read-out are split over the same number of threads as the first max-flow phase
     auto rows_parallel = [&](auto&& body) {
         if (bands <= 1) { body(0, h); return; }
-        std::vector<std::thread> th;
-        for (int b = 1; b < bands; b++) th.emplace_back([&, b] { body((int)((long long)h * b / bands), (int)((long long)h * (b + 1) / bands)); });
-        body(0, (int)((long long)h / bands));
-        for (auto& t : th) t.join();
+        BandPool::mine().run(bands, [&](int b) { body((int)((long long)h * b / bands), (int)((long long)h * (b + 1) / bands)); });
     };
     rows_parallel([&](int y0, int y1) {
         for (int y = y0; y < y1; y++)

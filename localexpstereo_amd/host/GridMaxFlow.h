@@ -13,9 +13,10 @@
 
 #include <algorithm>
 #include <cstdint>
-#include <thread>
 #include <limits>
 #include <vector>
+
+#include "BandPool.h"
 
 namespace les_host {
 
@@ -110,15 +111,11 @@ public:
                 for (int x = 0; x < w_; x++) nodes_[id(x, y)].band = (uint8_t)b;
         markPadding();
         std::vector<Ctx> ctx(bands);
-        std::vector<std::thread> th;
-        auto run = [&](int b) {
+        BandPool::mine().run(bands, [&](int b) {
             ctx[b].band = b;
             init_trees(ctx[b], row0[b], row0[b + 1]);
             search(ctx[b]);
-        };
-        for (int b = 1; b < bands; b++) th.emplace_back(run, b);
-        run(0);
-        for (auto& t : th) t.join();
+        });
         // continuation on the whole graph
         main_ = Ctx();
         for (int b = 0; b < bands; b++) { main_.flow += ctx[b].flow; main_.time = std::max(main_.time, ctx[b].time); }
