@@ -251,7 +251,10 @@ def main():
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.
     if rank == 0 and world == 1 and args.cpu_planes != 0 and planes is not None:
         from oracle import oracle as om
-        cores = os.cpu_count() or 1
+        # threads = the CPUs this process may keep busy: a cgroup CPU-time quota counts (the MI355X box shows 256 hardware threads
+        # and grants 16 CPUs of time per period; 256 threads then spend most of every period throttled: 111 instead of 522 Mevals/s)
+        from localexpstereo_amd.gc import cpu_budget
+        cores = cpu_budget()
         ns = args.cpu_planes if args.cpu_planes > 0 else max(cores, min(D - 1, 4 * cores, 96))
         ns = min(ns, D - 1)
         vol_host = vol[: ns + 1].cpu().numpy()

@@ -44,6 +44,26 @@ def load(path=None):
     return L
 
 
+def cpu_budget():
+    """CPUs this process may keep busy: the hardware threads, capped by a cgroup CPU-time quota (host/BandPool.h: cpuBudget)."""
+    import os
+    hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = period = -1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, period = int(q), int(p)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota > 0 and period > 0:
+        hw = min(hw, max(1, -(-quota // period)))
+    return hw
+
+
 def solve_prebuilt(regions, payload, offsets, masks_out, nthreads=0, lib=None):
     """Max-flow + segment readout of one lock-step of device-built graphs (stateless): fills masks_out (uint8, node order)."""
     L = load(lib)
