@@ -255,7 +255,7 @@ def main():
         # and grants 16 CPUs of time per period; 256 threads then spend most of every period throttled: 111 instead of 522 Mevals/s)
         from localexpstereo_amd.gc import cpu_budget
         cores = cpu_budget()
-        ns = args.cpu_planes if args.cpu_planes > 0 else max(cores, min(D - 1, 4 * cores, 96))
+        ns = args.cpu_planes if args.cpu_planes > 0 else D - 1          # (almost) the whole workload: ~12 CPU-seconds on 16 cores
         ns = min(ns, D - 1)
         vol_host = vol[: ns + 1].cpu().numpy()
         o = om.Oracle(guide, None, vol_host, None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1)
