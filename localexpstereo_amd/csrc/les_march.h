@@ -272,15 +272,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int pcX = cross ? Cfg::pcol((cP >> 6) * 64 - 1) : 0;           // element 0 is the constant zero
     const int pcS = Cfg::pcol(ci);
 
-#ifndef LES_MARCH_PRIO_C
-#define LES_MARCH_PRIO_C 0
-#define LES_MARCH_PRIO_D 0
-#endif
-#if defined(LES_SIM)
-#define LES_MARCH_SETPRIO(n) ((void)0)
-#else
-#define LES_MARCH_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#endif
+    // measurement switch (tools/role_time.sh): bit 0 / 1 / 2 = compile role A / C / D in; the waves of the other roles exit at once
 #ifndef LES_MARCH_ROLE_MASK
 #define LES_MARCH_ROLE_MASK 7
 #endif
@@ -424,7 +416,6 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         else march_a(std::integral_constant<int, 2>{});
     } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
         // ================================================= role C =================================================
-        LES_MARCH_SETPRIO(LES_MARCH_PRIO_C);
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
         const bool general_plane = !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2)
         // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
@@ -529,7 +520,6 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         LES_TICK_END(1);
     } else if (role == 2 && (LES_MARCH_ROLE_MASK & 4)) {
         // ================================================= role D =================================================
-        LES_MARCH_SETPRIO(LES_MARCH_PRIO_D);
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
         const uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;           // byte offset of the lane's output column in a row of the output tile
         // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
