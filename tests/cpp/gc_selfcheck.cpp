@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <thread>
 
 #include "PMStereo.h"
 #include "DemoScene.h"
@@ -209,6 +211,39 @@ static int banded_vs_plain()
     return fail;
 }
 
+// BandPool: every task of every run executes exactly once, also when several caller threads (each with its own persistent
+// team) run teams at the same time and when the team size changes between runs
+static int band_pool_check()
+{
+    int fail = 0;
+    auto caller = [&](int seed) {
+        RNG rng(seed);
+        for (int rep = 0; rep < 400; rep++) {
+            const int n = 1 + (int)(rng.uniform(0.f, 1.f) * 12);
+            std::vector<std::atomic<int>> hits(n);
+            for (auto& h : hits) h.store(0);
+            std::atomic<int> concurrent{0}, peak{0};
+            BandPool::mine().run(n, [&](int b) {
+                const int c = concurrent.fetch_add(1) + 1;
+                int p = peak.load();
+                while (c > p && !peak.compare_exchange_weak(p, c)) {}
+                volatile int spin = 0;
+                for (int k = 0; k < 200; k++) spin = spin + k;
+                hits[b].fetch_add(1);
+                concurrent.fetch_sub(1);
+            });
+            for (int b = 0; b < n; b++) if (hits[b].load() != 1) fail = 1;
+            if (peak.load() > n) fail = 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < 3; t++) th.emplace_back(caller, 100 + t);
+    caller(99);
+    for (auto& t : th) t.join();
+    printf("band pool: 4 callers x 400 runs %s\n", fail ? "FAILED" : "every task exactly once");
+    return fail;
+}
+
 int main(int argc, char** argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 120, H = argc > 2 ? atoi(argv[2]) : 80, D = argc > 3 ? atoi(argv[3]) : 24;
@@ -224,6 +259,7 @@ int main(int argc, char** argv)
         fail |= brute_force(tiny, param, 7.0f);
         fail |= grid_vs_generic();
         fail |= banded_vs_plain();
+        fail |= band_pool_check();
     }
     PMStereo st(W, H, param, maxd);
     st.setSeed(11);
