@@ -5,9 +5,12 @@
 //     q     = guided filter of p with the colour guide, radius R, eps           LES/GuidedFilter.h:142-266, 301-326
 //     q    -> 1e6 where the label is invalid                                    LES/CostVolumeEnergy.h:176-183
 //
-// but is organised around what the MI355X micro-benchmarks say is cheap (tools/ubench/valu_rates.hip): 32-bit integer /
-// fp32 adds issue in 2 cycles per wave, every fp64 operation, conversion, DPP move or 64-bit integer MAD in 4, an LDS
-// ds_write_b128 costs ~14 CU cycles and a ds_read_b128 4.  All four box-filter passes are therefore EXACT INTEGER sums:
+// but is organised around what the MI355X micro-benchmarks say is cheap (tools/ubench/valu_rates.hip, mix_issue.hip): 32-bit
+// integer / fp32 adds issue in 2 cycles per wave, every fp64 operation, conversion, DPP move or 64-bit integer MAD in 4 on a pipe
+// the waves of a SIMD share, an LDS ds_write_b128 costs ~13 CU cycles and a ds_read_b128 4, a wave issues at most one
+// instruction per ~4 cycles, a taken branch costs ~26, and the arbiter prefers the oldest wave.  All four box-filter passes are
+// therefore EXACT INTEGER sums, computed by three wave-specialised roles (A, C, D below; the prefix passes B1 / B2 run on the
+// waves of role A) that work on consecutive row blocks at the same time:
 //
 //   A  (lane = image column of a job, marching down the rows; NJ jobs per workgroup)
 //        p -> 22-bit fixed point  pi = round((p - vmin) * sp)      (p lives in [vmin, th_col]; vmin = min of the volume)
