@@ -163,6 +163,19 @@ int les_hip_batch_expansion_graph(les_hip_ctx* ctx, const les_hip_batch* batch, 
                                   const les_hip_plane* d_labels, const float* d_cur, const float* d_prop, float lambda, float th_smooth,
                                   float omega, float epsilon, float* d_payload, double* flow0_host);
 
+/* replaces (on the device, for cells of at most LES_HIP_MAXFLOW_MAX_NODES nodes): the max-flow and the segment read-out of
+ * FastGCStereo::expansionMoveBK -- graph.maxflow(); graph.what_segment(i) == SOURCE (LES/FastGCStereo.h:553-559) -- on the
+ * payload of les_hip_batch_expansion_graph, for all cells of the batch, one workgroup per cell with the whole graph in LDS
+ * (synchronous push-relabel; the cut is the canonical one of the reference's solver: SINK side = nodes that can still reach the
+ * sink).  d_masks: one byte per graph node (255 = the node takes the proposal), the input of les_hip_batch_apply_masks;
+ * d_status: n ints (0 = solved, 1 = iteration limit reached: cut that cell with the host solver instead); d_flows: n doubles or
+ * NULL (flow through the n-links; add flow0 of les_hip_batch_expansion_graph for the value of the cut).
+ * les_hip_batch_max_cell_nodes: the largest w * h of the batch's target rects (callers check it against the limit). */
+#define LES_HIP_MAXFLOW_MAX_NODES 2304
+long long les_hip_batch_max_cell_nodes(const les_hip_batch* batch);
+int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
+                               double* d_flows);
+
 /* replaces: the mask updates after a graph cut -- subProposalCost.copyTo(subCurrentCost, updateMask);
  * subCurrentLabeling.setTo(label, updateMask) (LES/FastGCStereo.h:61-62) -- for all cells of the batch.  d_masks: one
  * byte per graph node in the payload order of les_hip_batch_expansion_graph (non-zero = the node takes the proposal). */

@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
     "les_hip_calib_copy", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
@@ -68,6 +68,8 @@ def load(path=None):
         "les_hip_batch_graph_offsets": (ci, [vp, vp]),
         "les_hip_batch_expansion_graph": (ci, [vp, vp, ci, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
         "les_hip_batch_apply_masks": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+        "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
+        "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
         "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
@@ -237,6 +239,19 @@ class Batch:
                                                            C.c_void_p(int(cur_dev)), C.c_void_p(int(prop_dev)), lambda_, th_smooth, omega, epsilon,
                                                            C.c_void_p(int(payload_dev)), _ptr(f0)))
         return f0
+
+    MAXFLOW_MAX_NODES = 2304          # LES_HIP_MAXFLOW_MAX_NODES
+
+    @property
+    def max_cell_nodes(self):
+        return int(self.e.L.les_hip_batch_max_cell_nodes(self.h))
+
+    def solve_graphs(self, payload_dev, masks_dev, status_dev, flows_dev=None):
+        """Max-flow + segment read-out of every cell's expansion graph on the device (LES/FastGCStereo.h:553-559); cells of at most
+        MAXFLOW_MAX_NODES nodes.  masks (uint8 per node), status (int32 per cell: 0 solved, 1 = cut it on the host), flows (float64 per
+        cell, optional) are device pointers."""
+        self.e._chk(self.e.L.les_hip_batch_solve_graphs(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
+                                                        C.c_void_p(int(flows_dev)) if flows_dev else None))
 
     def apply_masks(self, planes_dev, masks_dev, cur_dev, prop_dev, labels_dev):
         """Mask updates of a lock-step on the device (LES/FastGCStereo.h:61-62); masks in graph-node order."""

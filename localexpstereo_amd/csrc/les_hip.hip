@@ -10,6 +10,7 @@
 #include "les_propose.h"
 #include "les_post.h"
 #include "les_pairwise.h"
+#include "les_maxflow.h"
 
 #include <algorithm>
 #include <mutex>
@@ -804,6 +805,38 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
             flow0_host[i] = s;
         }
     }
+    return LES_HIP_OK;
+}
+
+long long les_hip_batch_max_cell_nodes(const les_hip_batch* b)
+{
+    long long m = 0;
+    if (b) for (const les_hip_rect& t : b->targets) m = std::max(m, (long long)std::max(0, t.w) * std::max(0, t.h));
+    return m;
+}
+
+int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows)
+{
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
+    if (!c || !b || !d_payload || !d_masks || !d_status) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (b->n == 0) return LES_HIP_OK;
+    const long long maxn = les_hip_batch_max_cell_nodes(b);
+    if (maxn > LES_HIP_MAXFLOW_MAX_NODES) return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs: a cell of %lld nodes exceeds the limit of %d", maxn, LES_HIP_MAXFLOW_MAX_NODES);
+    static_assert(LES_HIP_MAXFLOW_MAX_NODES == les::kMfMaxNodes, "header constant out of date");
+    const int np = (int)((std::max<long long>(maxn, 1) + 7) / 8) * 8;
+    const size_t lds = les::mf_lds_bytes(np);
+#if !defined(LES_SIM)
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)les::mf_lds_bytes(les::kMfMaxNodes));
+    });
+    if (attr_rc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(attr_rc));
+#endif
+    const les::GraphCellMf* cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
+    hipLaunchKernelGGL(les::les_maxflow_kernel, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
+    HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
 

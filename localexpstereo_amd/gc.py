@@ -64,13 +64,16 @@ def cpu_budget():
     return hw
 
 
-def solve_prebuilt(regions, payload, offsets, masks_out, nthreads=0, lib=None):
-    """Max-flow + segment readout of one lock-step of device-built graphs (stateless): fills masks_out (uint8, node order)."""
+def solve_prebuilt(regions, payload, offsets, masks_out, nthreads=0, lib=None, flows_out=None):
+    """Max-flow + segment readout of one lock-step of device-built graphs (stateless): fills masks_out (uint8, node order) and, when
+    given, flows_out (float64 per cell: the flow through the n-links)."""
     L = load(lib)
     regions = api._rects(regions)
     assert payload.dtype == np.float32 and payload.flags.c_contiguous and masks_out.dtype == np.uint8 and masks_out.flags.c_contiguous
+    assert flows_out is None or (flows_out.dtype == np.float64 and flows_out.flags.c_contiguous and len(flows_out) >= len(regions))
     offsets = np.ascontiguousarray(offsets, np.int64)
-    if L.les_gc_solve_prebuilt(len(regions), api._ptr(regions), api._ptr(payload), api._ptr(offsets), nthreads, api._ptr(masks_out), None):
+    if L.les_gc_solve_prebuilt(len(regions), api._ptr(regions), api._ptr(payload), api._ptr(offsets), nthreads, api._ptr(masks_out),
+                               api._ptr(flows_out) if flows_out is not None else None):
         raise RuntimeError(L.les_gc_last_error().decode())
 
 

@@ -198,6 +198,11 @@ class PMRunner:
         gc_iteration) = the reference's shape: host-resident solution, host graph construction."""
         self.gc = graph_cut
         self.device_graph = device_graph
+        # device_cuts: cells small enough for a workgroup's LDS (the finest layer) are also CUT on the GPU (les_hip_batch_solve_graphs),
+        # so neither their graphs nor their masks cross PCIe and the host cores only see the larger cells.  On by default on a GPU
+        # (the simulator build used by the CPU tests would spend minutes in it).
+        if not hasattr(self, "device_cuts"):
+            self.device_cuts = self.device.type == "cuda"
         self._gc_mode = self.mode if mode is None else mode
         self.sync_gc_state()
         pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
@@ -265,11 +270,24 @@ class PMRunner:
                                 sh.batch.expansion_graph(sh.planes.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(),
                                                          sh.payload.data_ptr(), mode=m, lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"],
                                                          epsilon=p["epsilon"])
-                                self._sync()
-                                sh.payload_host.copy_(sh.payload)
-                                t1 = time.perf_counter()
-                                lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
-                                t2 = time.perf_counter()
+                                on_dev = False
+                                if self.device_cuts and sh.n and sh.batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES:
+                                    if getattr(self, "_gc_status", None) is None:
+                                        nmax = max([1] + [s_.n for layer_ in self.shards for s_ in layer_])
+                                        self._gc_status = torch.zeros(nmax, dtype=torch.int32, device=self.device)
+                                    st = self._gc_status[: sh.n]
+                                    sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr())
+                                    on_dev = not bool(st.any().item())          # (the only synchronisation of the lock-step)
+                                    if on_dev:
+                                        self.gc_seconds["cells_cut_on_device"] = self.gc_seconds.get("cells_cut_on_device", 0) + sh.n
+                                if on_dev:
+                                    t1 = t2 = time.perf_counter()
+                                else:
+                                    self._sync()
+                                    sh.payload_host.copy_(sh.payload)
+                                    t1 = time.perf_counter()
+                                    lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
+                                    t2 = time.perf_counter()
                                 dump = os.environ.get("LES_DUMP_GRAPHS")           # tooling: timing log of the lock-steps + the graphs of the slowest one of the coarsest layer
                                 if dump:
                                     with open(os.path.join(dump, f"cutlog_view{m}.txt"), "a") as f:
@@ -279,7 +297,8 @@ class PMRunner:
                                     nn = int(sh.graph_off[-1] + int(sh.regions[-1]["w"]) * int(sh.regions[-1]["h"]))
                                     np.savez_compressed(os.path.join(dump, f"graphs_view{m}_layer{li}.npz"), regions=sh.regions, offsets=sh.graph_off,
                                                         payload=sh.payload_host.numpy()[: nn * 5].copy(), seconds=t2 - t1)
-                                sh.masks.copy_(sh.masks_host)
+                                if not on_dev:
+                                    sh.masks.copy_(sh.masks_host)
                                 sh.batch.apply_masks(sh.planes.data_ptr(), sh.masks.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
                             t3 = time.perf_counter()
                             self.gc_seconds["device"] += t1 - t0

@@ -32,6 +32,7 @@ class FastGCStereo:
         self.concurrent_views = world == 1 and int(np.asarray(imL).shape[0]) * int(np.asarray(imL).shape[1]) >= 500_000
         self.joint_views = False
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
+        self.device_cuts = None                  # None: cut the cells that fit a workgroup's LDS on the GPU when there is one (pm.PMRunner.begin_gc)
 
     def addLayer(self, unit_region_size, proposers):
         """proposers: list of (kind, K) with kind in api.PROPOSE_EXPANSION / _RANDOM / _RANSAC (LES/FastGCStereo.h:88-92)."""
@@ -91,6 +92,8 @@ class FastGCStereo:
         self.gc_max_gap, self.gc_seconds = 0.0, {}
         if maxIteration > 0:
             for m in viewModes:
+                if self.device_cuts is not None:
+                    runners[m].device_cuts = bool(self.device_cuts)
                 runners[m].begin_gc(g, mode=m)
             main_device = torch.cuda.current_device() if torch.device(self.device).type == "cuda" else 0
 

@@ -791,6 +791,71 @@ def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25)
     return hist, gap
 
 
+def case_device_cuts_vs_host_cuts(lib, device, gc_iters=2, units=(14, 43)):
+    """(1) Lock-step by lock-step, on the graphs of real graph-cut iterations: the cells cut on the device
+    (les_hip_batch_solve_graphs) against the host solver on the same payload.  Both are minimum cuts of the same float graphs
+    with the same segment rule: the flow values agree to 1e-5, and the masks agree except for nodes on a tie that float
+    rounding of the residuals may move (measured on the MI355X: 3 of 779 100 nodes in the hardest lock-steps; bound: 2e-5).
+    (2) Whole iterations with device cuts against whole iterations with host cuts: the trajectories are both valid (a moved
+    tie changes later proposals), so only the energies are compared (5e-3)."""
+    from localexpstereo_amd import gc as lgc
+    from localexpstereo_amd import pm
+    imL, vol, gt = cones_ad_volume()
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 7)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]][: len(units)]
+    energies, worst, checked = [], 0.0, 0
+    for dev_cuts in (False, True):
+        e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0, lib=lib)
+        r = pm.PMRunner(e, units, table, seed=11, device=device)
+        g = lgc.GraphCut(imL, None, lambda_=1.0)
+        r.init_labels()
+        r.iteration(0)
+        r.device_cuts = dev_cuts
+        r.begin_gc(g)
+        if dev_cuts:
+            # (1) on the state the iterations start from
+            p = g.params
+            for sh in r.shards[0][:6]:
+                if not sh.n:
+                    continue
+                assert sh.batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES
+                r._gc_buffers(sh)
+                for kind in (api.PROPOSE_EXPANSION, api.PROPOSE_RANDOM, api.PROPOSE_RANSAC):
+                    sh.batch.propose(kind, r.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=0)
+                    sh.batch.run(sh.planes.data_ptr(), r.prop.data_ptr(), mode=0, check=True, planes_on_device=True)
+                    sh.batch.expansion_graph(sh.planes.data_ptr(), r.labels.data_ptr(), r.cur.data_ptr(), r.prop.data_ptr(), sh.payload.data_ptr(),
+                                             mode=0, lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"], epsilon=p["epsilon"])
+                    st = api.DeviceBuffer(e, 4 * sh.n)
+                    fl = api.DeviceBuffer(e, 8 * sh.n)
+                    sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.ptr, fl.ptr)
+                    e.synchronize()
+                    assert not st.download((sh.n,), np.int32).any()
+                    nn = sh.graph_nodes
+                    dm = sh.masks[:nn].cpu().numpy()
+                    ph = sh.payload[: nn * 5].cpu().numpy()
+                    hm, hf = np.zeros(nn, np.uint8), np.zeros(sh.n, np.float64)
+                    lgc.solve_prebuilt(sh.regions, ph, sh.graph_off, hm, flows_out=hf)
+                    df = fl.download((sh.n,), np.float64)
+                    # float residuals: every push rounds at the magnitude of the capacity it is taken from (1e6 terminals of
+                    # invalid labels: ulp 0.06), so the two flow values agree relative to the total terminal capacity of the cell
+                    tsum = np.add.reduceat(np.abs(ph.reshape(-1, 5)[:, 0]).astype(np.float64), np.asarray(sh.graph_off, np.int64))
+                    tol = 1e-6 * tsum + 1e-5 * np.abs(hf) + 1e-5
+                    assert (np.abs(df - hf) <= tol).all(), f"flow values differ by up to {np.abs(df - hf).max():.3e} (tolerance {tol[np.argmax(np.abs(df - hf))]:.3e})"
+                    frac = float(((dm != 0) != (hm != 0)).mean())
+                    worst = max(worst, frac)
+                    checked += 1
+                    assert frac <= 2e-5, f"{frac:.2e} of the nodes of a lock-step differ between the device cut and the host cut"
+                    st.free(); fl.free()
+        for it in range(gc_iters):
+            r.gc_iteration(it)
+        r.sync_gc_state()
+        energies.append(g.data_cost(0) + g.smoothness_cost(0))
+        assert (r.gc_seconds.get("cells_cut_on_device", 0) > 0) == dev_cuts
+        r.close(); e.close(); g.close()
+    assert checked >= 9
+    assert abs(energies[0] - energies[1]) <= 5e-3 * abs(energies[0]), energies
+    return worst, energies
+
+
 def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     """The Python FastGCStereo mirror end to end on the (padded) cones crop with config 1's energy, two views:
     PatchMatch iteration(s), graph-cut iteration(s), left-right post-processing, Evaluator rows."""
@@ -835,6 +900,7 @@ def case_joint_views(lib, device, units=(16,), pmInit=1, maxIteration=1):
         e = api.HipCostVolumeEnergy.naive(imLw, imRw, max_disp=63.0, lib=lib)
         st = stereo.FastGCStereo(e, imLw, imRw, dict(lambda_=1.0), device=device, seed=3)
         st.joint_views, st.concurrent_views = joint, False
+        st.device_cuts = False                 # (the joint form cuts on the host: compare like with like, bit for bit)
         for u, t in zip(units, tabs):
             st.addLayer(u, t)
         lab, raw = st.run(maxIteration, (0, 1), pmInit)
@@ -904,6 +970,20 @@ def case_expansion_graph(pr, unit=14, set_index=5, seed=41, lambda_=0.7):
         lgc.solve_prebuilt(regions, got, off, masks)
         mbuf = api.DeviceBuffer(pr.e, max(1, nn))
         mbuf.upload(masks)
+        # the same cuts on the device (cells that fit a workgroup's LDS): identical masks, flow = the host solver's
+        if batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES:
+            dm, ds, df = api.DeviceBuffer(pr.e, max(1, nn)), api.DeviceBuffer(pr.e, 4 * len(cells)), api.DeviceBuffer(pr.e, 8 * len(cells))
+            batch.solve_graphs(bufs["payload"].ptr, dm.ptr, ds.ptr, df.ptr)
+            pr.e.synchronize()
+            assert not ds.download((len(cells),), np.int32).any(), "device max-flow hit its iteration limit"
+            dev_masks = dm.download((nn,), np.uint8)
+            ndiff = int(((dev_masks != 0) != (masks != 0)).sum())
+            assert ndiff == 0, f"device cut differs from the host cut in {ndiff} of {nn} nodes (mode {mode}, set {si})"
+            assert (dev_masks != 0).any() and not (dev_masks != 0).all()
+            dev_flow = df.download((len(cells),), np.float64) + np.asarray(flow0, np.float64)
+            assert np.allclose(dev_flow, flows, rtol=2e-6, atol=1e-6), f"flows differ: {np.abs(dev_flow - flows).max()}"
+            for b_ in (dm, ds, df):
+                b_.free()
         batch.apply_masks(bufs["planes"].ptr, mbuf.ptr, bufs["cur"].ptr, bufs["prop"].ptr, bufs["labels"].ptr)
         pr.e.synchronize()
         assert np.array_equal(bufs["labels"].download((H, W, 4), np.float32).view(np.uint32), lab_dev.view(np.uint32))

@@ -347,6 +347,11 @@ def test_gpu_graph_cut_iterations(oracle_mod):
     print("cones crop PM+GC (bad1.0, data, smooth):", hist, "max flow-energy gap", gap)
 
 
+def test_gpu_device_cuts_vs_host_cuts(oracle_mod):
+    worst, energies = pc.case_device_cuts_vs_host_cuts(None, "cuda")
+    print("device cuts vs host cuts: largest fraction of differing nodes per lock-step", worst, "energies after the iterations (host, device)", energies)
+
+
 def test_gpu_stereo_driver_two_views(oracle_mod):
     rows = pc.case_stereo_driver(None, "cuda", units=(5, 15, 25), pmInit=1, maxIteration=1)
     print("FastGCStereo mirror, cones crop, two views:", rows)
