@@ -110,6 +110,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     __syncthreads();
 
     // residual distance to the sink (Jacobi sweeps); on return hgt = max(hgt, distance) when raise_only, else = distance
+    int dbg_sweeps = 0;                                    // (measurement builds report it through `flows`)
     auto global_relabel = [&](bool raise_only) {
         int d[kMfNodesPerThread];
 #pragma unroll
@@ -128,6 +129,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         for (;;) {
             if (tid == 0) flag[1] = 0;
             __syncthreads();
+            dbg_sweeps++;
             bool changed = false;
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
@@ -300,7 +302,11 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
 #else
         status[blockIdx.x] = converged ? 0 : 1;
 #endif
+#if defined(LES_MF_DEBUG_ITERS)
+        if (flows) flows[blockIdx.x] = (double)dbg_sweeps;
+#else
         if (flows) flows[blockIdx.x] = red[0];
+#endif
     }
 }
 

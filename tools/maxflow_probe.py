@@ -27,14 +27,15 @@ for kind in (api.PROPOSE_EXPANSION, api.PROPOSE_EXPANSION, api.PROPOSE_RANDOM, a
     sh.batch.expansion_graph(sh.planes.data_ptr(), r.labels.data_ptr(), r.cur.data_ptr(), r.prop.data_ptr(), sh.payload.data_ptr(), mode=0,
                              lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"], epsilon=p["epsilon"])
     st = torch.zeros(sh.n, dtype=torch.int32, device="cuda")
+    sw = torch.zeros(sh.n, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     t = time.perf_counter()
-    sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr())
+    sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr(), sw.data_ptr())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     its = -st.cpu().numpy()
     ph = sh.payload.cpu().numpy(); mh = np.zeros(sh.graph_nodes, np.uint8)
     t = time.perf_counter(); lgc.solve_prebuilt(sh.regions, ph, sh.graph_off, mh); th = time.perf_counter() - t
     dm = sh.masks.cpu().numpy()[: sh.graph_nodes]
-    print(f"kind {kind}: {sh.n} cells, device {dt * 1e3:.2f} ms, host {th * 1e3:.2f} ms; iterations median {np.median(its):.0f} mean {its.mean():.1f} max {its.max()}; "
+    print(f"kind {kind}: {sh.n} cells, device {dt * 1e3:.2f} ms, host {th * 1e3:.2f} ms; iterations median {np.median(its):.0f} mean {its.mean():.1f} max {its.max()}, relabel sweeps median {np.median(sw.cpu().numpy()):.0f} max {sw.max().item():.0f}; "
           f"nodes that differ from the host cut: {int(((dm != 0) != (mh != 0)).sum())} of {sh.graph_nodes}; changed {100 * (mh != 0).mean():.2f} %")
