@@ -829,13 +829,19 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)les::mf_lds_bytes(les::kMfMaxNodes));
+        if (attr_rc == hipSuccess)
+            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)les::mf_lds_bytes(les::kMfMaxNodes));
     });
     if (attr_rc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(attr_rc));
 #endif
     const les::GraphCellMf* cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
-    hipLaunchKernelGGL(les::les_maxflow_kernel, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
+    if (maxn <= 4 * les::kMfThreads)
+        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
+    else
+        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }

@@ -5,11 +5,12 @@
 // les_expansion_graph_kernel (les_pairwise.h): terminal residual + capacities of the arcs to the E, S, SW, SE neighbours.
 //
 // Algorithm: synchronous push-relabel (Goldberg-Tarjan, first phase only) in the data-parallel form that needs no atomics:
-//   per iteration   1. every active node pushes to the sink if its height is 1;
-//                   2. for each of the 8 grid directions in turn: every active node pushes along its arc of that direction when
-//                      the arc is admissible (height(v) == height(w) + 1); a node receives from at most one sender per direction,
-//                      so the receiving side is a second pass behind a barrier (`sent`), no two lanes ever write the same word;
-//                   3. active nodes without an admissible arc are relabelled from a snapshot of the heights;
+//   per iteration   1. four passes of two grid directions each: every active node pushes along its arcs of those directions when
+//                      they are admissible (height(v) == height(w) + 1); a node receives from at most one sender per direction,
+//                      so the receiving side is a second half behind a barrier (`sentA`, `sentB`) and no two lanes ever write
+//                      the same word.  Sink arcs are the negative part of the excess array: arriving excess is absorbed by the
+//                      addition itself (a node with sink capacity sits at height 1, the push to the sink is always admissible);
+//                   2. active nodes without an admissible arc are relabelled from a snapshot of the heights;
 //   every G iterations and at the end: global relabelling = residual distance to the sink by Jacobi sweeps until nothing changes.
 // Termination: no node with excess can reach the sink.  The cut is then read off the final distances: SINK side = the nodes that
 // can still reach the sink in the residual graph, which is the segment rule of the reference's solver (`what_segment` with
@@ -28,9 +29,9 @@ namespace les {
 // kernel is a chain of dependent LDS accesses between barriers and lives on latency hiding (measured: 256 threads and one
 // workgroup per CU took 8.6 ms for a lock-step of 450 cells that the host team cuts in 6.1 ms)
 constexpr int kMfThreads = 512;
-constexpr int kMfNodesPerThread = 5;                      // up to 2560 >= 2304 nodes (48 x 48) per cell
+// nodes per thread: a template parameter (4 for cells of up to 2048 nodes -- no register spills at 128 VGPRs --, 5 up to the limit)
 constexpr int kMfMaxNodes = 2304;
-static_assert(kMfThreads * kMfNodesPerThread >= kMfMaxNodes, "every node needs an owner");
+static_assert(kMfThreads * 5 >= kMfMaxNodes, "every node needs an owner");
 #ifndef LES_MF_G
 #define LES_MF_G 16
 #endif
@@ -39,7 +40,7 @@ constexpr int kMfGlobalRelabelEvery = LES_MF_G;
 #define LES_MF_MAX_ITER 6000
 #endif
 
-// LDS bytes for a launch whose largest cell has `nodes` nodes: r[8] + e + tcap + sent (float each) + height (uint16), + flags
+// LDS bytes for a launch whose largest cell has `nodes` nodes: r[8] + excess + two exchange words (float each) + height (uint16), + flags
 __host__ __device__ inline size_t mf_lds_bytes(int nodes)
 {
     const size_t n = (size_t)((nodes + 7) / 8) * 8;
@@ -54,8 +55,9 @@ struct GraphCellMf { int x, y, w, h; };                   // same layout as Grap
 __host__ __device__ inline int mf_dx(int k) { return (int)((0x02201102u >> (4 * k)) & 0xfu) - 1; }      // +1 -1  0  0 -1 +1 +1 -1
 __host__ __device__ inline int mf_dy(int k) { return (int)((0x02020211u >> (4 * k)) & 0xfu) - 1; }      //  0  0 +1 -1 +1 -1 +1 -1
 
-// grid = cells; block = kMfThreads; dynamic LDS = mf_lds_bytes(max nodes of the launch)
-__global__ void __launch_bounds__(kMfThreads)
+// grid = cells; block = kMfThreads; dynamic LDS = mf_lds_bytes(max nodes of the launch); NPT * kMfThreads >= nodes of every cell
+template <int kMfNodesPerThread>
+__global__ void __launch_bounds__(kMfThreads, 4)     // 4 waves per SIMD: two 8-wave workgroups per CU -> at most 128 VGPRs
 les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __restrict__ offsets, const float* __restrict__ payload,
                    int nmax_padded, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows)
 {
@@ -68,10 +70,10 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
 #endif
     const int NP = nmax_padded;                            // array pitch (multiple of 8)
     float* r = reinterpret_cast<float*>(base);             // r[k * NP + v], k = E W S N SW NE SE NW (sister = k ^ 1)
-    float* e = r + 8 * NP;
-    float* tcap = e + NP;
-    float* sent = tcap + NP;
-    uint16_t* hgt = reinterpret_cast<uint16_t*>(sent + NP);
+    float* ex = r + 8 * NP;                                // > 0: excess of the node; < 0: its remaining capacity to the sink
+    float* sentA = ex + NP;                                // what a node pushed along the first / second direction of the pass
+    float* sentB = sentA + NP;
+    uint16_t* hgt = reinterpret_cast<uint16_t*>(sentB + NP);
     int* flag = reinterpret_cast<int*>(hgt + NP);          // [0] any active, [1] relabel sweep changed something
 
     const GraphCellMf c = cells[blockIdx.x];
@@ -81,7 +83,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     if (N <= 0) { if (tid == 0) { status[blockIdx.x] = 0; if (flows) flows[blockIdx.x] = 0.0; } return; }
     const int BIG = N + 2;                                 // "cannot reach the sink" (fits uint16: N <= 2304)
 
-    // ---- own nodes: v = tid + j * 256
+    // ---- own nodes: v = tid + j * kMfThreads
     int vx[kMfNodesPerThread], vy[kMfNodesPerThread];
 #pragma unroll
     for (int j = 0; j < kMfNodesPerThread; j++) {
@@ -102,9 +104,10 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         r[4 * NP + v] = (y + 1 < H && x > 0) ? p5[5 * v + 3] : 0.0f;
         r[6 * NP + v] = (y + 1 < H && x + 1 < W) ? p5[5 * v + 4] : 0.0f;
         r[1 * NP + v] = 0.0f; r[3 * NP + v] = 0.0f; r[5 * NP + v] = 0.0f; r[7 * NP + v] = 0.0f;
-        e[v] = tr > 0.0f ? tr : 0.0f;
-        tcap[v] = tr < 0.0f ? -tr : 0.0f;
-        t_in += (double)tcap[v];
+        // source arcs are saturated at the start (excess = their capacity); a sink arc is the negative part: excess that arrives
+        // at such a node is absorbed by the addition itself (the node sits at height 1, the push to the sink is always admissible)
+        ex[v] = tr;
+        if (tr < 0.0f) t_in += (double)(-tr);
         hgt[v] = 0;
     }
     __syncthreads();
@@ -113,16 +116,12 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     int dbg_sweeps = 0;                                    // (measurement builds report it through `flows`)
     auto global_relabel = [&](bool raise_only) {
         int d[kMfNodesPerThread];
+        // the distances live in `sentA` (as integers) during the sweeps: the heights stay readable for raise_only
+        int* dist = reinterpret_cast<int*>(sentA);
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
             const int v = tid + j * kMfThreads;
-            d[j] = (v < N && tcap[v] > 0.0f) ? 1 : BIG;
-        }
-        // the distances live in `sent` (as integers) during the sweeps: the heights stay readable for raise_only
-        int* dist = reinterpret_cast<int*>(sent);
-#pragma unroll
-        for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            d[j] = (v < N && ex[v] < 0.0f) ? 1 : BIG;
             if (v < N) dist[v] = d[j];
         }
         __syncthreads();
@@ -135,13 +134,16 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             for (int j = 0; j < kMfNodesPerThread; j++) {
                 const int v = tid + j * kMfThreads;
                 if (v >= N) continue;
+                float rk[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) rk[k] = r[k * NP + v];
                 int best = d[j];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    if (!(r[k * NP + v] > 0.0f)) continue;                   // (a positive residual implies the neighbour exists)
-                    const int w = (vy[j] + mf_dy(k)) * W + vx[j] + mf_dx(k);
+                    // (a positive residual implies the neighbour exists; otherwise read the node's own word)
+                    const int w = rk[k] > 0.0f ? (vy[j] + mf_dy(k)) * W + vx[j] + mf_dx(k) : v;
                     const int dw = dist[w] + 1;
-                    best = dw < best ? dw : best;
+                    best = (rk[k] > 0.0f && dw < best) ? dw : best;
                 }
                 if (best < d[j]) { d[j] = best; changed = true; }
             }
@@ -178,75 +180,64 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
             const int v = tid + j * kMfThreads;
-            if (v < N && e[v] > 0.0f && (int)hgt[v] < BIG) act = true;
+            if (v < N && ex[v] > 0.0f && (int)hgt[v] < BIG) act = true;
         }
         if (act) flag[0] = 1;
         __syncthreads();
         if (!flag[0]) { converged = true; break; }
         __syncthreads();
-        // ---- 1. sink pushes (own data only)
-#pragma unroll
-        for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
-            if (v >= N) continue;
-            const float ev = e[v], tc = tcap[v];
-            if (ev > 0.0f && tc > 0.0f && hgt[v] == 1) {
-                const float d = ev < tc ? ev : tc;
-                e[v] = ev - d;
-                tcap[v] = tc - d;
-            }
-        }
-        // ---- 2. one direction at a time: push, barrier, receive, barrier.  All loads of a pass are issued before the first store
-        // (the passes are chains of LDS round trips; the own-node loop is unrolled so that the loads of all nodes overlap)
+        // ---- pushes, two directions per pass: a pass is "push, barrier, receive, barrier"; every word has one writer per half
+        // (a node has at most one sender per direction, and of the two arcs between a pair of nodes only one can be admissible).
+        // All loads of a half are issued before its first store: the halves are chains of LDS round trips.
 #pragma unroll 1
-        for (int k = 0; k < 8; k++) {
-            const int dx = mf_dx(k), dy = mf_dy(k);
-            const int woff = dy * W + dx;
-            float ev[kMfNodesPerThread], rv[kMfNodesPerThread];
-            int hv[kMfNodesPerThread], hw[kMfNodesPerThread];
+        for (int kp = 0; kp < 8; kp += 2) {
+            const int dxa = mf_dx(kp), dya = mf_dy(kp), dxb = mf_dx(kp + 1), dyb = mf_dy(kp + 1);
+            const int offa = dya * W + dxa, offb = dyb * W + dxb;
+            float ev[kMfNodesPerThread], ra[kMfNodesPerThread], rb[kMfNodesPerThread];
+            int hv[kMfNodesPerThread], ha[kMfNodesPerThread], hb[kMfNodesPerThread];
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
                 const int v = tid + j * kMfThreads;
                 const bool in = v < N;
                 const int vs = in ? v : 0;
-                ev[j] = e[vs]; rv[j] = r[k * NP + vs]; hv[j] = (int)hgt[vs];
+                ev[j] = ex[vs]; ra[j] = r[kp * NP + vs]; rb[j] = r[(kp + 1) * NP + vs]; hv[j] = (int)hgt[vs];
                 // the neighbour exists whenever the arc has capacity; otherwise read a harmless in-range word
-                const int nx = vx[j] + dx, ny = vy[j] + dy;
-                const int w = (in && nx >= 0 && nx < W && ny >= 0 && ny < H) ? vs + woff : vs;
-                hw[j] = (int)hgt[w];
+                const int ax = vx[j] + dxa, ay = vy[j] + dya, bx = vx[j] + dxb, by = vy[j] + dyb;
+                ha[j] = (int)hgt[(in && ax >= 0 && ax < W && ay >= 0 && ay < H) ? vs + offa : vs];
+                hb[j] = (int)hgt[(in && bx >= 0 && bx < W && by >= 0 && by < H) ? vs + offb : vs];
             }
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
                 const int v = tid + j * kMfThreads;
                 if (v >= N) continue;
-                float d = 0.0f;
-                if (ev[j] > 0.0f && rv[j] > 0.0f && hv[j] < BIG && hv[j] == hw[j] + 1) {
-                    d = ev[j] < rv[j] ? ev[j] : rv[j];
-                    e[v] = ev[j] - d;
-                    r[k * NP + v] = rv[j] - d;
+                float e0 = ev[j], da = 0.0f, db = 0.0f;
+                if (e0 > 0.0f && hv[j] < BIG) {
+                    if (ra[j] > 0.0f && hv[j] == ha[j] + 1) { da = e0 < ra[j] ? e0 : ra[j]; e0 -= da; r[kp * NP + v] = ra[j] - da; }
+                    if (e0 > 0.0f && rb[j] > 0.0f && hv[j] == hb[j] + 1) { db = e0 < rb[j] ? e0 : rb[j]; e0 -= db; r[(kp + 1) * NP + v] = rb[j] - db; }
+                    if (da > 0.0f || db > 0.0f) ex[v] = e0;
                 }
-                sent[v] = d;
+                sentA[v] = da;
+                sentB[v] = db;
             }
             __syncthreads();
-            float got[kMfNodesPerThread];
+            float ga[kMfNodesPerThread], gb[kMfNodesPerThread];
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
                 const int v = tid + j * kMfThreads;
-                const int ux = vx[j] - dx, uy = vy[j] - dy;                  // the node that pushes towards v in direction k
-                const bool has = v < N && ux >= 0 && ux < W && uy >= 0 && uy < H;
-                got[j] = has ? sent[v - woff] : 0.0f;
+                const int uax = vx[j] - dxa, uay = vy[j] - dya, ubx = vx[j] - dxb, uby = vy[j] - dyb;   // the nodes that push towards v
+                ga[j] = (v < N && uax >= 0 && uax < W && uay >= 0 && uay < H) ? sentA[v - offa] : 0.0f;
+                gb[j] = (v < N && ubx >= 0 && ubx < W && uby >= 0 && uby < H) ? sentB[v - offb] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
                 const int v = tid + j * kMfThreads;
-                if (got[j] > 0.0f) {
-                    e[v] += got[j];
-                    r[(k ^ 1) * NP + v] += got[j];
-                }
+                if (ga[j] > 0.0f) r[(kp ^ 1) * NP + v] += ga[j];
+                if (gb[j] > 0.0f) r[((kp + 1) ^ 1) * NP + v] += gb[j];
+                if (ga[j] > 0.0f || gb[j] > 0.0f) ex[v] += ga[j] + gb[j];     // (a sink arc absorbs what it can right here)
             }
             __syncthreads();
         }
-        // ---- 3. relabel (from a snapshot of the heights)
+        // ---- relabel (from a snapshot of the heights)
         int hn[kMfNodesPerThread];
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
@@ -254,8 +245,8 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             hn[j] = -1;
             if (v >= N) continue;
             const int hv = (int)hgt[v];
-            if (!(e[v] > 0.0f) || hv >= BIG) continue;
-            int best = tcap[v] > 0.0f ? 1 : BIG;
+            if (!(ex[v] > 0.0f) || hv >= BIG) continue;
+            int best = BIG;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 if (!(r[k * NP + v] > 0.0f)) continue;
@@ -263,7 +254,6 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
                 const int hw = (int)hgt[w] + 1;
                 best = hw < best ? hw : best;
             }
-            if (best > BIG) best = BIG;
             if (best > hv) hn[j] = best;
         }
         __syncthreads();
@@ -284,27 +274,24 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         const int v = tid + j * kMfThreads;
         if (v >= N) continue;
         m[v] = (int)hgt[v] >= BIG ? 255 : 0;
-        t_out += (double)tcap[v];
+        const float xv = ex[v];
+        if (xv < 0.0f) t_out += (double)(-xv);
     }
-    // flow into the sink = sink capacity used (block reduction through `sent`, 256 doubles fit: N >= 128 is not required, the
-    // array pitch is at least 64 floats ... use the r array, which is no longer needed)
+    // flow into the sink = sink capacity used; block reduction in the (no longer needed) residual array
     __syncthreads();
     double* red = reinterpret_cast<double*>(r);
     red[tid] = t_in - t_out;
     __syncthreads();
-    for (int s = kMfThreads / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+    for (int s2 = kMfThreads / 2; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
         __syncthreads();
     }
     if (tid == 0) {
 #if defined(LES_MF_DEBUG_ITERS)
         status[blockIdx.x] = converged ? -it : 1;             // measurement builds: the iteration count, negated
-#else
-        status[blockIdx.x] = converged ? 0 : 1;
-#endif
-#if defined(LES_MF_DEBUG_ITERS)
         if (flows) flows[blockIdx.x] = (double)dbg_sweeps;
 #else
+        status[blockIdx.x] = converged ? 0 : 1;
         if (flows) flows[blockIdx.x] = red[0];
 #endif
     }
