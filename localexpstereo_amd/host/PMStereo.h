@@ -13,6 +13,7 @@
 // the unary costs still come from the GPU; the graph cuts of the cells of a set run on the host cores (OpenMP) and
 // the updated label map goes back to the device after every lock-step.
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 
 #include <omp.h>
@@ -246,7 +247,9 @@ public:
             std::vector<long long> goff;
             float* d_payload = nullptr;
             unsigned char* d_masks = nullptr;
-            long long payload_cap = 0;
+            int* d_status = nullptr;
+            std::vector<int> status;
+            long long payload_cap = 0, status_cap = 0;
             // deviceGraph: the solution stays on the GPU; the host receives the ready-made graphs and returns one mask byte
             // per node.  Otherwise (or with the self-check on): host-resident solution and host graph construction.
             const bool devGraph = deviceGraph && !checkFlowEnergy;
@@ -275,6 +278,26 @@ public:
                                     }
                                     chk(les_hip_batch_expansion_graph(ctx, sb.b, mode, sb.planes, d_labels, d_cur, d_prop, params.lambda, params.th_smooth,
                                                                       params.omega, params.epsilon, d_payload, nullptr));
+                                    // cells that fit a workgroup's LDS (the finest layer) are also CUT on the device: neither their graphs
+                                    // nor their masks cross PCIe (LES/FastGCStereo.h:553-559 -> les_hip_batch_solve_graphs)
+                                    bool cutOnDevice = false;
+                                    if (deviceCuts && ok && les_hip_batch_max_cell_nodes(sb.b) <= LES_HIP_MAXFLOW_MAX_NODES) {
+                                        if (sb.n > status_cap) {
+                                            if (d_status) les_hip_free(ctx, d_status);
+                                            d_status = nullptr;
+                                            status_cap = sb.n;
+                                            chk(les_hip_malloc(ctx, (void**)&d_status, sizeof(int) * (size_t)sb.n));
+                                        }
+                                        status.assign((size_t)sb.n, 1);
+                                        chk(les_hip_batch_solve_graphs(ctx, sb.b, d_payload, d_masks, d_status, nullptr));
+                                        if (ok) chk(les_hip_memcpy_d2h(ctx, status.data(), d_status, sizeof(int) * (size_t)sb.n));
+                                        cutOnDevice = ok && std::all_of(status.begin(), status.end(), [](int v) { return v == 0; });
+                                    }
+                                    if (cutOnDevice) {
+                                        tB = tC = std::chrono::steady_clock::now();
+                                        chk(les_hip_batch_apply_masks(ctx, sb.b, sb.planes, d_masks, d_cur, d_prop, d_labels));
+                                        gcCellsCutOnDevice += sb.n;
+                                    } else {
                                     payload.resize((size_t)nodes * 5);
                                     masks.resize((size_t)nodes);
                                     goff.resize((size_t)sb.n);
@@ -290,6 +313,7 @@ public:
                                     tC = std::chrono::steady_clock::now();
                                     chk(les_hip_memcpy_h2d(ctx, d_masks, masks.data(), (size_t)nodes));
                                     chk(les_hip_batch_apply_masks(ctx, sb.b, sb.planes, d_masks, d_cur, d_prop, d_labels));
+                                    }
                                 } else {
                                     hplanes.resize(sb.n);
                                     chk(les_hip_memcpy_d2h(ctx, hplanes.data(), sb.planes, sizeof(les_hip_plane) * sb.n));
@@ -317,6 +341,7 @@ public:
             }
             if (d_payload) les_hip_free(ctx, d_payload);
             if (d_masks) les_hip_free(ctx, d_masks);
+            if (d_status) les_hip_free(ctx, d_status);
         }
         // two-view runs end with the left-right post-processing (LES/FastGCStereo.h:199-203)
         if (ok && viewModes.size() == 2) ok = postProcess(1.5f);
@@ -376,6 +401,8 @@ public:
     double gcSeconds[3] = {0, 0, 0};    // runDevice graph-cut lock-steps: GPU propose+unary+D2H / host cuts / H2D labels
     long gcLockSteps = 0;
     bool deviceGraph = true;            // runDevice: pairwise terms / graph capacities of the moves computed on the GPU (N1)
+    bool deviceCuts = true;             // runDevice: cells of at most LES_HIP_MAXFLOW_MAX_NODES nodes are cut on the GPU as well
+    long gcCellsCutOnDevice = 0;
     int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: at most 24 and one per cell -- larger teams are slower)
 
 private:

@@ -135,12 +135,28 @@ static int cmd_run(int argc, char** argv)
         st3->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
         st3->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
         double sec3 = 0;
+        st3->deviceCuts = false;                       // (host cuts on device-built graphs: bit for bit the host-built result)
         if (!st3->runDevice(1, {0}, &sec3, iters)) { printf("FAIL: runDevice (device graphs)\n"); return 1; }
         size_t diff = 0;
         for (size_t i = 0; i < st3->currentLabeling_[0].data.size(); i++) diff += !(st3->currentLabeling_[0].data[i] == st2->currentLabeling_[0].data[i]);
         printf("device-built graphs: %zu label differences vs host-built  (%.3f s; GPU %.3f s, host cuts %.3f s, H2D %.3f s)\n", diff, sec3,
                st3->gcSeconds[0], st3->gcSeconds[1], st3->gcSeconds[2]);
         if (diff) { printf("FAIL: device-built graphs changed the result\n"); fail = 1; }
+        // and with the cells that fit a workgroup's LDS cut on the GPU too (les_hip_batch_solve_graphs): minimum cuts of the same
+        // graphs with the same segment rule; a node on a tie may fall either way, which later proposals amplify, so the run is
+        // compared through its energy
+        auto st4 = build(7);
+        st4->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st4->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        double sec4 = 0;
+        if (!st4->runDevice(1, {0}, &sec4, iters)) { printf("FAIL: runDevice (device cuts)\n"); return 1; }
+        const double e_dc = st4->totalEnergy(0);
+        size_t diff4 = 0;
+        for (size_t i = 0; i < st4->currentLabeling_[0].data.size(); i++) diff4 += !(st4->currentLabeling_[0].data[i] == st2->currentLabeling_[0].data[i]);
+        printf("device cuts: %ld cells cut on the GPU, E=%.1f (host cuts: %.1f), %zu label differences  (%.3f s; GPU %.3f s, host cuts %.3f s)\n",
+               st4->gcCellsCutOnDevice, e_dc, e_gc, diff4, sec4, st4->gcSeconds[0], st4->gcSeconds[1]);
+        if (st4->gcCellsCutOnDevice == 0) { printf("FAIL: no cell was cut on the device\n"); fail = 1; }
+        if (std::fabs(e_dc - e_gc) > 5e-3 * std::fabs(e_gc)) { printf("FAIL: device cuts changed the energy\n"); fail = 1; }
         if (e_gc > e_pm) { printf("FAIL: graph-cut iterations increased the energy\n"); fail = 1; }
         if (st2->maxFlowEnergyGap > 1e-5) { printf("FAIL: flow != energy\n"); fail = 1; }
         if (bad_gc > 10.0) { printf("FAIL: graph-cut run did not converge\n"); fail = 1; }
