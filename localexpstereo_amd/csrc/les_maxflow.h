@@ -33,7 +33,7 @@ constexpr int kMfThreads = 512;
 constexpr int kMfMaxNodes = 2304;
 static_assert(kMfThreads * 5 >= kMfMaxNodes, "every node needs an owner");
 #ifndef LES_MF_G
-#define LES_MF_G 16
+#define LES_MF_G 8
 #endif
 constexpr int kMfGlobalRelabelEvery = LES_MF_G;
 #ifndef LES_MF_MAX_ITER
