@@ -1,4 +1,7 @@
-# iteration counts and kernel time of the device max-flow on a layer-0 lock-step of a synthetic Adirondack-shape scene
+"""Iteration counts, relabel sweeps and kernel time of the device max-flow (csrc/les_maxflow.h) on layer-0 lock-steps of a synthetic
+Adirondack-shape scene, next to the host team on the same graphs.  Needs a measurement build that reports the counts through the
+status / flows outputs:  bash tools/build_variant.sh mfdbg -DLES_MF_DEBUG_ITERS   (MF_LIB=<other variant>.so selects another one,
+e.g. built with -DLES_MF_G=<period of the global relabelling>)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 os.environ["LES_HIP_LIB"] = os.path.join(os.getcwd(), "localexpstereo_amd/csrc", os.environ.get("MF_LIB", "libles_mfdbg.so"))
