@@ -139,6 +139,31 @@ def one_case(rng, lib, stats):
         finite = np.isfinite(ref_payload)
         if not (np.array_equal(got.view(np.uint32)[finite], ref_payload.view(np.uint32)[finite]) and np.array_equal(np.isnan(got), np.isnan(ref_payload))):
             raise AssertionError(f"expansion-graph payload differs ({W}x{H}, {k} cells, mode {mode}, lambda {lam})")
+        # the cuts themselves: device solver (cells that fit a workgroup's LDS) against the host solver on the same payload.
+        # (NaN planes give NaN capacities: such graphs have no defined cut and are skipped, as are overlapping rects -- the
+        # payload offsets require disjoint node ranges, which the random rect pairs satisfy by construction)
+        if k > 0 and nn > 0 and batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES and np.isfinite(got).all():
+            dm, ds, df = api.DeviceBuffer(e, nn), api.DeviceBuffer(e, 4 * k), api.DeviceBuffer(e, 8 * k)
+            batch.solve_graphs(bufs[4].ptr, dm.ptr, ds.ptr, df.ptr)
+            e.synchronize()
+            if ds.download((k,), np.int32).any():
+                raise AssertionError(f"device max-flow hit its iteration limit ({W}x{H}, {k} cells)")
+            dev_m = dm.download((nn,), np.uint8)
+            host_m, host_f = np.zeros(nn, np.uint8), np.zeros(k, np.float64)
+            lgc.solve_prebuilt(trs, got, off, host_m, flows_out=host_f)
+            dev_f = df.download((k,), np.float64)
+            sizes = np.array([max(0, int(t["w"])) * max(0, int(t["h"])) for t in trs], np.int64)
+            tsum = np.array([np.abs(got.reshape(-1, 5)[int(o):int(o) + int(n_), 0]).astype(np.float64).sum() for o, n_ in zip(off, sizes)])
+            if not (np.abs(dev_f - host_f) <= 1e-6 * tsum + 1e-5 * np.abs(host_f) + 1e-5).all():
+                raise AssertionError(f"device / host flow values differ by {np.abs(dev_f - host_f).max():.3e} ({W}x{H}, {k} cells, lambda {lam})")
+            ndiff = int(((dev_m != 0) != (host_m != 0)).sum())
+            if ndiff > max(2, 2e-5 * nn):
+                raise AssertionError(f"device cut differs from the host cut in {ndiff} of {nn} nodes ({W}x{H}, {k} cells, lambda {lam})")
+            stats["cuts"] = stats.get("cuts", 0) + 1
+            stats["cut_nodes"] = stats.get("cut_nodes", 0) + nn
+            stats["cut_diff"] = stats.get("cut_diff", 0) + ndiff
+            for b_ in (dm, ds, df):
+                b_.free()
         batch.destroy()
         for b in bufs:
             b.free()
@@ -178,7 +203,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
-          f"{stats.get('graphs', 0)} expansion-graph lock-steps, {stats.get('naive', 0)} image-based energies, {stats.get('march', 0)} configurations on the march kernel, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut), {stats.get('naive', 0)} image-based energies, {stats.get('march', 0)} configurations on the march kernel, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
