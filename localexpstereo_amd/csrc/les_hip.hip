@@ -838,10 +838,12 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     if (attr_rc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(attr_rc));
 #endif
     const les::GraphCellMf* cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
+    int max_iter = les::kMfMaxIter;
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) max_iter = std::max(0, atoi(ev));      // tests of the callers' host fall-back
     if (maxn <= 4 * les::kMfThreads)
-        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     else
-        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }

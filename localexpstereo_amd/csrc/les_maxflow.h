@@ -16,7 +16,7 @@
 // can still reach the sink in the residual graph, which is the segment rule of the reference's solver (`what_segment` with
 // SOURCE as the default) and does not depend on which maximum preflow was found.  Capacities float as in Graph<float,float,double>.
 // tools/pushrelabel_probe.py is the numpy model of exactly this scheme (median 16 iterations on 42 x 42 crops of real graphs,
-// cuts identical to the host solver).  A cell that does not converge within LES_MF_MAX_ITER reports status 1 and is cut on the host.
+// cuts identical to the host solver).  A cell that does not converge within the iteration limit reports status 1 and is cut on the host.
 #pragma once
 
 #include <cstdint>
@@ -36,9 +36,7 @@ static_assert(kMfThreads * 5 >= kMfMaxNodes, "every node needs an owner");
 #define LES_MF_G 8
 #endif
 constexpr int kMfGlobalRelabelEvery = LES_MF_G;
-#ifndef LES_MF_MAX_ITER
-#define LES_MF_MAX_ITER 6000
-#endif
+constexpr int kMfMaxIter = 6000;                          // default iteration limit (LES_HIP_MAXFLOW_MAX_ITER overrides it: tests of the host fall-back)
 
 // LDS bytes for a launch whose largest cell has `nodes` nodes: r[8] + excess + two exchange words (float each) + height (uint16), + flags
 __host__ __device__ inline size_t mf_lds_bytes(int nodes)
@@ -59,7 +57,7 @@ __host__ __device__ inline int mf_dy(int k) { return (int)((0x02020211u >> (4 * 
 template <int kMfNodesPerThread>
 __global__ void __launch_bounds__(kMfThreads, 4)     // 4 waves per SIMD: two 8-wave workgroups per CU -> at most 128 VGPRs
 les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __restrict__ offsets, const float* __restrict__ payload,
-                   int nmax_padded, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows)
+                   int nmax_padded, int max_iter, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows)
 {
 #if defined(LES_SIM)
     static thread_local float s_raw[(kMfMaxNodes * 46 + 4160) / 4 + 16];
@@ -172,7 +170,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     global_relabel(false);
     int it = 0;
     bool converged = false;
-    for (; it < LES_MF_MAX_ITER; it++) {
+    for (; it < max_iter; it++) {
         // ---- any active node?
         if (tid == 0) flag[0] = 0;
         __syncthreads();

@@ -352,6 +352,33 @@ def test_gpu_device_cuts_vs_host_cuts(oracle_mod):
     print("device cuts vs host cuts: largest fraction of differing nodes per lock-step", worst, "energies after the iterations (host, device)", energies)
 
 
+def test_gpu_device_cuts_fall_back_to_the_host(oracle_mod, monkeypatch):
+    """A device max-flow that gives up (iteration limit 0) reports every cell, the lock-step is then cut on the host: the iteration
+    must equal, bit for bit, the one with device cuts switched off."""
+    from localexpstereo_amd import gc as lgc, pm
+    imL, vol, gt = pc.cones_ad_volume()
+    api = pc.api
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANDOM, 3)], [(api.PROPOSE_EXPANSION, 1)]]
+    out = []
+    for limit in ("0", None):
+        if limit is None:
+            monkeypatch.delenv("LES_HIP_MAXFLOW_MAX_ITER", raising=False)
+        else:
+            monkeypatch.setenv("LES_HIP_MAXFLOW_MAX_ITER", limit)
+        e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0)
+        r = pm.PMRunner(e, (14, 43), table, seed=5, device="cuda")
+        g = lgc.GraphCut(imL, None, lambda_=1.0)
+        r.init_labels()
+        r.iteration(0)
+        r.device_cuts = limit is not None
+        r.begin_gc(g)
+        r.gc_iteration(0)
+        assert r.gc_seconds.get("cells_cut_on_device", 0) == 0
+        out.append(r.labels.cpu().numpy().copy())
+        r.close(); e.close(); g.close()
+    assert out[0].tobytes() == out[1].tobytes()
+
+
 def test_gpu_stereo_driver_two_views(oracle_mod):
     rows = pc.case_stereo_driver(None, "cuda", units=(5, 15, 25), pmInit=1, maxIteration=1)
     print("FastGCStereo mirror, cones crop, two views:", rows)
