@@ -72,6 +72,10 @@ const char* les_hip_last_error(void);                   /* thread-local descript
 
 /* All launches go to this hipStream_t (NULL = the default stream).  Not in the reference. */
 int les_hip_set_stream(les_hip_ctx* ctx, void* hip_stream);
+/* bind != 0: from now on the launches the CALLING host thread makes on this context (and its les_hip_synchronize) go to
+ * hip_stream instead; bind == 0: back to the context's stream.  For callers that advance the two views of one context from two
+ * host threads (doDual: the views are independent until the post-processing, LES/FastGCStereo.h:172-185). */
+int les_hip_set_thread_stream(les_hip_ctx* ctx, void* hip_stream, int bind);
 int les_hip_synchronize(les_hip_ctx* ctx);
 
 /* replaces: CostVolumeEnergy::ComputeUnaryPotential (check != 0, LES/CostVolumeEnergy.h:176-183) and

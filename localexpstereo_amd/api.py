@@ -17,7 +17,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 
 # every symbol include/localexp_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_synchronize",
+    "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_set_thread_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
     "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
@@ -77,6 +77,7 @@ def load(path=None):
         "les_hip_destroy": (None, [vp]),
         "les_hip_last_error": (C.c_char_p, []),
         "les_hip_set_stream": (ci, [vp, vp]),
+        "les_hip_set_thread_stream": (ci, [vp, vp, ci]),
         "les_hip_synchronize": (ci, [vp]),
         "les_hip_unary_one": (ci, [vp, ci, vp, vp, vp, vp, ci, ci]),
         "les_hip_unary_batch": (ci, [vp, ci, ci, vp, vp, vp, vp, ci]),
@@ -328,6 +329,10 @@ class HipCostVolumeEnergy:
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.les_hip_set_stream(self.h, C.c_void_p(int(stream_ptr))))
+
+    def set_thread_stream(self, stream_ptr, bind=True):
+        """The calling host thread's launches on this context go to `stream_ptr` (bind=False: back to the context's stream)."""
+        self._chk(self.L.les_hip_set_thread_stream(self.h, C.c_void_p(int(stream_ptr)) if stream_ptr else None, int(bool(bind))))
 
     def synchronize(self):
         self._chk(self.L.les_hip_synchronize(self.h))

@@ -195,6 +195,12 @@ struct les_hip_scratch {
 
 namespace {
 
+// The stream the calling thread's launches go to: the context's stream, unless this host thread has bound its own for this
+// context (les_hip_set_thread_stream: two views advanced by two host threads on one context, each on its own stream).
+thread_local const les_hip_ctx* tl_stream_ctx = nullptr;
+thread_local hipStream_t tl_stream = nullptr;
+inline hipStream_t cur_stream(const les_hip_ctx* c) { return (tl_stream_ctx == c) ? tl_stream : c->stream; }
+
 int check_rects(const les_hip_ctx* c, const les_hip_rect& f, const les_hip_rect& t)
 {
     if (f.w < 0 || f.h < 0 || t.w < 0 || t.h < 0) return fail(LES_HIP_ERR_ARG, "negative rect size");
@@ -386,11 +392,11 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     float* d_min = nullptr; int* d_bad = nullptr;
     HIPCHECK(hipMalloc((void**)&d_min, nb * sizeof(float)));
     HIPCHECK(hipMalloc((void**)&d_bad, nb * sizeof(int)));
-    hipLaunchKernelGGL(les::les_range_kernel, dim3(nb), dim3(256), 0, c->stream, v.vol, P * (size_t)c->p.D, d_min, d_bad);
+    hipLaunchKernelGGL(les::les_range_kernel, dim3(nb), dim3(256), 0, cur_stream(c), v.vol, P * (size_t)c->p.D, d_min, d_bad);
     std::vector<float> hmin(nb); std::vector<int> hbad(nb);
-    HIPCHECK(hipMemcpyAsync(hmin.data(), d_min, nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipMemcpyAsync(hbad.data(), d_bad, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyAsync(hmin.data(), d_min, nb * sizeof(float), hipMemcpyDeviceToHost, cur_stream(c)));
+    HIPCHECK(hipMemcpyAsync(hbad.data(), d_bad, nb * sizeof(int), hipMemcpyDeviceToHost, cur_stream(c)));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     HIPCHECK(hipFree(d_min)); HIPCHECK(hipFree(d_bad));
     float vmin = INFINITY; int bad = 0;
     for (int i = 0; i < nb; i++) { vmin = std::min(vmin, hmin[i]); bad |= hbad[i]; }
@@ -401,14 +407,14 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     // tables
     unsigned* d_dmax = nullptr;
     HIPCHECK(hipMalloc((void**)&d_dmax, sizeof(unsigned)));
-    HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), c->stream));
+    HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), cur_stream(c)));
     HIPCHECK(hipMalloc((void**)&v.ipk8, P * sizeof(uint32_t)));
     HIPCHECK(hipMalloc((void**)&v.mstats, P * 3 * sizeof(float4)));
-    hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
+    hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
     HIPCHECK(hipGetLastError());
     unsigned dbits = 0;
-    HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, cur_stream(c)));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     HIPCHECK(hipFree(d_dmax));
     float dmax;
     memcpy(&dmax, &dbits, sizeof dmax);
@@ -449,22 +455,22 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     HIPCHECK(hipMalloc((void**)&v.ipk, P * sizeof(uint32_t)));
     HIPCHECK(hipMalloc((void**)&v.ipk10, P * sizeof(uint32_t)));
     HIPCHECK(hipMalloc((void**)&v.stats, (P * 3 + 1) * sizeof(float4)));           // + one all-zero entry (read by the k = 3 lanes of phase V)
-    HIPCHECK(hipMemsetAsync(v.stats + P * 3, 0, sizeof(float4), c->stream));
+    HIPCHECK(hipMemsetAsync(v.stats + P * 3, 0, sizeof(float4), cur_stream(c)));
     HIPCHECK(hipMalloc((void**)&d_hs, P * 9 * sizeof(double)));
     const int W = c->p.W, H = c->p.H;
     if (c->naive) {
         HIPCHECK(hipMalloc((void**)&v.feat, P * sizeof(float4)));
-        hipLaunchKernelGGL(les::les_naive_features_kernel, dim3((c->p.W + 255) / 256, c->p.H), dim3(256), 0, c->stream, d_img, v.feat, c->p.H, c->p.W, naive_alpha(c));
+        hipLaunchKernelGGL(les::les_naive_features_kernel, dim3((c->p.W + 255) / 256, c->p.H), dim3(256), 0, cur_stream(c), d_img, v.feat, c->p.H, c->p.W, naive_alpha(c));
     }
-    hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, c->stream, d_img, v.ipk, v.ipk10, (int)P);
-    hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, v.ipk, d_hs, H, W, c->R);
-    hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_hs, v.stats, H, W, c->R, c->p.eps);
+    hipLaunchKernelGGL(les::les_pack_guide_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, cur_stream(c), d_img, v.ipk, v.ipk10, (int)P);
+    hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), v.ipk, d_hs, H, W, c->R);
+    hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.stats, H, W, c->R, c->p.eps);
     HIPCHECK(hipGetLastError());
     if (c->march && v.vol) {
         int rc = build_march_view(c, m, d_hs);
         if (rc) { (void)hipFree(d_img); (void)hipFree(d_hs); return rc; }
     }
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     HIPCHECK(hipFree(d_img));
     HIPCHECK(hipFree(d_hs));
     return LES_HIP_OK;
@@ -588,10 +594,18 @@ int les_hip_set_stream(les_hip_ctx* c, void* s)
     return LES_HIP_OK;
 }
 
+int les_hip_set_thread_stream(les_hip_ctx* c, void* s, int bind)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null context");
+    if (bind) { tl_stream_ctx = c; tl_stream = (hipStream_t)s; }
+    else if (tl_stream_ctx == c) { tl_stream_ctx = nullptr; tl_stream = nullptr; }
+    return LES_HIP_OK;
+}
+
 int les_hip_synchronize(les_hip_ctx* c)
 {
     if (!c) return fail(LES_HIP_ERR_ARG, "null context");
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     return LES_HIP_OK;
 }
 
@@ -714,20 +728,20 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
     const float mind = c->p.min_disparity, maxd = c->p.max_disparity;
     switch (kind) {
     case LES_HIP_PROPOSE_EXPANSION:
-        hipLaunchKernelGGL(les::les_expansion_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n);
+        hipLaunchKernelGGL(les::les_expansion_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, lab, W, rng, pl, n);
         break;
     case LES_HIP_PROPOSE_RANDOM:
-        hipLaunchKernelGGL(les::les_random_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, n, m, mind, maxd);
+        hipLaunchKernelGGL(les::les_random_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, lab, W, rng, pl, n, m, mind, maxd);
         break;
     case LES_HIP_PROPOSE_RANSAC:
         // RansacProposer(K, MAX_SAM = 500, conf = 0.95), threshold 1.0 (LES/Proposer.h:265,305)
-        hipLaunchKernelGGL(les::les_ransac_snapshot_kernel, dim3(n), dim3(256), 0, c->stream, b->d_units, lab, W, b->rs);
-        hipLaunchKernelGGL(les::les_ransac_draw_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, b->rs, n, kRansacMaxSam);
-        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 15) / 16), dim3(64), 0, c->stream, b->d_units, b->rs, kRansacMaxSam, 1.0f);
-        hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f);
+        hipLaunchKernelGGL(les::les_ransac_snapshot_kernel, dim3(n), dim3(256), 0, cur_stream(c), b->d_units, lab, W, b->rs);
+        hipLaunchKernelGGL(les::les_ransac_draw_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, b->rs, n, kRansacMaxSam);
+        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 15) / 16), dim3(64), 0, cur_stream(c), b->d_units, b->rs, kRansacMaxSam, 1.0f);
+        hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f);
         break;
     case LES_HIP_PROPOSE_INIT:
-        hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, c->stream, b->d_units, lab, W, rng, pl, mind, maxd);
+        hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, cur_stream(c), b->d_units, lab, W, rng, pl, mind, maxd);
         break;
     default:
         return fail(LES_HIP_ERR_ARG, "unknown proposer kind %d", kind);
@@ -743,7 +757,7 @@ int les_hip_batch_wta(les_hip_ctx* c, const les_hip_batch* b, const les_hip_plan
     if (!c || !b || !planes || !cur || !prop || !labels) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
     if (!b->d_targets) return fail(LES_HIP_ERR_ARG, "batch has no target table");
-    hipLaunchKernelGGL(les::les_wta_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, b->d_targets, reinterpret_cast<const float4*>(planes),
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, cur_stream(c), b->d_targets, reinterpret_cast<const float4*>(planes),
                        cur, prop, reinterpret_cast<float4*>(labels), c->p.W);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
@@ -780,8 +794,8 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
         std::vector<float> tab(766);
         for (int k = 0; k < 766; k++) tab[k] = std::max(epsilon, std::exp(-(float)k / omega));
         if (!c->d_pw_tab) HIPCHECK(hipMalloc((void**)&c->d_pw_tab, tab.size() * sizeof(float)));
-        HIPCHECK(hipMemcpyAsync(c->d_pw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpyAsync(c->d_pw_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, cur_stream(c)));
+        HIPCHECK(hipStreamSynchronize(cur_stream(c)));
         c->pw_omega = omega; c->pw_epsilon = epsilon;
     }
     lk.unlock();
@@ -792,13 +806,13 @@ int les_hip_batch_expansion_graph(les_hip_ctx* c, const les_hip_batch* b, int mo
     const uint32_t* ipk = c->v[mode].ipk;
     const float* wtab = c->d_pw_tab;
     double* flow0 = b->d_flow0;
-    hipLaunchKernelGGL(les::les_expansion_graph_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, cells, offs, pl, lab, d_cur, d_prop, ipk, wtab,
+    hipLaunchKernelGGL(les::les_expansion_graph_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, cur_stream(c), cells, offs, pl, lab, d_cur, d_prop, ipk, wtab,
                        pp, d_payload, flow0);
     HIPCHECK(hipGetLastError());
     if (flow0_host) {
         std::vector<double> part((size_t)b->n * b->wta_chunks);
-        HIPCHECK(hipMemcpyAsync(part.data(), b->d_flow0, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpyAsync(part.data(), b->d_flow0, part.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream(c)));
+        HIPCHECK(hipStreamSynchronize(cur_stream(c)));
         for (int i = 0; i < b->n; i++) {
             double s = 0;
             for (int k = 0; k < b->wta_chunks; k++) s += part[(size_t)i * b->wta_chunks + k];
@@ -841,9 +855,9 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     int max_iter = les::kMfMaxIter;
     if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) max_iter = std::max(0, atoi(ev));      // tests of the callers' host fall-back
     if (maxn <= 4 * les::kMfThreads)
-        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     else
-        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, c->stream, cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -858,7 +872,7 @@ int les_hip_batch_apply_masks(les_hip_ctx* c, const les_hip_batch* b, const les_
     const long long* offs = b->d_graph_off;
     const float4* pl = reinterpret_cast<const float4*>(d_planes);
     float4* lab = reinterpret_cast<float4*>(d_labels);
-    hipLaunchKernelGGL(les::les_apply_masks_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, c->stream, cells, offs, pl, d_masks, d_cur, d_prop, lab, c->p.W);
+    hipLaunchKernelGGL(les::les_apply_masks_kernel, dim3(b->n, b->wta_chunks), dim3(256), 0, cur_stream(c), cells, offs, pl, d_masks, d_cur, d_prop, lab, c->p.W);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -873,12 +887,12 @@ int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const le
     if (!planes_on_device) {
         int rc = ensure_planes(c, (size_t)b->n);
         if (rc) return rc;
-        HIPCHECK(hipMemcpyAsync(c->d_planes, planes, (size_t)b->n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(c->d_planes, planes, (size_t)b->n * sizeof(float4), hipMemcpyHostToDevice, cur_stream(c)));
         d_planes = c->d_planes;
     }
     if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok)
-        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, c->stream);
-    return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check, c->stream);
+        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, cur_stream(c));
+    return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check, cur_stream(c));
 }
 
 int les_hip_unary_batch(les_hip_ctx* c, int mode, int n, const les_hip_rect* frs, const les_hip_rect* trs,
@@ -896,10 +910,10 @@ int les_hip_unary_batch(les_hip_ctx* c, int mode, int n, const les_hip_rect* frs
             if (t.w <= 0 || t.h <= 0) continue;
             size_t off = (size_t)t.y * c->p.W + t.x;
             hipError_t e = hipMemcpy2DAsync(cost_map + off, (size_t)c->p.W * sizeof(float), c->d_map + off, (size_t)c->p.W * sizeof(float),
-                                            (size_t)t.w * sizeof(float), (size_t)t.h, hipMemcpyDeviceToHost, c->stream);
+                                            (size_t)t.w * sizeof(float), (size_t)t.h, hipMemcpyDeviceToHost, cur_stream(c));
             if (e != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "hipMemcpy2DAsync failed: %s", hipGetErrorString(e));
         }
-        if (rc == LES_HIP_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "stream synchronize failed");
+        if (rc == LES_HIP_OK && hipStreamSynchronize(cur_stream(c)) != hipSuccess) rc = fail(LES_HIP_ERR_DEVICE, "stream synchronize failed");
     }
     les_hip_batch_destroy(b);
     return rc;
@@ -1045,7 +1059,7 @@ int les_hip_wta_update(les_hip_ctx* c, int n, const les_hip_rect* rects, const l
         c->wta_cap = std::max<size_t>(n, 1024);
     }
     static_assert(sizeof(les::WtaJob) == sizeof(les_hip_rect), "rect layout");
-    HIPCHECK(hipMemcpyAsync(c->d_wta, rects, (size_t)n * sizeof(les::WtaJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->d_wta, rects, (size_t)n * sizeof(les::WtaJob), hipMemcpyHostToDevice, cur_stream(c)));
     const float4* d_planes = reinterpret_cast<const float4*>(planes);
     if (!planes_on_device) {
         if ((size_t)n > c->wta_planes_cap) {
@@ -1054,13 +1068,13 @@ int les_hip_wta_update(les_hip_ctx* c, int n, const les_hip_rect* rects, const l
             HIPCHECK(hipMalloc((void**)&c->d_wta_planes, std::max<size_t>(n, 1024) * sizeof(float4)));
             c->wta_planes_cap = std::max<size_t>(n, 1024);
         }
-        HIPCHECK(hipMemcpyAsync(c->d_wta_planes, planes, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(c->d_wta_planes, planes, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, cur_stream(c)));
         d_planes = c->d_wta_planes;
     }
     int max_area = 1;
     for (int i = 0; i < n; i++) max_area = std::max(max_area, rects[i].w * rects[i].h);
     const int chunks = std::min(32, std::max(1, (max_area + 4095) / 4096));
-    hipLaunchKernelGGL(les::les_wta_kernel, dim3(n, chunks), dim3(256), 0, c->stream, c->d_wta, d_planes, cur, prop,
+    hipLaunchKernelGGL(les::les_wta_kernel, dim3(n, chunks), dim3(256), 0, cur_stream(c), c->d_wta, d_planes, cur, prop,
                        reinterpret_cast<float4*>(labels), c->p.W);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
@@ -1112,7 +1126,7 @@ int post_disparities(les_hip_ctx* c, PostScratch& ps, const les_hip_plane* const
         if (!ps.disp[m]) HIPCHECK(hipMalloc((void**)&ps.disp[m], P * sizeof(float)));
         const float4* lab = (const float4*)labels[m];
         float* disp = ps.disp[m];
-        hipLaunchKernelGGL(les::les_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, lab, disp, H, W);
+        hipLaunchKernelGGL(les::les_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), lab, disp, H, W);
     }
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
@@ -1134,10 +1148,10 @@ int les_hip_consistency_check(les_hip_ctx* c, const les_hip_plane* d_labelsL, co
         const float *d_self = ps.disp[m], *d_other = ps.disp[1 - m];
         unsigned char* o = out[m];
         const float sign = m ? -1.0f : 1.0f;
-        hipLaunchKernelGGL(les::les_lr_check_kernel, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d_self, d_other, o, H, W, sign, threshold);
+        hipLaunchKernelGGL(les::les_lr_check_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_self, d_other, o, H, W, sign, threshold);
     }
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     return LES_HIP_OK;
 }
 
@@ -1163,8 +1177,8 @@ int les_hip_post_process(les_hip_ctx* c, les_hip_plane* d_labelsL, les_hip_plane
         std::vector<float> tab(766);
         for (int k = 0; k < 766; k++) tab[k] = std::exp(-(float)k / omega);
         HIPCHECK(hipMalloc((void**)&ps.wtab, tab.size() * sizeof(float)));
-        HIPCHECK(hipMemcpyAsync(ps.wtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpyAsync(ps.wtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, cur_stream(c)));
+        HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     }
     const dim3 g((W + 255) / 256, H), b(256);
     // both fail masks come from the labels before any of them is modified (LES/PMStereoBase.h:158-164)
@@ -1176,28 +1190,28 @@ int les_hip_post_process(les_hip_ctx* c, les_hip_plane* d_labelsL, les_hip_plane
         uint8_t* failb = ps.failb + m * P;
         float4* lab = (float4*)labels[m];
         const float sign = m ? -1.0f : 1.0f;
-        hipLaunchKernelGGL(les::les_lr_check_kernel, g, b, 0, c->stream, d_self, d_other, failm, H, W, sign, threshold);
-        hipLaunchKernelGGL(les::les_fail_dilate_kernel, g, b, 0, c->stream, failm, failb, fail2, H, W);
-        hipLaunchKernelGGL(les::les_nn_fill_kernel, g, b, 0, c->stream, failb, fail2, lab, H, W);
+        hipLaunchKernelGGL(les::les_lr_check_kernel, g, b, 0, cur_stream(c), d_self, d_other, failm, H, W, sign, threshold);
+        hipLaunchKernelGGL(les::les_fail_dilate_kernel, g, b, 0, cur_stream(c), failm, failb, fail2, H, W);
+        hipLaunchKernelGGL(les::les_nn_fill_kernel, g, b, 0, cur_stream(c), failb, fail2, lab, H, W);
     }
     for (int m = 0; m < 2; m++) {
-        HIPCHECK(hipMemcpyAsync(ps.copy, labels[m], P * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(ps.copy, labels[m], P * sizeof(float4), hipMemcpyDeviceToDevice, cur_stream(c)));
         const dim3 gp(W, H);
         const int area = (2 * windR + 1) * (2 * windR + 1);
         const uint8_t* failb = ps.failb + m * P;
         float4* lab = (float4*)labels[m];
         const uint32_t* ipk = c->v[m].ipk;
         if (area <= 256)
-            hipLaunchKernelGGL((les::les_weighted_median_kernel<256, 64>), gp, dim3(64), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<256, 64>), gp, dim3(64), 0, cur_stream(c), failb, copy, lab, ipk, wtab, H, W, windR);
         else if (area <= 1024)
-            hipLaunchKernelGGL((les::les_weighted_median_kernel<1024, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<1024, 256>), gp, dim3(256), 0, cur_stream(c), failb, copy, lab, ipk, wtab, H, W, windR);
         else if (area <= 2048)
-            hipLaunchKernelGGL((les::les_weighted_median_kernel<2048, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<2048, 256>), gp, dim3(256), 0, cur_stream(c), failb, copy, lab, ipk, wtab, H, W, windR);
         else
-            hipLaunchKernelGGL((les::les_weighted_median_kernel<4096, 256>), gp, dim3(256), 0, c->stream, failb, copy, lab, ipk, wtab, H, W, windR);
+            hipLaunchKernelGGL((les::les_weighted_median_kernel<4096, 256>), gp, dim3(256), 0, cur_stream(c), failb, copy, lab, ipk, wtab, H, W, windR);
     }
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     return LES_HIP_OK;
 }
 
@@ -1225,21 +1239,21 @@ int les_hip_free(les_hip_ctx* c, void* p)
 int les_hip_memcpy_h2d(les_hip_ctx* c, void* d, const void* s, size_t bytes)
 {
     if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
-    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, cur_stream(c)));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     return LES_HIP_OK;
 }
 int les_hip_memcpy_d2h(les_hip_ctx* c, void* d, const void* s, size_t bytes)
 {
     if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
-    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, cur_stream(c)));
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
     return LES_HIP_OK;
 }
 int les_hip_memset(les_hip_ctx* c, void* d, int value, size_t bytes)
 {
     if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
-    HIPCHECK(hipMemsetAsync(d, value, bytes, c->stream));
+    HIPCHECK(hipMemsetAsync(d, value, bytes, cur_stream(c)));
     return LES_HIP_OK;
 }
 

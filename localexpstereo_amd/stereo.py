@@ -115,9 +115,26 @@ class FastGCStereo:
                     # 12 threads 10.3 s, 16 threads 10.2 s, 24 threads 10.8 s, 32 threads 11.1 s, 64 threads 11.7 s)
                     per_view = self.host_threads if self.host_threads > 0 else 16
 
+                    on_gpu = torch.device(self.device).type == "cuda"
+
                     def guarded(m):
                         try:
-                            one_view(m, it, per_view)
+                            if on_gpu:
+                                # each view advances on its own stream: its synchronisations (one per lock-step) then wait for its
+                                # own kernels only, and the two views' kernels overlap on the GPU
+                                dev = torch.device(self.device)
+                                torch.cuda.set_device(dev.index if dev.index is not None else main_device)
+                                side = torch.cuda.Stream()
+                                side.wait_stream(torch.cuda.default_stream())
+                                with torch.cuda.stream(side):
+                                    self.e.set_thread_stream(side.cuda_stream)
+                                    try:
+                                        one_view(m, it, per_view)
+                                        side.synchronize()
+                                    finally:
+                                        self.e.set_thread_stream(0, bind=False)
+                            else:
+                                one_view(m, it, per_view)
                         except BaseException as ex:          # re-raised in the caller's thread below
                             errors.append(ex)
                     ths = [threading.Thread(target=guarded, args=(m,)) for m in viewModes]
