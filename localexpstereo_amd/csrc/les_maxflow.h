@@ -168,12 +168,10 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     };
 
     global_relabel(false);
-    int it = 0;
-    bool converged = false;
-    for (; it < max_iter; it++) {
-        // ---- any active node?
-        if (tid == 0) flag[0] = 0;
-        __syncthreads();
+    // "is any node active?" (excess and a height below BIG) is evaluated where the heights are written -- here and at the end of
+    // every iteration -- so the loop head only reads the flag.  A periodic global relabelling in between can only deactivate
+    // nodes: the flag may then be stale by one (harmless) iteration.
+    auto note_active = [&]() {
         bool act = false;
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
@@ -181,9 +179,15 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             if (v < N && ex[v] > 0.0f && (int)hgt[v] < BIG) act = true;
         }
         if (act) flag[0] = 1;
-        __syncthreads();
+    };
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    note_active();
+    __syncthreads();
+    int it = 0;
+    bool converged = false;
+    for (; it < max_iter; it++) {
         if (!flag[0]) { converged = true; break; }
-        __syncthreads();
         // ---- pushes, two directions per pass: a pass is "push, barrier, receive, barrier"; every word has one writer per half
         // (a node has at most one sender per direction, and of the two arcs between a pair of nodes only one can be admissible).
         // All loads of a half are issued before its first store: the halves are chains of LDS round trips.
@@ -218,6 +222,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
                 sentB[v] = db;
             }
             __syncthreads();
+            if (kp == 0 && tid == 0) flag[0] = 0;                            // (every lane has read the flag at the loop head)
             float ga[kMfNodesPerThread], gb[kMfNodesPerThread];
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
@@ -260,6 +265,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             const int v = tid + j * kMfThreads;
             if (v < N && hn[j] >= 0) hgt[v] = (uint16_t)hn[j];
         }
+        note_active();                                                       // (own nodes only: their excess and new heights)
         __syncthreads();
         if ((it + 1) % kMfGlobalRelabelEvery == 0) global_relabel(true);
     }
