@@ -856,6 +856,76 @@ def case_device_cuts_vs_host_cuts(lib, device, gc_iters=2, units=(14, 43)):
     return worst, energies
 
 
+def case_device_maxflow_edge_cells(pr, seed=3):
+    """les_hip_batch_solve_graphs on hand-made graphs of awkward shapes -- single rows and columns, 1 x 1 and 2 x 2 cells, cells with no
+    arcs, with only source or only sink terminals, with terminals of 1e6 next to capacities below 1, and one cell just under the
+    node limit -- against the host solver on the same payload: identical masks, equal flows.  Also: a cell above the limit is refused."""
+    from localexpstereo_amd import gc as lgc
+    rng = np.random.default_rng(seed)
+    H, W = pr.H, pr.W
+    shapes = [(1, 1), (2, 2), (1, 17), (19, 1), (7, 5), (12, 12), (16, 9), (5, 23), (13, 13), (11, 8), (9, 9), (10, 6)]
+    if W >= 48 and H >= 48:
+        shapes.append((48, 48))                              # 2304 nodes: the largest cell the kernel takes (five nodes per thread)
+    rects, x, y, rowh = [], 0, 0, 0
+    for (w, h) in shapes:
+        if x + w > W:
+            x, y, rowh = 0, y + rowh, 0
+        assert y + h <= H
+        rects.append((x, y, w, h))
+        x += w
+        rowh = max(rowh, h)
+    trs = api._rects(np.array(rects, np.int32))
+    batch = api.Batch(pr.e, trs, trs)
+    off, nn, k = batch.graph_offsets(), batch.graph_nodes(), len(rects)
+    pay = np.zeros((nn, 5), np.float32)
+    for i, (_, _, w, h) in enumerate(rects):
+        n = w * h
+        p = pay[off[i]: off[i] + n]
+        p[:, 0] = rng.normal(0, 0.8, n)
+        p[:, 1:] = rng.uniform(0, 0.6, (n, 4)) * (rng.uniform(0, 1, (n, 4)) < 0.8)
+        kind = i % 6
+        if kind == 1:
+            p[:, 1:] = 0                                      # no arcs at all
+        elif kind == 2:
+            p[:, 0] = np.abs(p[:, 0])                         # only source terminals: everything takes the proposal
+        elif kind == 3:
+            p[:, 0] = -np.abs(p[:, 0])                        # only sink terminals: nothing changes
+        elif kind == 4:
+            big = rng.uniform(0, 1, n) < 0.3
+            p[big, 0] = np.where(rng.uniform(0, 1, int(big.sum())) < 0.5, 1e6, -1e6)
+        q = p.reshape(h, w, 5)                                # arcs E, S, SW, SE that would leave the cell carry no capacity
+        q[:, -1, 1] = 0; q[-1, :, 2] = 0; q[-1, :, 3] = 0; q[:, 0, 3] = 0; q[-1, :, 4] = 0; q[:, -1, 4] = 0
+    pay = np.ascontiguousarray(pay.reshape(-1))
+    dp, dm, ds, df = api.DeviceBuffer(pr.e, nn * 20), api.DeviceBuffer(pr.e, nn), api.DeviceBuffer(pr.e, 4 * k), api.DeviceBuffer(pr.e, 8 * k)
+    dp.upload(pay)
+    batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
+    pr.e.synchronize()
+    assert not ds.download((k,), np.int32).any()
+    dev_m, dev_f = dm.download((nn,), np.uint8), df.download((k,), np.float64)
+    host_m, host_f = np.zeros(nn, np.uint8), np.zeros(k, np.float64)
+    lgc.solve_prebuilt(trs, pay, off, host_m, flows_out=host_f)
+    assert np.array_equal(dev_m != 0, host_m != 0), f"{int(((dev_m != 0) != (host_m != 0)).sum())} nodes differ from the host cut"
+    tsum = np.array([np.abs(pay.reshape(-1, 5)[off[i]: off[i] + w * h, 0]).astype(np.float64).sum() for i, (_, _, w, h) in enumerate(rects)])
+    assert (np.abs(dev_f - host_f) <= 1e-6 * tsum + 1e-5 * np.abs(host_f) + 1e-5).all(), np.abs(dev_f - host_f).max()
+    assert (dev_m != 0).any() and not (dev_m != 0).all()
+    for b_ in (dp, dm, ds, df):
+        b_.free()
+    batch.destroy()
+    if W >= 49 and H >= 48:                                   # 49 x 48 > 2304 nodes: refused, the caller keeps such cells on the host
+        big = api._rects(np.array([(0, 0, 49, 48)], np.int32))
+        b2 = api.Batch(pr.e, big, big)
+        assert b2.max_cell_nodes == 49 * 48
+        d1, d2, d3 = api.DeviceBuffer(pr.e, 49 * 48 * 20), api.DeviceBuffer(pr.e, 49 * 48), api.DeviceBuffer(pr.e, 4)
+        try:
+            b2.solve_graphs(d1.ptr, d2.ptr, d3.ptr)
+            raise AssertionError("a cell above LES_HIP_MAXFLOW_MAX_NODES was accepted")
+        except api.LesHipError as ex:
+            assert "exceeds the limit" in str(ex)
+        for b_ in (d1, d2, d3):
+            b_.free()
+        b2.destroy()
+
+
 def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     """The Python FastGCStereo mirror end to end on the (padded) cones crop with config 1's energy, two views:
     PatchMatch iteration(s), graph-cut iteration(s), left-right post-processing, Evaluator rows."""

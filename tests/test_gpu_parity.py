@@ -352,6 +352,11 @@ def test_gpu_device_cuts_vs_host_cuts(oracle_mod):
     print("device cuts vs host cuts: largest fraction of differing nodes per lock-step", worst, "energies after the iterations (host, device)", energies)
 
 
+def test_gpu_device_maxflow_edge_cells(cones, mid):
+    pc.case_device_maxflow_edge_cells(cones)
+    pc.case_device_maxflow_edge_cells(mid, seed=8)
+
+
 def test_gpu_device_cuts_fall_back_to_the_host(oracle_mod, monkeypatch):
     """A device max-flow that gives up (iteration limit 0) reports every cell, the lock-step is then cut on the host: the iteration
     must equal, bit for bit, the one with device cuts switched off."""

@@ -196,6 +196,13 @@ def test_sim_expansion_graph_on_device(cones):
     pc.case_expansion_graph(cones)
 
 
+def test_sim_device_maxflow_edge_cells(cones):
+    """The device max-flow (csrc/les_maxflow.h) on hand-made graphs of awkward shapes against the host solver."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    pc.case_device_maxflow_edge_cells(cones)
+
+
 def test_sim_graph_cut_iterations(sim_lib, oracle_mod, monkeypatch):
     """PatchMatch + graph-cut iterations through the Python driver: simulator proposals / unary costs, host cuts.
     (Driver and host-cut logic are under test: the fiber simulator runs them on the 256-thread strip kernel, ~4x faster than on the
