@@ -214,6 +214,17 @@ def test_sim_graph_cut_iterations(sim_lib, oracle_mod, monkeypatch):
     print("cones crop PM+GC (bad1.0, data, smooth):", hist, "max flow-energy gap", gap)
 
 
+def test_sim_graph_cut_iteration_with_device_cuts(sim_lib, oracle_mod, monkeypatch):
+    """The same driver with the cells cut by the device max-flow kernel (run here by the fiber simulator): the iteration lowers the
+    energy and every cell that fits is cut on the "device"."""
+    monkeypatch.setenv("LES_HIP_KERNEL", "strip")
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    hist, gap = pc.case_quality_cones_gc(sim_lib, "cpu", units=(12,), device_cuts=True, table=[[(pc.api.PROPOSE_EXPANSION, 1), (pc.api.PROPOSE_RANDOM, 1)]],
+                                         check_quality=False)      # (two proposals per cell: the energy must go down, convergence is not expected)
+    print("cones crop PM+GC with device cuts (bad1.0, data, smooth):", hist)
+
+
 def test_sim_ingest_files(sim_lib, oracle_mod, tmp_path):
     pc.case_ingest_files(sim_lib, "cpu", tmp_path)
 
