@@ -389,15 +389,19 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     if (!(th > 0.0f) || !(th < INFINITY)) return LES_HIP_OK;
     // cost range
     const int nb = 2048;
-    float* d_min = nullptr; int* d_bad = nullptr;
-    HIPCHECK(hipMalloc((void**)&d_min, nb * sizeof(float)));
-    HIPCHECK(hipMalloc((void**)&d_bad, nb * sizeof(int)));
-    hipLaunchKernelGGL(les::les_range_kernel, dim3(nb), dim3(256), 0, cur_stream(c), v.vol, P * (size_t)c->p.D, d_min, d_bad);
     std::vector<float> hmin(nb); std::vector<int> hbad(nb);
-    HIPCHECK(hipMemcpyAsync(hmin.data(), d_min, nb * sizeof(float), hipMemcpyDeviceToHost, cur_stream(c)));
-    HIPCHECK(hipMemcpyAsync(hbad.data(), d_bad, nb * sizeof(int), hipMemcpyDeviceToHost, cur_stream(c)));
-    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
-    HIPCHECK(hipFree(d_min)); HIPCHECK(hipFree(d_bad));
+    {
+        // one allocation for both partial arrays, released on every path (a failing call must not leak device memory)
+        struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } part;
+        HIPCHECK(hipMalloc(&part.p, nb * (sizeof(float) + sizeof(int))));
+        float* d_min = static_cast<float*>(part.p);
+        int* d_bad = reinterpret_cast<int*>(d_min + nb);
+        hipLaunchKernelGGL(les::les_range_kernel, dim3(nb), dim3(256), 0, cur_stream(c), v.vol, P * (size_t)c->p.D, d_min, d_bad);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(hmin.data(), d_min, nb * sizeof(float), hipMemcpyDeviceToHost, cur_stream(c)));
+        HIPCHECK(hipMemcpyAsync(hbad.data(), d_bad, nb * sizeof(int), hipMemcpyDeviceToHost, cur_stream(c)));
+        HIPCHECK(hipStreamSynchronize(cur_stream(c)));
+    }
     float vmin = INFINITY; int bad = 0;
     for (int i = 0; i < nb; i++) { vmin = std::min(vmin, hmin[i]); bad |= hbad[i]; }
     if (bad || !(vmin < INFINITY)) return LES_HIP_OK;              // NaN / inf costs: the fp64 strip kernel reproduces the reference's propagation
@@ -405,17 +409,19 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     const double range = (double)th - (double)vmin;
     if (!(range <= 8.0 * (double)th)) return LES_HIP_OK;            // the 22-bit fixed point would resolve th_col too coarsely
     // tables
-    unsigned* d_dmax = nullptr;
-    HIPCHECK(hipMalloc((void**)&d_dmax, sizeof(unsigned)));
-    HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), cur_stream(c)));
-    HIPCHECK(hipMalloc((void**)&v.ipk8, P * sizeof(uint32_t)));
-    HIPCHECK(hipMalloc((void**)&v.mstats, P * 3 * sizeof(float4)));
-    hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
-    HIPCHECK(hipGetLastError());
     unsigned dbits = 0;
-    HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, cur_stream(c)));
-    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
-    HIPCHECK(hipFree(d_dmax));
+    {
+        struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } dm;
+        HIPCHECK(hipMalloc(&dm.p, sizeof(unsigned)));
+        unsigned* d_dmax = static_cast<unsigned*>(dm.p);
+        HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), cur_stream(c)));
+        HIPCHECK(hipMalloc((void**)&v.ipk8, P * sizeof(uint32_t)));
+        HIPCHECK(hipMalloc((void**)&v.mstats, P * 3 * sizeof(float4)));
+        hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, cur_stream(c)));
+        HIPCHECK(hipStreamSynchronize(cur_stream(c)));
+    }
     float dmax;
     memcpy(&dmax, &dbits, sizeof dmax);
     if (!(dmax > 0.0f) || !(dmax < INFINITY)) return LES_HIP_OK;

@@ -209,6 +209,11 @@ typedef float mstat4 __attribute__((ext_vector_type(4)));
 #define LES_STATS_WAIT6(n, r, q) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]))
 #endif
 
+// measurement switches (ablations: the output is meaningless, the time shows what a resource costs): 1 role C issues no statistics
+// loads, 2 role C reads no LDS, 16 role D reads no LDS, 64 role A loads nothing, 128 role D loads / stores nothing
+#ifndef LES_MARCH_EXP
+#define LES_MARCH_EXP 0
+#endif
 template <int R, int WGC, int NJ, int BY>
 __global__ void __launch_bounds__(3 * WGC * NJ)
 les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
@@ -329,6 +334,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             constexpr int i = decltype(itag)::value;
             const uint32_t rowpx = (uint32_t)readlane_i32(nx_rowpx, i);
             const uint32_t ro = rowpx & 0x7fffffffu;
+            if (LES_MARCH_EXP & 64) { rowbits = 0x7f; v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
             if constexpr (KIND < 2) {
                 rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
                 const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
@@ -446,6 +452,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             const float4* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * 3;          // scalar row base + the lane's column
             mstat4 &d0 = st[i][0], &d1 = st[i][1], &d2 = st[i][2];                    // (named here: operands of an asm statement alone do not capture)
             const uint32_t off = sx48;
+            if (LES_MARCH_EXP & 1) return;
             LES_STATS_LOAD(d0, sp, off, 0); LES_STATS_LOAD(d1, sp, off, 16); LES_STATS_LOAD(d2, sp, off, 32);
         };
         prep(0);
@@ -466,7 +473,10 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     constexpr int S = decltype(stag)::value;
 #pragma unroll
                     for (int j = 0; j < GC; j++)
-                        if (S * GC + j < BY) { pp[S & 1][j] = T1[S * GC + j][pcP]; pm[S & 1][j] = T1[S * GC + j][pcM]; px[S & 1][j] = T1[S * GC + j][pcX]; }
+                        if (S * GC + j < BY) {
+                            if (LES_MARCH_EXP & 2) { pp[S & 1][j] = int4{lane, k, 2, 3}; pm[S & 1][j] = int4{3, 2, k, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
+                            else { pp[S & 1][j] = T1[S * GC + j][pcP]; pm[S & 1][j] = T1[S * GC + j][pcM]; px[S & 1][j] = T1[S * GC + j][pcX]; }
+                        }
                 };
                 lds_stage(std::integral_constant<int, 0>{});
                 static_for<NS>([&](auto gtag) {
@@ -551,6 +561,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             rny2[i] = readlane_f32(nx_rny, i);
             okbits = (okbits & ~(1u << i)) | ((grow >> 31) << i);
             const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
+            if (LES_MARCH_EXP & 128) { gq[i] = (uint32_t)lane; return; }
             gq[i] = ld_sbase(rg, sx4);
         };
         // two specialisations (label check on / off), selected once per job -- see role A
@@ -573,7 +584,10 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             constexpr int S = decltype(stag)::value;
 #pragma unroll
                             for (int j = 0; j < GD; j++)
-                                if (S * GD + j < BY) { pp[S & 1][j] = T2[S * GD + j][pcP]; pm[S & 1][j] = T2[S * GD + j][pcM]; px[S & 1][j] = T2[S * GD + j][pcX]; }
+                                if (S * GD + j < BY) {
+                                    if (LES_MARCH_EXP & 16) { pp[S & 1][j] = int4{lane, b, 2, 3}; pm[S & 1][j] = int4{3, 2, b, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
+                                    else { pp[S & 1][j] = T2[S * GD + j][pcP]; pm[S & 1][j] = T2[S * GD + j][pcM]; px[S & 1][j] = T2[S * GD + j][pcX]; }
+                                }
                         };
                         lds_stage(std::integral_constant<int, 0>{});
                         static_for<NS>([&](auto gtag) {
@@ -608,6 +622,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                         const float mn = fmin3(fmin3(ds, d1, d2), d3, d4), mx = fmax3(fmax3(ds, d1, d2), d3, d4);
                                         if (!(mn >= g.mind && mx <= g.maxd)) q = LES_COST_INVALID;
                                     }
+                                    if (!((LES_MARCH_EXP & 128) && q != 12345.0f))
                                     st_sbase(out + (job.out_off + (long long)(t - 4 * R) * job.out_stride), oc4, q);
                                 }
                             });
