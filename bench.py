@@ -7,14 +7,17 @@ synthetic 1500 x 1000 x 256 float32 U[0,1) cost volume, windR = 20 (guided-filte
 eps = 1e-4, th_col = 0.5.  One "step" = one pass over all 256 hypotheses = W*H*D = 384 M cost
 evaluations (gather the volume taps -> truncate -> colour guided filter), inputs resident in HBM.
 
-Multi-GPU (--gpus N > 1, launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[4],
-the synthetic 3000 x 2000 x 512 volume: hypotheses (disparity slices) are independent, so the 512 slices are
-split into 512/N per rank with no data-path collective, guide statistics replicated (at N = 8 every rank
-aggregates 64 slices of 3000 x 2000 = the evaluation count of the 1-GPU workload).  The total is fixed, so the
-N > 1 lines are "strong" scaling of configs[4]; N = 1 stays on configs[2].
+Multi-GPU (--gpus N > 1, launched by torch.distributed.run, one rank per GPU): the shard of BASELINE.json configs[4] --
+hypotheses (disparity slices) are independent, so every rank aggregates 64 slices of a 3000 x 2000 image (= 384 M evaluations,
+the evaluation count of the 1-GPU workload) with no data-path collective and replicated guide statistics; at N = 8 the ranks
+together hold exactly the 3000 x 2000 x 512 volume of configs[4].  Per-GPU work is fixed for every N: "weak" scaling.  N = 1
+stays on configs[2] (the configuration the metric is quoted on) and also reports the per-rank shape of the N > 1 runs as the
+sub-record `n8_rank_shape`, so that a 1 -> 8 curve has a like-for-like baseline.
 
 At N = 1 the JSON line also carries the H2 (slanted planes, two volume taps) and H3 (LayerManager cell batches, the
-optimiser's geometry) measurements of the same build as sub-records (`h2`, `h3`).
+optimiser's geometry) measurements of the same build as sub-records (`h2`, `h3`), the copy ceiling measured in the same run
+(`roofline.peak_achievable`) and, with --e2e 1 (default), the end-to-end wall-clock of the MidV3 loop at the Adirondack-H shape
+(`e2e`: one view and two views + post-processing; north_star's third target).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-HBM_ACHIEVABLE_GBS = 6290.0  # measured float4-copy ceiling of the same guide (79 % of peak)
+HBM_ACHIEVABLE_GUIDE_GBS = 6290.0  # float4-copy ceiling quoted by the guide (79 % of peak); the run measures its own, see copy_ceiling()
 
 
 def kernel_source_hash():
@@ -51,7 +54,8 @@ def main():
     ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3"])
     ap.add_argument("--height", type=int, default=0, help="default: 1000 at N = 1 (configs[2]), 2000 at N > 1 (configs[4])")
     ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 512 / N at N > 1")
+    ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 64 at N > 1")
+    ap.add_argument("--e2e", type=int, default=1, help="1: add the end-to-end sub-record (N = 1, ~15 s); 0: skip it")
     ap.add_argument("--sub-steps", type=int, default=20, help="steps of the H2 / H3 sub-records at N = 1 (0: skip them)")
     ap.add_argument("--cpu-planes", type=int, default=-1, help="planes of the CPU-baseline sample (-1: auto, 0: skip)")
     args = ap.parse_args()
@@ -85,7 +89,7 @@ def main():
     multi = world > 1
     H = args.height or (2000 if multi else 1000)
     W = args.width or (3000 if multi else 1500)
-    D = args.ndisp or (max(1, 512 // world) if multi else 256)       # slices of this rank
+    D = args.ndisp or (64 if multi else 256)                         # slices of this rank
     P = H * W
     # ---- synthetic inputs (seeded); the volume shard is generated directly in HBM
     guide = synth.make_guide(H, W, 1234)
@@ -168,6 +172,26 @@ def main():
             dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
         return float(elapsed.item()), float(kern_ms.item())
 
+    def copy_ceiling():
+        """GB/s (read + written) of a 16-byte-per-lane device copy of 2 x 1 GiB, best of 5 launches after a warm-up: the streaming
+        ceiling of THIS box, measured in this run."""
+        n = 1 << 28
+        a = torch.empty(n, device=dev, dtype=torch.float32).normal_()
+        b = torch.empty(n, device=dev, dtype=torch.float32)
+        best = 0.0
+        for it in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = e.L.les_hip_calib_copy_wide(a.data_ptr(), b.data_ptr(), n, dev_index, stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            if rc != 0:
+                return None
+            if it > 0:
+                best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        return best
+
     step, evals_rank, bytes_per_eval, batch, desc, planes = make_workload(args.workload)
     elapsed, kern_ms = measure(step, args.steps, args.warmup)
     kind = batch.kernel_kind(0)
@@ -178,6 +202,7 @@ def main():
     value = evals_per_step * args.steps / elapsed / 1e6
     alg_bytes = evals_rank * bytes_per_eval + float(P) * 48.0        # per step and rank (H1 / H2: one launch)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    ceiling = copy_ceiling()
 
     # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate passes,
     # tools/collect_profiles.sh): cannot be collected live inside this process, so the committed measurement is quoted --
@@ -201,12 +226,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if multi else "weak",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "i32/i64 fixed-point box sums (exact), f32 3x3 algebra, f64 final combine" if kind == 1 else "f64 sums / f32 algebra",
         "data": "synthetic",
         "config": {
-            "workload": desc + (f"; BASELINE configs[4]: 3000x2000x512 split into {D} slices per rank" if multi else "; BASELINE configs[2]"),
+            "workload": desc + (f"; the per-rank shard of BASELINE configs[4] ({D} slices of {W}x{H} per rank, {D * world} in total)" if multi else "; BASELINE configs[2]"),
             "evals_per_step_per_gpu": int(evals_rank),
             "sharding": "hypotheses (disparity slices) split across ranks, no data-path collective",
             "workgroups_per_launch": batch.num_jobs,
@@ -217,8 +242,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "peak_achievable": HBM_ACHIEVABLE_GBS,       # float4-copy ceiling measured on MI355X (MI355X_MICROARCH.md)
-            "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
+            "peak_achievable": round(ceiling, 1) if ceiling else None,       # 16-byte-per-lane copy measured in THIS run (les_hip_calib_copy_wide)
+            "frac_of_achievable": round(achieved / ceiling, 5) if ceiling else None,
+            "peak_achievable_guide": HBM_ACHIEVABLE_GUIDE_GBS,
             "traffic": traffic,
             "kernel": kernel_name,
             "kernel_ms": round(kern_ms, 4),
@@ -246,6 +272,49 @@ def main():
             }
         step()                        # the H1 result buffer is compared with the oracle below
         torch.cuda.synchronize(dev)
+        saved = out[: min(D, 256)].clone() if args.cpu_planes != 0 else None
+
+        # ---- the per-rank shape of the N > 1 runs (64 slices of 3000 x 2000) on this one GPU: baseline of a future scaling curve
+        try:
+            H8, W8, D8 = 2000, 3000, 64
+            del batch
+            vol8 = torch.rand((D8, H8, W8), device=dev, dtype=torch.float32, generator=gen)
+            e8 = api.HipCostVolumeEnergy(synth.make_guide(H8, W8, 1234), None, vol8.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D8 - 1,
+                                         device=dev_index, volumes_on_device=True, shape=(D8, H8, W8))
+            e8.set_stream(stream.cuda_stream)
+            out8 = out.view(-1)[: D8 * H8 * W8].view(D8, H8, W8)          # same byte count as the headline output
+            pl8 = torch.from_numpy(synth.fronto_planes(D8)).to(dev)
+            b8 = api.Batch(e8, [(0, 0, W8, H8)] * D8, [(0, 0, W8, H8)] * D8, out_slabs=True)
+            el8, km8 = measure(lambda: b8.run(pl8.data_ptr(), out8.data_ptr(), mode=0, check=False, planes_on_device=True), args.sub_steps, 2)
+            ev8 = float(H8) * W8 * D8
+            result["n8_rank_shape"] = {
+                "workload": f"H1 on the shard one rank holds at N = 8: {D8} fronto-parallel planes x {W8}x{H8} (configs[4] / 8)",
+                "ms_per_step": round(el8 / args.sub_steps * 1e3, 4), "value": round(ev8 * args.sub_steps / el8 / 1e6, 2), "unit": "Mcost-evals/s",
+                "steps": args.sub_steps, "kernel": "march" if b8.kernel_kind(0) == 1 else "strip", "workgroups_per_launch": b8.num_jobs,
+                "algorithmic_GBps": round((ev8 * 8.0 + float(H8) * W8 * 48.0) / (km8 * 1e-3) / 1e9, 2),
+            }
+            del b8, e8, vol8
+        except Exception as ex:                      # never lose the headline line to a sub-record
+            result["n8_rank_shape"] = {"error": repr(ex)}
+        if saved is not None:
+            out[: saved.shape[0]].copy_(saved)
+            del saved
+
+        # ---- end to end (north_star: Adirondack-H wall-clock < 10 s): the MidV3 loop of tools/e2e_bench.py on a synthetic pair
+        if args.e2e:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import e2e_bench
+                rec = {}
+                for dual in (0, 1):
+                    r = e2e_bench.run(dual=dual, quiet=True)
+                    rec["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
+                from localexpstereo_amd.gc import cpu_budget
+                rec["host_cpus"] = cpu_budget()
+                rec["note"] = "synthetic pair at the Adirondack-H shape (the data set is not in the container); MidV3 defaults: layers 14/43/129, 2 PatchMatch + 5 graph-cut iterations"
+                result["e2e"] = rec
+            except Exception as ex:
+                result["e2e"] = {"error": repr(ex)}
 
     # ---- CPU baseline: the oracle (CPU restatement, double guided filter like the reference default),
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.

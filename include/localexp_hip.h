@@ -74,7 +74,12 @@ const char* les_hip_last_error(void);                   /* thread-local descript
 int les_hip_set_stream(les_hip_ctx* ctx, void* hip_stream);
 /* bind != 0: from now on the launches the CALLING host thread makes on this context (and its les_hip_synchronize) go to
  * hip_stream instead; bind == 0: back to the context's stream.  For callers that advance the two views of one context from two
- * host threads (doDual: the views are independent until the post-processing, LES/FastGCStereo.h:172-185). */
+ * host threads (doDual: the views are independent until the post-processing, LES/FastGCStereo.h:172-185).
+ * What two threads with their own streams may call concurrently on ONE context: everything that works on caller-owned or
+ * batch-owned device memory -- les_hip_batch_run / _propose / _wta / _expansion_graph / _solve_graphs / _apply_masks with
+ * planes_on_device != 0 and distinct batches, les_hip_unary_one[_scratch] (per-thread / per-scratch buffers), les_hip_synchronize.
+ * NOT safe under per-thread streams, because they stage through one context-owned buffer: les_hip_batch_run with planes_on_device
+ * == 0, les_hip_unary_batch and les_hip_wta_update -- serialise those in the caller (host/HipCostVolumeEnergy.h holds a mutex). */
 int les_hip_set_thread_stream(les_hip_ctx* ctx, void* hip_stream, int bind);
 int les_hip_synchronize(les_hip_ctx* ctx);
 
@@ -202,6 +207,9 @@ int les_hip_post_process(les_hip_ctx* ctx, les_hip_plane* d_labelsL, les_hip_pla
 /* diagnostics: dword-per-lane streaming copy of n floats (device pointers), the known-byte-count pattern used to
  * calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for this library's access width (profiles/). */
 int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, void* stream);
+/* the same with 16 bytes per lane (n a multiple of 4, 16-byte aligned pointers): the streaming-copy ceiling that bench.py measures
+ * in its own run and reports as roofline.peak_achievable. */
+int les_hip_calib_copy_wide(const float* d_src, float* d_dst, size_t n, int device, void* stream);
 
 /* Device memory helpers for callers without a HIP toolchain (host C++ adapter, ctypes). */
 int les_hip_malloc(les_hip_ctx* ctx, void** dev_ptr, size_t bytes);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
-    "les_hip_calib_copy", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
+    "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
 ]
 
 
@@ -44,9 +44,18 @@ _libs = {}
 
 def load(path=None):
     """Load the C-ABI library (default: the in-tree HIP build).  Raises if it does not exist."""
+    from_env = path is None and bool(os.environ.get("LES_HIP_LIB"))
     path = os.path.abspath(path or os.environ.get("LES_HIP_LIB") or DEFAULT_LIB)     # LES_HIP_LIB: A/B builds of the same ABI
     if path in _libs:
         return _libs[path]
+    # LES_HIP_LIB is a measurement switch between HIP builds.  Anything without a gfx950 code object (the CPU simulator build the
+    # tests use, or a stranger's library with the same symbols) is refused, so that an environment variable can never put a
+    # CPU path under the package; tests that exercise the simulator pass its path explicitly (or set LES_HIP_ALLOW_SIM=1).
+    if from_env and os.path.exists(path) and os.environ.get("LES_HIP_ALLOW_SIM") != "1":
+        blob = open(path, "rb").read()
+        if b"gfx950" not in blob or b"les_march_kernel" not in blob:
+            raise LesHipError(f"LES_HIP_LIB={path} holds no gfx950 code object of this package's kernels; refusing to load it "
+                              "(set LES_HIP_ALLOW_SIM=1 only in tests of the simulator build)")
     # PyTorch-ROCm bundles its own HIP runtime.  If this library initialises the system runtime first and torch
     # initialises CUDA/HIP later in the same process, torch reports "No HIP GPUs are available".  Loading torch's
     # runtime first makes both share one copy (bench.py / pm.py use torch tensors for device memory anyway).
@@ -71,6 +80,7 @@ def load(path=None):
         "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
+        "les_hip_calib_copy_wide": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
         "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
         "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),

@@ -13,6 +13,8 @@
 #include "les_maxflow.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <mutex>
 #include <cstdarg>
 #include <cstdio>
@@ -153,6 +155,9 @@ struct les_hip_ctx {
     // smoothness-coefficient table of the pairwise terms, cached per (omega, epsilon)
     float* d_pw_tab = nullptr; float pw_omega = -1.f, pw_epsilon = -1.f;
     std::mutex mu;                       // guards the lazily built tables when two host threads (the two views) share the context
+    unsigned long long gen = 0;          // unique id of this context: thread-local bindings compare it, not the address (an address can be reused)
+    std::vector<les_hip_scratch*> idle_scratch;  // hidden scratches whose owning thread has exited, ready for the next new thread
+    bool maxflow_lds_ready = false;      // the per-device dynamic-LDS opt-in of les_maxflow_kernel has been made on this context's device
     std::vector<les_hip_scratch*> own_scratch;   // scratch objects created behind les_hip_unary_one (one per calling thread), freed with the context
 };
 
@@ -197,9 +202,25 @@ namespace {
 
 // The stream the calling thread's launches go to: the context's stream, unless this host thread has bound its own for this
 // context (les_hip_set_thread_stream: two views advanced by two host threads on one context, each on its own stream).
-thread_local const les_hip_ctx* tl_stream_ctx = nullptr;
+std::atomic<unsigned long long> g_ctx_gen{0};
+// live contexts by generation id (the thread-exit hook of les_hip_unary_one returns a hidden scratch to its context only if that
+// very context -- not a later one at the same address -- still exists)
+std::mutex g_live_mu;
+std::vector<std::pair<unsigned long long, les_hip_ctx*>> g_live;
+void release_hidden_scratch(unsigned long long gen, les_hip_scratch* s)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (auto& e : g_live)
+        if (e.first == gen) {
+            std::lock_guard<std::mutex> lk2(e.second->mu);
+            e.second->idle_scratch.push_back(s);         // still owned (and eventually freed) by the context
+            return;
+        }
+    // the context is gone: it has already destroyed the scratch
+}
+thread_local unsigned long long tl_stream_gen = 0;       // generation id of the context the stream below is bound to (0: none)
 thread_local hipStream_t tl_stream = nullptr;
-inline hipStream_t cur_stream(const les_hip_ctx* c) { return (tl_stream_ctx == c) ? tl_stream : c->stream; }
+inline hipStream_t cur_stream(const les_hip_ctx* c) { return (tl_stream_gen != 0 && tl_stream_gen == c->gen) ? tl_stream : c->stream; }
 
 int check_rects(const les_hip_ctx* c, const les_hip_rect& f, const les_hip_rect& t)
 {
@@ -524,6 +545,8 @@ static int create_common(les_hip_ctx** out, const les_hip_params* params, const 
     if (p.device < 0 || p.device >= ndev) return fail(LES_HIP_ERR_ARG, "device %d out of range (%d devices)", p.device, ndev);
     HIPCHECK(hipSetDevice(p.device));
     les_hip_ctx* c = new les_hip_ctx();
+    c->gen = ++g_ctx_gen;
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.emplace_back(c->gen, c); }
     c->p = p;
     c->R = p.windR / 2;
     c->strip = strip;
@@ -574,6 +597,11 @@ void les_hip_destroy(les_hip_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
+    if (tl_stream_gen == c->gen) { tl_stream_gen = 0; tl_stream = nullptr; }     // the destroying thread's own binding (other threads' bindings die with the id)
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove_if(g_live.begin(), g_live.end(), [c](const std::pair<unsigned long long, les_hip_ctx*>& e) { return e.second == c; }), g_live.end());
+    }
     for (int m = 0; m < 2; m++) {
         if (c->v[m].own_vol && c->v[m].vol) (void)hipFree(c->v[m].vol);
         if (c->v[m].stats) (void)hipFree(c->v[m].stats);
@@ -603,8 +631,8 @@ int les_hip_set_stream(les_hip_ctx* c, void* s)
 int les_hip_set_thread_stream(les_hip_ctx* c, void* s, int bind)
 {
     if (!c) return fail(LES_HIP_ERR_ARG, "null context");
-    if (bind) { tl_stream_ctx = c; tl_stream = (hipStream_t)s; }
-    else if (tl_stream_ctx == c) { tl_stream_ctx = nullptr; tl_stream = nullptr; }
+    if (bind) { tl_stream_gen = c->gen; tl_stream = (hipStream_t)s; }
+    else if (tl_stream_gen == c->gen) { tl_stream_gen = 0; tl_stream = nullptr; }
     return LES_HIP_OK;
 }
 
@@ -846,16 +874,23 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     const int np = (int)((std::max<long long>(maxn, 1) + 7) / 8) * 8;
     const size_t lds = les::mf_lds_bytes(np);
 #if !defined(LES_SIM)
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)les::mf_lds_bytes(les::kMfMaxNodes));
-        if (attr_rc == hipSuccess)
-            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // The opt-in to more than 64 KB of dynamic LDS is a per-DEVICE function attribute: it is set once per context (a context is bound
+    // to one device), under the context's mutex, with that device current -- a process-wide flag would leave the second GPU of a
+    // process that drives two without it.  A failure is reported with its own message so that callers can cut on the host instead.
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->maxflow_lds_ready) {
+            HIPCHECK(hipSetDevice(c->p.device));
+            hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)les::mf_lds_bytes(les::kMfMaxNodes));
+            if (arc == hipSuccess)
+                arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)les::mf_lds_bytes(les::kMfMaxNodes));
-    });
-    if (attr_rc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(attr_rc));
+            if (arc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs: device max-flow unavailable on device %d (hipFuncSetAttribute max dynamic LDS: %s); cut on the host",
+                                               c->p.device, hipGetErrorString(arc));
+            c->maxflow_lds_ready = true;
+        }
+    }
 #endif
     const les::GraphCellMf* cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
     int max_iter = les::kMfMaxIter;
@@ -1030,22 +1065,28 @@ int les_hip_unary_one(les_hip_ctx* c, int mode, const les_hip_rect* fr, const le
                       float* costs, int row_stride, int check)
 {
     if (!c || !fr || !tr || !plane || !costs) return fail(LES_HIP_ERR_ARG, "null argument");
-    // one scratch per (calling thread, context), created on the thread's first call and owned by the context
-    thread_local std::vector<std::pair<les_hip_ctx*, les_hip_scratch*>> mine;
+    // One scratch per (calling thread, context), created on the thread's first call and owned by the context.  The thread-local entry
+    // is keyed by the context's generation id (never by its address); when the thread exits, its scratches go back to their contexts'
+    // idle lists -- if those contexts are still alive -- so short-lived caller threads recycle a bounded set instead of piling up.
+    struct Mine {
+        std::vector<std::pair<unsigned long long, les_hip_scratch*>> v;
+        ~Mine() { for (auto& e : v) release_hidden_scratch(e.first, e.second); }
+    };
+    thread_local Mine mine;
     les_hip_scratch* s = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);            // (the context may have been destroyed and its address reused: its registry is the truth)
-        for (auto it = mine.begin(); it != mine.end();) {
-            if (it->first == c && std::find(c->own_scratch.begin(), c->own_scratch.end(), it->second) != c->own_scratch.end()) { s = it->second; break; }
-            if (it->first == c) it = mine.erase(it); else ++it;
-        }
-    }
+    for (auto& e : mine.v) if (e.first == c->gen) { s = e.second; break; }
     if (!s) {
-        int rc = les_hip_scratch_create(c, &s);
-        if (rc) return rc;
-        std::lock_guard<std::mutex> lk(c->mu);
-        c->own_scratch.push_back(s);
-        mine.emplace_back(c, s);
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!c->idle_scratch.empty()) { s = c->idle_scratch.back(); c->idle_scratch.pop_back(); }
+        }
+        if (!s) {
+            int rc = les_hip_scratch_create(c, &s);
+            if (rc) return rc;
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->own_scratch.push_back(s);
+        }
+        mine.v.emplace_back(c->gen, s);
     }
     return les_hip_unary_one_scratch(c, s, mode, fr, tr, plane, costs, row_stride, check);
 }
@@ -1226,6 +1267,17 @@ int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, v
     if (!d_src || !d_dst || n == 0) return fail(LES_HIP_ERR_ARG, "bad argument");
     HIPCHECK(hipSetDevice(device));
     hipLaunchKernelGGL(les::les_calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, n);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_calib_copy_wide(const float* d_src, float* d_dst, size_t n, int device, void* stream)
+{
+    if (!d_src || !d_dst || n == 0 || (n & 3) || (((uintptr_t)d_src | (uintptr_t)d_dst) & 15)) return fail(LES_HIP_ERR_ARG, "bad argument (n must be a multiple of 4, pointers 16-byte aligned)");
+    HIPCHECK(hipSetDevice(device));
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(les::les_calib_copy_wide_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(d_src), reinterpret_cast<float4*>(d_dst), n4);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }

@@ -695,6 +695,18 @@ __global__ void les_calib_copy_kernel(const float* __restrict__ src, float* __re
     if (i < n) dst[i] = src[i];
 }
 
+// 16 bytes per lane, four chunks per thread: the streaming-copy ceiling of the chip for this process (bench.py quotes the rate
+// it measures in the same run as roofline.peak_achievable)
+__global__ void les_calib_copy_wide_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
+{
+    const size_t i = ((size_t)blockIdx.x * 4) * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t j = i + (size_t)k * blockDim.x;
+        if (j < n4) dst[j] = src[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Volume preparation ("next" row N3): LES/main.cpp:146-176 fillOutOfView and :178-199 convertVolumeL2R with
 // margin = 0 (interp_margin, LES/main.cpp:359).  grid = (ceil(W/256), H, D).

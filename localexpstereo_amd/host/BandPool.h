@@ -7,9 +7,12 @@
 // on the caller, and returns when all are done.  Helpers spin briefly for the next phase of the same cut before they sleep.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -17,8 +20,37 @@
 
 namespace les_host {
 
+// CPUs this process may keep busy: the hardware threads, capped by a cgroup CPU-time quota (cpu.max "quota period"; the MI355X boxes show
+// 256 hardware threads and grant 16 CPUs of time).  Read once.
+inline int cpuBudget()
+{
+    static const int budget = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw <= 0) hw = 1;
+        long long quota = -1, period = -1;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+        }
+        if (quota > 0 && period > 0) hw = (int)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+        return hw;
+    }();
+    return budget;
+}
+
 class BandPool {
 public:
+    // How long idle helpers spin for the next phase before they sleep.  A lock-step whose cells x bands exceed the CPU budget sets it
+    // low (spinning helpers would burn the quota the working threads need); the band COUNT never depends on the machine.
+    static std::atomic<int>& spinLimit()
+    {
+        static std::atomic<int> limit{20000};
+        return limit;
+    }
     static BandPool& mine()
     {
         static thread_local BandPool pool;
@@ -78,7 +110,8 @@ private:
         for (;;) {
             // wait for the next generation: spin for the back-to-back phases of one cut, then sleep
             bool fresh = false;
-            for (int spin = 0; spin < 20000; spin++) {
+            const int limit = spinLimit().load(std::memory_order_relaxed);
+            for (int spin = 0; spin < limit; spin++) {
                 if (gen_.load(std::memory_order_acquire) != seen) { fresh = true; break; }
                 cpu_relax();
             }

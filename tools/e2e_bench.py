@@ -27,6 +27,27 @@ sys.path.insert(0, ROOT)
 from localexpstereo_amd.synth import make_scene, ad_volume      # noqa: E402
 
 
+def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0, smooth_weight=0.5, host_threads=0, quiet=False):
+    """One end-to-end run; returns the record `main` prints."""
+    import torch  # noqa: F401
+    from localexpstereo_amd import stereo
+    dev = "cuda"
+    H, W, D = height, width, ndisp
+    t0 = time.perf_counter()
+    imL, imR, gt = make_scene(H, W, D)
+    volL = ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
+    t_scene = time.perf_counter() - t0
+    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    t1 = time.perf_counter()
+    st, lab, raw = stereo.MidV3(data, volL, None, iterations=iterations, pmIterations=pm_iterations, doDual=bool(dual),
+                                smooth_weight=smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=host_threads)
+    t_total = time.perf_counter() - t1
+    rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
+    return dict(shape=[W, H, D], iterations=iterations, pm_iterations=pm_iterations, dual=bool(dual), host_cores=os.cpu_count(),
+                seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
+                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, log=rows)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1436)
@@ -38,25 +59,7 @@ def main():
     ap.add_argument("--smooth-weight", type=float, default=0.5)
     ap.add_argument("--host-threads", type=int, default=0)
     args = ap.parse_args()
-    import torch
-    from localexpstereo_amd import io as lio
-    from localexpstereo_amd import stereo
-    dev = "cuda"
-    H, W, D = args.height, args.width, args.ndisp
-    t0 = time.perf_counter()
-    imL, imR, gt = make_scene(H, W, D)
-    volL = ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
-    t_scene = time.perf_counter() - t0
-    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
-    t1 = time.perf_counter()
-    st, lab, raw = stereo.MidV3(data, volL, None, iterations=args.iterations, pmIterations=args.pm_iterations, doDual=bool(args.dual),
-                                smooth_weight=args.smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=args.host_threads)
-    t_total = time.perf_counter() - t1
-    rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
-    out = dict(shape=[W, H, D], iterations=args.iterations, pm_iterations=args.pm_iterations, dual=bool(args.dual), host_cores=os.cpu_count(),
-               seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
-               gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, log=rows)
-    print(json.dumps(out))
+    print(json.dumps(run(args.width, args.height, args.ndisp, args.iterations, args.pm_iterations, args.dual, args.smooth_weight, args.host_threads)))
 
 
 if __name__ == "__main__":
