@@ -29,7 +29,7 @@ namespace les {
 // kernel is a chain of dependent LDS accesses between barriers and lives on latency hiding (measured: 256 threads and one
 // workgroup per CU took 8.6 ms for a lock-step of 450 cells that the host team cuts in 6.1 ms)
 constexpr int kMfThreads = 512;
-// nodes per thread: a template parameter (4 for cells of up to 2048 nodes -- no register spills at 128 VGPRs --, 5 up to the limit)
+// nodes per thread: a template parameter (4 for cells of up to 2048 nodes, 5 up to the limit; neither spills at 128 VGPRs)
 constexpr int kMfMaxNodes = 2304;
 static_assert(kMfThreads * 5 >= kMfMaxNodes, "every node needs an owner");
 #ifndef LES_MF_G
@@ -195,31 +195,41 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         for (int kp = 0; kp < 8; kp += 2) {
             const int dxa = mf_dx(kp), dya = mf_dy(kp), dxb = mf_dx(kp + 1), dyb = mf_dy(kp + 1);
             const int offa = dya * W + dxa, offb = dyb * W + dxb;
-            float ev[kMfNodesPerThread], ra[kMfNodesPerThread], rb[kMfNodesPerThread];
-            int hv[kMfNodesPerThread], ha[kMfNodesPerThread], hb[kMfNodesPerThread];
+            // (a lane only writes words of its own nodes in this half and reads no word another lane writes in it, so the own nodes are
+            // handled in batches of JB: with five nodes per thread all six operands of all of them do not fit 128 VGPRs)
+            constexpr int JB = kMfNodesPerThread > 4 ? 3 : kMfNodesPerThread;
 #pragma unroll
-            for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
-                const bool in = v < N;
-                const int vs = in ? v : 0;
-                ev[j] = ex[vs]; ra[j] = r[kp * NP + vs]; rb[j] = r[(kp + 1) * NP + vs]; hv[j] = (int)hgt[vs];
-                // the neighbour exists whenever the arc has capacity; otherwise read a harmless in-range word
-                const int ax = vx[j] + dxa, ay = vy[j] + dya, bx = vx[j] + dxb, by = vy[j] + dyb;
-                ha[j] = (int)hgt[(in && ax >= 0 && ax < W && ay >= 0 && ay < H) ? vs + offa : vs];
-                hb[j] = (int)hgt[(in && bx >= 0 && bx < W && by >= 0 && by < H) ? vs + offb : vs];
-            }
+            for (int j0 = 0; j0 < kMfNodesPerThread; j0 += JB) {
+                float ev[JB], ra[JB], rb[JB];
+                int hv[JB], ha[JB], hb[JB];
 #pragma unroll
-            for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
-                if (v >= N) continue;
-                float e0 = ev[j], da = 0.0f, db = 0.0f;
-                if (e0 > 0.0f && hv[j] < BIG) {
-                    if (ra[j] > 0.0f && hv[j] == ha[j] + 1) { da = e0 < ra[j] ? e0 : ra[j]; e0 -= da; r[kp * NP + v] = ra[j] - da; }
-                    if (e0 > 0.0f && rb[j] > 0.0f && hv[j] == hb[j] + 1) { db = e0 < rb[j] ? e0 : rb[j]; e0 -= db; r[(kp + 1) * NP + v] = rb[j] - db; }
-                    if (da > 0.0f || db > 0.0f) ex[v] = e0;
+                for (int jj = 0; jj < JB; jj++) {
+                    const int j = j0 + jj;
+                    if (j >= kMfNodesPerThread) continue;
+                    const int v = tid + j * kMfThreads;
+                    const bool in = v < N;
+                    const int vs = in ? v : 0;
+                    ev[jj] = ex[vs]; ra[jj] = r[kp * NP + vs]; rb[jj] = r[(kp + 1) * NP + vs]; hv[jj] = (int)hgt[vs];
+                    // the neighbour exists whenever the arc has capacity; otherwise read a harmless in-range word
+                    const int ax = vx[j] + dxa, ay = vy[j] + dya, bx = vx[j] + dxb, by = vy[j] + dyb;
+                    ha[jj] = (int)hgt[(in && ax >= 0 && ax < W && ay >= 0 && ay < H) ? vs + offa : vs];
+                    hb[jj] = (int)hgt[(in && bx >= 0 && bx < W && by >= 0 && by < H) ? vs + offb : vs];
                 }
-                sentA[v] = da;
-                sentB[v] = db;
+#pragma unroll
+                for (int jj = 0; jj < JB; jj++) {
+                    const int j = j0 + jj;
+                    if (j >= kMfNodesPerThread) continue;
+                    const int v = tid + j * kMfThreads;
+                    if (v >= N) continue;
+                    float e0 = ev[jj], da = 0.0f, db = 0.0f;
+                    if (e0 > 0.0f && hv[jj] < BIG) {
+                        if (ra[jj] > 0.0f && hv[jj] == ha[jj] + 1) { da = e0 < ra[jj] ? e0 : ra[jj]; e0 -= da; r[kp * NP + v] = ra[jj] - da; }
+                        if (e0 > 0.0f && rb[jj] > 0.0f && hv[jj] == hb[jj] + 1) { db = e0 < rb[jj] ? e0 : rb[jj]; e0 -= db; r[(kp + 1) * NP + v] = rb[jj] - db; }
+                        if (da > 0.0f || db > 0.0f) ex[v] = e0;
+                    }
+                    sentA[v] = da;
+                    sentB[v] = db;
+                }
             }
             __syncthreads();
             if (kp == 0 && tid == 0) flag[0] = 0;                            // (every lane has read the flag at the loop head)

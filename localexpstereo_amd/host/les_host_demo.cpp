@@ -9,6 +9,7 @@
 //                                              ground truth (needs an MI355X)
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 
@@ -228,6 +229,40 @@ static int cmd_run(int argc, char** argv)
     return fail;
 }
 
+// The MidV3 loop (LES/main.cpp:330-420) driven by the C++ host at full size: layers of 1 % / 3 % / 9 % of the width with the reference's
+// proposer table, pmInit PatchMatch iterations, then `iters` graph-cut iterations with device-built graphs, the finest layer cut on
+// the GPU and the rest on the host cores.  Prints the wall-clock split; the C++ counterpart of tools/e2e_bench.py.
+static int cmd_full(int argc, char** argv)
+{
+    const int W = argc > 2 ? atoi(argv[2]) : 1436, H = argc > 3 ? atoi(argv[3]) : 992, D = argc > 4 ? atoi(argv[4]) : 256;
+    const int iters = argc > 5 ? atoi(argv[5]) : 5, pm = argc > 6 ? atoi(argv[6]) : 2;
+    const auto t0 = std::chrono::steady_clock::now();
+    Scene s = make_scene(W, H, D);
+    const double t_scene = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    Parameters param(1.0f, 20, "GF", 1e-4f);
+    param.th_col = 0.5f;
+    const float maxdisp = (float)D - 1;
+    const auto t1 = std::chrono::steady_clock::now();
+    auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
+    st->setSeed(7);
+    st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp));
+    const double t_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    st->addLayer(std::max(2, int(W * 0.01)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});   // LES/main.cpp:391-397
+    st->addLayer(std::max(4, int(W * 0.03)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    st->addLayer(std::max(8, int(W * 0.09)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    double sec = 0;
+    if (!st->runDevice(pm, {0}, &sec, iters)) { printf("FAIL: runDevice\n"); return 1; }
+    const double bad = bad_pixels(st->computeDisparities(0), s, 1.0f), e = st->totalEnergy(0);
+    printf("full %dx%dx%d  pm %d + gc %d: optimiser %.3f s  (context + upload %.3f s, scene %.2f s)  E=%.1f  bad1.0=%.2f%%\n", W, H, D, pm, iters, sec, t_ctx, t_scene, e, bad);
+    printf("full graph-cut lock-steps: %ld   GPU propose+unary+graphs+device cuts %.3f s   host cuts %.3f s   H2D labels %.3f s   cells cut on the GPU %ld\n",
+           st->gcLockSteps, st->gcSeconds[0], st->gcSeconds[1], st->gcSeconds[2], st->gcCellsCutOnDevice);
+    int fail = 0;
+    if (st->gcCellsCutOnDevice == 0 && iters > 0) { printf("FAIL: no cell was cut on the device\n"); fail = 1; }
+    if (bad > 10.0) { printf("FAIL: did not converge\n"); fail = 1; }
+    printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
+    return fail;
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "layers")) return cmd_layers(argc, argv);
@@ -240,6 +275,14 @@ int main(int argc, char** argv)
             return 3;
         }
     }
-    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters]\n");
+    if (argc >= 2 && !strcmp(argv[1], "full")) {
+        try {
+            return cmd_full(argc, argv);
+        } catch (const std::exception& e) {
+            printf("les_host_demo: %s\n", e.what());
+            return 3;
+        }
+    }
+    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters] | full [W H D iters pmInit]\n");
     return 2;
 }

@@ -931,6 +931,172 @@ def case_device_maxflow_edge_cells(pr, seed=3):
         b2.destroy()
 
 
+def _grid_graph_reference(pay, w, h):
+    """Independent min cut of one device-format cell (5 floats per node: terminal residual, caps E, S, SW, SE) with networkx:
+    -> (max-flow value through the arcs, canonical SOURCE mask = nodes that can NOT reach the sink in the residual graph, which is the
+    unique minimum cut with the smallest sink side: the rule of the reference's solver with SOURCE as the default, LES/FastGCStereo.h:557)."""
+    import networkx as nx
+    q = pay.reshape(h, w, 5).astype(np.float64)
+    G = nx.DiGraph()
+    G.add_nodes_from(["s", "t"])
+    G.add_nodes_from(range(w * h))
+    for y in range(h):
+        for x in range(w):
+            i = y * w + x
+            tr = q[y, x, 0]
+            if tr > 0:
+                G.add_edge("s", i, capacity=tr)
+            elif tr < 0:
+                G.add_edge(i, "t", capacity=-tr)
+            for k, (dx, dy) in enumerate(((1, 0), (0, 1), (-1, 1), (1, 1))):
+                c = q[y, x, 1 + k]
+                xx, yy = x + dx, y + dy
+                if c > 0 and 0 <= xx < w and 0 <= yy < h:
+                    G.add_edge(i, yy * w + xx, capacity=c)
+    R = nx.algorithms.flow.preflow_push(G, "s", "t")
+    value = R.graph["flow_value"]
+    # nodes that reach t through arcs with residual capacity
+    reach, stack = {"t"}, ["t"]
+    while stack:
+        v = stack.pop()
+        for u in R.predecessors(v):
+            if u not in reach and R[u][v]["capacity"] - R[u][v]["flow"] > 0:
+                reach.add(u)
+                stack.append(u)
+    src = np.array([i not in reach for i in range(w * h)], bool)
+    return value, src
+
+
+def _cut_capacity(pay, w, h, src):
+    """capacity of the s/t cut whose SOURCE side is `src` (bool per node), arcs + terminals, in double"""
+    q = pay.reshape(h, w, 5).astype(np.float64)
+    m = src.reshape(h, w)
+    tr = q[..., 0]
+    cap = np.where(m, np.maximum(-tr, 0), np.maximum(tr, 0)).sum()           # SOURCE nodes pay their sink link, SINK nodes their source link
+    for k, (dx, dy) in enumerate(((1, 0), (0, 1), (-1, 1), (1, 1))):
+        c = q[..., 1 + k]
+        ys, xs = np.nonzero(c > 0)
+        yy, xx = ys + dy, xs + dx
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        ys, xs, yy, xx = ys[ok], xs[ok], yy[ok], xx[ok]
+        cap += (c[ys, xs] * (m[ys, xs] & ~m[yy, xx])).sum()
+    return float(cap)
+
+
+def _random_cell_payloads(rng, shapes, dyadic):
+    """device-format payloads of random cells; dyadic: every capacity is a multiple of 2^-10 below 4, so that every flow and residual is
+    exact in float32 and in double alike and the cut is unique up to genuine ties"""
+    pays = []
+    for (w, h) in shapes:
+        n = w * h
+        p = np.zeros((n, 5), np.float32)
+        p[:, 0] = rng.normal(0, 0.8, n)
+        p[:, 1:] = rng.uniform(0, 0.6, (n, 4)) * (rng.uniform(0, 1, (n, 4)) < 0.8)
+        if dyadic:
+            p = (np.round(p * 1024.0) / 1024.0).astype(np.float32)
+        q = p.reshape(h, w, 5)
+        q[:, -1, 1] = 0; q[-1, :, 2] = 0; q[-1, :, 3] = 0; q[:, 0, 3] = 0; q[-1, :, 4] = 0; q[:, -1, 4] = 0
+        pays.append(p)
+    return pays
+
+
+def _solve_cells_on_device(pr, shapes, pays):
+    H, W = pr.H, pr.W
+    rects, x, y, rowh = [], 0, 0, 0
+    for (w, h) in shapes:
+        if x + w > W:
+            x, y, rowh = 0, y + rowh, 0
+        assert y + h <= H, "cells do not fit the image"
+        rects.append((x, y, w, h))
+        x += w
+        rowh = max(rowh, h)
+    trs = api._rects(np.array(rects, np.int32))
+    batch = api.Batch(pr.e, trs, trs)
+    off, nn, k = batch.graph_offsets(), batch.graph_nodes(), len(rects)
+    pay = np.zeros((nn, 5), np.float32)
+    for i, p in enumerate(pays):
+        pay[off[i]: off[i] + len(p)] = p
+    pay = np.ascontiguousarray(pay.reshape(-1))
+    dp, dm, ds, df = api.DeviceBuffer(pr.e, nn * 20), api.DeviceBuffer(pr.e, nn), api.DeviceBuffer(pr.e, 4 * k), api.DeviceBuffer(pr.e, 8 * k)
+    dp.upload(pay)
+    batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
+    pr.e.synchronize()
+    status = ds.download((k,), np.int32)
+    masks, flows = dm.download((nn,), np.uint8), df.download((k,), np.float64)
+    for b_ in (dp, dm, ds, df):
+        b_.free()
+    batch.destroy()
+    return off, status, masks, flows
+
+
+def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45):
+    """les_maxflow_kernel against an INDEPENDENT checker (networkx preflow-push + residual reachability), not against the host solver:
+      * dyadic capacities (arithmetic exact in float and double): the device mask equals the canonical minimum cut node for node and the
+        flow is equal;
+      * arbitrary float32 capacities: the flow agrees to 1e-6 relative, the device mask is a minimum cut (its capacity equals the
+        max-flow value to 1e-6), and every node where it differs from the canonical cut is a tie (moving those nodes changes the cut
+        capacity by < 1e-6 of it).
+    -> (cells, nodes, differing nodes in the float cases)"""
+    rng = np.random.default_rng(seed)
+    side_hi = min(max_side, pr.W, pr.H)
+    total_nodes = total_diff = 0
+    for dyadic in (True, False):
+        shapes = [(int(rng.integers(6, side_hi + 1)), int(rng.integers(6, side_hi + 1))) for _ in range(ncells // 2)]
+        shapes[0] = (side_hi, side_hi)
+        if side_hi >= 42:
+            shapes[1] = (42, 42)
+        pays = _random_cell_payloads(rng, shapes, dyadic)
+        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays)
+        assert not status.any(), "a cell hit the iteration limit"
+        for i, ((w, h), p) in enumerate(zip(shapes, pays)):
+            ref_flow, ref_src = _grid_graph_reference(p, w, h)
+            dev_src = masks[off[i]: off[i] + w * h] != 0
+            scale = max(1.0, np.abs(p[:, 0]).astype(np.float64).sum())
+            total_nodes += w * h
+            if dyadic:
+                assert np.array_equal(dev_src, ref_src), f"cell {i} ({w}x{h}): {int((dev_src != ref_src).sum())} nodes differ from the canonical minimum cut"
+                assert abs(flows[i] - ref_flow) <= 1e-9 * scale, (flows[i], ref_flow)
+            else:
+                assert abs(flows[i] - ref_flow) <= 1e-6 * scale, (flows[i], ref_flow)
+                cap_dev = _cut_capacity(p, w, h, dev_src)
+                assert abs(cap_dev - ref_flow) <= 1e-6 * scale, f"cell {i}: the device mask is not a minimum cut ({cap_dev} vs {ref_flow})"
+                total_diff += int((dev_src != ref_src).sum())
+    return ncells // 2 * 2, total_nodes, total_diff
+
+
+def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40):
+    """Cells of at most 4 x 4 nodes: every one of the 2^n labelings is enumerated; the device mask must be THE canonical minimum cut
+    (the minimum-capacity labeling whose sink side is the intersection of all minimum sink sides).  Dyadic capacities: exact."""
+    rng = np.random.default_rng(seed)
+    shapes = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(ncells)]
+    shapes[0] = (4, 4)
+    pays = _random_cell_payloads(rng, shapes, dyadic=True)
+    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays)
+    assert not status.any()
+    for i, ((w, h), p) in enumerate(zip(shapes, pays)):
+        n = w * h
+        codes = np.arange(1 << n, dtype=np.int64)
+        bits = ((codes[:, None] >> np.arange(n)[None, :]) & 1).astype(bool)              # True = SOURCE
+        q = p.reshape(h, w, 5).astype(np.float64)
+        tr = q[..., 0].reshape(-1)
+        cap = np.where(bits, np.maximum(-tr, 0)[None, :], np.maximum(tr, 0)[None, :]).sum(1)
+        for k, (dx, dy) in enumerate(((1, 0), (0, 1), (-1, 1), (1, 1))):
+            for y in range(h):
+                for x in range(w):
+                    c, xx, yy = q[y, x, 1 + k], x + dx, y + dy
+                    if c > 0 and 0 <= xx < w and 0 <= yy < h:
+                        cap += c * (bits[:, y * w + x] & ~bits[:, yy * w + xx])
+        best = cap.min()
+        minimal = bits[cap == best]
+        # minimum cuts are closed under union of their source sides: the canonical cut (smallest sink side) is that union
+        canonical = minimal.any(axis=0)
+        assert cap[(bits == canonical[None, :]).all(1)][0] == best
+        dev_src = masks[off[i]: off[i] + n] != 0
+        assert np.array_equal(dev_src, canonical), f"cell {i} ({w}x{h}): device {dev_src.astype(int)} canonical {canonical.astype(int)}"
+        assert abs(flows[i] - best) <= 1e-9 * max(1.0, np.abs(tr).sum()), (flows[i], best)
+    return len(shapes)
+
+
 def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     """The Python FastGCStereo mirror end to end on the (padded) cones crop with config 1's energy, two views:
     PatchMatch iteration(s), graph-cut iteration(s), left-right post-processing, Evaluator rows."""

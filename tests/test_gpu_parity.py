@@ -357,6 +357,16 @@ def test_gpu_device_maxflow_edge_cells(cones, mid):
     pc.case_device_maxflow_edge_cells(mid, seed=8)
 
 
+def test_gpu_device_maxflow_against_independent_checkers(mid):
+    """les_maxflow_kernel is checked WITHOUT product code on the other side: networkx (preflow-push + residual reachability = the
+    canonical cut of the reference's solver) on 50 layer-0-sized cells, and exhaustive enumeration on cells of at most 4 x 4 nodes."""
+    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(mid, seed=5, ncells=50, max_side=45)
+    print(f"device max-flow vs networkx: {cells} cells, {nodes} nodes; float-capacity cells: {diff} nodes on ties (zero energy difference, asserted)")
+    assert diff <= 2e-4 * nodes
+    n = pc.case_device_maxflow_vs_brute_force(mid, seed=9, ncells=40)
+    print(f"device max-flow vs brute force: {n} cells of at most 4 x 4 nodes, canonical cut reproduced exactly")
+
+
 def test_gpu_device_cuts_fall_back_to_the_host(oracle_mod, monkeypatch):
     """A device max-flow that gives up (iteration limit 0) reports every cell, the lock-step is then cut on the host: the iteration
     must equal, bit for bit, the one with device cuts switched off."""

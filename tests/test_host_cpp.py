@@ -45,6 +45,23 @@ def test_host_demo_runs_on_gpu(demo):
     assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
 
 
+@pytest.mark.gpu
+def test_host_demo_full_size_on_gpu(demo):
+    """The C++ host (PMStereo::runDevice) at the Adirondack-H shape: the MidV3 loop with device-built graphs and device cuts; its
+    wall-clock stands next to the Python driver's (tools/e2e_bench.py) in DESIGN.md."""
+    import os
+    env = dict(os.environ, OMP_WAIT_POLICY="passive")
+    r = subprocess.run([demo, "full", "1436", "992", "256", "5", "2"], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
+    import re
+    sec = float(re.search(r"optimiser ([0-9.]+) s", r.stdout).group(1))
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "host_demo_full.log"), "w") as f:
+        f.write(r.stdout)
+    assert sec < 8.0, sec
+
+
 def test_host_graph_cut_selfcheck(demo):
     """Local expansion moves on the host (ExpansionMove.h over MaxFlow.h): brute-force optimality on tiny regions, the
     reference's flow == energy self-check (LES/FastGCStereo.h:561-594) on every move, monotone energy, convergence."""

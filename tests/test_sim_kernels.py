@@ -203,6 +203,13 @@ def test_sim_device_maxflow_edge_cells(cones):
     pc.case_device_maxflow_edge_cells(cones)
 
 
+def test_sim_device_maxflow_against_independent_checkers(cones):
+    """The same kernel source against networkx and brute force (no product code as the checker); the full-size version runs on the GPU."""
+    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24)
+    assert diff <= 1e-3 * nodes
+    pc.case_device_maxflow_vs_brute_force(cones, seed=9, ncells=12)
+
+
 def test_sim_graph_cut_iterations(sim_lib, oracle_mod, monkeypatch):
     """PatchMatch + graph-cut iterations through the Python driver: simulator proposals / unary costs, host cuts.
     (Driver and host-cut logic are under test: the fiber simulator runs them on the 256-thread strip kernel, ~4x faster than on the
