@@ -169,6 +169,67 @@ def test_validity_mask(ctx):
     assert o.valid_mask((5, 5, 1, 1), (0, 0, 16.0, 0))[0, 0] == 0
 
 
+def _gather_numpy(vol, fr, pl, th, mind, maxd):
+    """LES/CostVolumeEnergy.h:70-98 restated independently of the oracle, array-wise in float32 (interpolate == 1)."""
+    a, b, c = (np.float32(v) for v in pl[:3])
+    Dn = vol.shape[0]
+    D0 = int(-mind)
+    ys = np.arange(fr[1], fr[1] + fr[3], dtype=np.float32)[:, None]
+    xs = np.arange(fr[0], fr[0] + fr[2], dtype=np.float32)[None, :]
+    with np.errstate(invalid="ignore", over="ignore"):
+        d = (a * xs + (b * ys + c)).astype(np.float32)
+        yy, xx = np.broadcast_arrays(ys.astype(int), xs.astype(int))
+        bad = ~np.isfinite(d)
+        dsafe = np.where(bad, np.float32(0), d)
+        d0 = np.trunc(dsafe).astype(np.int64) + D0                      # int(d): truncation towards zero
+        d1 = d0 + 1
+        f1 = (dsafe - np.floor(dsafe)).astype(np.float32)
+        f0 = (np.float32(1) - f1).astype(np.float32)
+        ok = (d1 < Dn) & (d0 >= 0)
+        lo, hi = np.clip(d0, 0, Dn - 1), np.clip(d1, 0, Dn - 1)
+        C = ((f0 * vol[lo, yy, xx]).astype(np.float32) + (f1 * vol[hi, yy, xx]).astype(np.float32)).astype(np.float32)
+        C = np.where(ok, C, np.float32(1e6))
+        C = np.where(bad, np.float32(1e6), C)
+        C = np.where(d >= np.float32(maxd), vol[Dn - 1, yy, xx], C)
+        C = np.where(d < np.float32(mind), vol[0, yy, xx], C)
+    return np.minimum(C, np.float32(th)).astype(np.float32)
+
+
+def test_gather_and_validity_random_planes_match_numpy(oracle_mod):
+    """Randomised form of the two tests above: 60 planes (slanted, out of range on either side, huge, infinite, NaN) on both views,
+    with MIN_DISPARITY = 0 and -3: the oracle's gather and IsValiLabel against array-wise numpy restatements, bit for bit."""
+    imL, imR = load_cones_crop()
+    volL, volR = synth.make_volume(D, H, W, seed=52), synth.make_volume(D, H, W, seed=53)
+    rng = np.random.default_rng(11)
+    for mind in (0.0, -3.0):
+        maxd = float(D - 1) + mind
+        o = oracle_mod.Oracle(imL, imR, volL, volR, windR=20, eps=1e-4, th_col=0.5, max_disp=maxd, min_disp=mind)
+        for k in range(60):
+            fr = (int(rng.integers(0, 40)), int(rng.integers(0, 30)), int(rng.integers(1, 80)), int(rng.integers(1, 60)))
+            pl = [rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(mind - 4, maxd + 4), 0.0]
+            if k % 10 == 7:
+                pl[2] = [1e9, -1e9, float("inf"), float("-inf"), float("nan"), 1e30][(k // 10) % 6]
+            if k % 10 == 8:
+                pl[0] = [float("nan"), 1e30, -1e30, float("inf")][(k // 10) % 4]
+            mode = k & 1
+            got = o.gather(fr, pl, mode=mode)
+            ref = _gather_numpy(volR if mode else volL, fr, pl, 0.5, mind, maxd)
+            assert np.array_equal(got, ref, equal_nan=True), (mind, k, pl)
+            # IsValiLabel (LES/StereoEnergy.h:560-610): the five probes of the 11 x 11 patch corners and centre must lie in [MIN, MAX]
+            a, b, c = (np.float32(v) for v in pl[:3])
+            ys = np.arange(fr[1], fr[1] + fr[3], dtype=np.float32)[:, None]
+            xs = np.arange(fr[0], fr[0] + fr[2], dtype=np.float32)[None, :]
+            with np.errstate(invalid="ignore", over="ignore"):
+                ds = ((xs * a + ys * b).astype(np.float32) + c).astype(np.float32)
+                a5, b5 = np.float32(a * 5), np.float32(b * 5)
+                okm = (ds >= np.float32(mind)) & (ds <= np.float32(maxd))
+                for sa in (1, -1):
+                    for sb in (1, -1):
+                        dd = ((ds + np.float32(sa) * a5).astype(np.float32) + np.float32(sb) * b5).astype(np.float32)
+                        okm &= (dd >= np.float32(mind)) & (dd <= np.float32(maxd))
+            assert np.array_equal(o.valid_mask(fr, pl), np.where(okm, 255, 0).astype(np.uint8)), (mind, k, pl)
+
+
 def test_unary_writes_only_target_and_marks_invalid(ctx):
     o = ctx[0]
     fr, tr = (19, 22, 82, 74), (39, 42, 42, 34)
