@@ -204,6 +204,26 @@ int les_hip_consistency_check(les_hip_ctx* ctx, const les_hip_plane* d_labelsL, 
  * Both device label maps are updated in place.  Needs both views' images in the context; windR <= 31. */
 int les_hip_post_process(les_hip_ctx* ctx, les_hip_plane* d_labelsL, les_hip_plane* d_labelsR, float threshold, float omega);
 
+/* ---- multi-GPU: publishing the tiles a rank updated (not in the reference, which is single-process; SURVEY 8(e): the cells of a
+ * disjoint set -- LES/LayerManager.h:168-172 -- are split over the ranks, replicas of the label / cost maps are kept coherent by one
+ * all-gather per set of the label (16 B/px) and cost (4 B/px) tiles of the shared regions, LES/FastGCStereo.h:22-72).
+ * An exchange object is the plan for one (layer, set): rects = the target rects of ALL ranks' cells in rank order, first[r] .. first[r+1]
+ * those of rank r (first has world + 1 entries).  Slot of a rank in the gathered buffer = les_hip_exchange_slot_floats floats:
+ * [float4 labels x lmax][float costs x lmax] in rect order, row-major inside a rect.
+ *   les_hip_exchange_pack    this rank's tiles (device maps) -> its slot (device buffer of slot_floats floats)
+ *   les_hip_exchange_unpack  the gathered world x slot_floats buffer -> the other ranks' tiles into this rank's device maps
+ *   les_hip_exchange_tiles   pack -> ncclAllGather on the ncclComm_t the HOST created (RCCL, resolved at run time with dlopen:
+ *                            single-GPU users need no librccl) -> unpack, all enqueued on the calling thread's stream of the
+ *                            context, no host synchronisation.  world == 1 with a null communicator is a no-op.
+ * pack / unpack are exposed so that a host with another transport (torch.distributed in the tests) can move the slot itself. */
+typedef struct les_hip_exchange les_hip_exchange;
+int les_hip_exchange_create(les_hip_ctx* ctx, int rank, int world, int n_rects, const les_hip_rect* rects, const int* first, les_hip_exchange** out);
+void les_hip_exchange_destroy(les_hip_exchange* x);
+long long les_hip_exchange_slot_floats(const les_hip_exchange* x);
+int les_hip_exchange_pack(les_hip_ctx* ctx, const les_hip_exchange* x, const les_hip_plane* d_labels, const float* d_cost, float* d_slot);
+int les_hip_exchange_unpack(les_hip_ctx* ctx, const les_hip_exchange* x, const float* d_gathered, les_hip_plane* d_labels, float* d_cost);
+int les_hip_exchange_tiles(les_hip_ctx* ctx, les_hip_exchange* x, void* nccl_comm, les_hip_plane* d_labels, float* d_cost);
+
 /* diagnostics: dword-per-lane streaming copy of n floats (device pointers), the known-byte-count pattern used to
  * calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for this library's access width (profiles/). */
 int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, void* stream);

@@ -22,7 +22,8 @@ SYMBOLS = [
     "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
-    "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
+    "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_exchange_create", "les_hip_exchange_destroy", "les_hip_exchange_slot_floats",
+    "les_hip_exchange_pack", "les_hip_exchange_unpack", "les_hip_exchange_tiles", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
 ]
 
 
@@ -81,6 +82,12 @@ def load(path=None):
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_calib_copy_wide": (ci, [vp, vp, C.c_size_t, ci, vp]),
+        "les_hip_exchange_create": (ci, [vp, ci, ci, ci, vp, vp, C.POINTER(vp)]),
+        "les_hip_exchange_destroy": (None, [vp]),
+        "les_hip_exchange_slot_floats": (C.c_longlong, [vp]),
+        "les_hip_exchange_pack": (ci, [vp, vp, vp, vp, vp]),
+        "les_hip_exchange_unpack": (ci, [vp, vp, vp, vp, vp]),
+        "les_hip_exchange_tiles": (ci, [vp, vp, vp, vp, vp]),
         "les_hip_consistency_check": (ci, [vp, vp, vp, C.c_float, vp, vp]),
         "les_hip_post_process": (ci, [vp, vp, vp, C.c_float, C.c_float]),
         "les_hip_create_naive": (ci, [C.POINTER(vp), C.POINTER(Params), vp, vp, C.c_float, C.c_float]),
@@ -187,6 +194,37 @@ class DeviceBuffer:
         if self.ptr:
             self.e.L.les_hip_free(self.e.h, C.c_void_p(self.ptr))
             self.ptr = None
+
+
+class Exchange:
+    """Plan of the per-set tile exchange between ranks (include/localexp_hip.h: les_hip_exchange_*): `rects_per_rank[r]` = the target
+    rects of rank r's cells.  pack / unpack move this rank's tiles into / the other ranks' tiles out of the all-gather buffer; tiles()
+    does pack -> ncclAllGather -> unpack inside the library on an ncclComm_t (C++ hosts); the Python driver gathers with torch.distributed."""
+
+    def __init__(self, energy, rank, rects_per_rank):
+        self.e, self.rank, self.world = energy, rank, len(rects_per_rank)
+        parts = [_rects(r) for r in rects_per_rank]
+        first = np.cumsum([0] + [len(p) for p in parts]).astype(np.int32)
+        allr = np.concatenate(parts) if parts else np.zeros(0, RECT_DT)
+        h = C.c_void_p()
+        energy._chk(energy.L.les_hip_exchange_create(energy.h, rank, self.world, len(allr), _ptr(allr) if len(allr) else None, _ptr(first), C.byref(h)))
+        self.h = h
+        self.slot_floats = int(energy.L.les_hip_exchange_slot_floats(h))
+
+    def pack(self, labels_ptr, cost_ptr, slot_ptr):
+        self.e._chk(self.e.L.les_hip_exchange_pack(self.e.h, self.h, C.c_void_p(int(labels_ptr)), C.c_void_p(int(cost_ptr)), C.c_void_p(int(slot_ptr))))
+
+    def unpack(self, gathered_ptr, labels_ptr, cost_ptr):
+        self.e._chk(self.e.L.les_hip_exchange_unpack(self.e.h, self.h, C.c_void_p(int(gathered_ptr)), C.c_void_p(int(labels_ptr)), C.c_void_p(int(cost_ptr))))
+
+    def tiles(self, nccl_comm, labels_ptr, cost_ptr):
+        self.e._chk(self.e.L.les_hip_exchange_tiles(self.e.h, self.h, C.c_void_p(int(nccl_comm)) if nccl_comm else None, C.c_void_p(int(labels_ptr)),
+                                                    C.c_void_p(int(cost_ptr))))
+
+    def destroy(self):
+        if self.h:
+            self.e.L.les_hip_exchange_destroy(self.h)
+            self.h = None
 
 
 class Batch:

@@ -17,6 +17,7 @@ HOST = os.path.join(_HERE, "host")
 HIP_SO = os.path.join(CSRC, "liblocalexp_hip.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_LIBS = ["-ldl"]      # dlopen of librccl at run time (les_hip_exchange_tiles): no link-time dependency on RCCL
 
 
 def _newer(target, sources):
@@ -38,7 +39,7 @@ def build_hip(force=False, verbose=False):
     srcs.append(os.path.join(ROOT, "include", "localexp_hip.h"))
     if not force and _newer(HIP_SO, srcs):
         return HIP_SO
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", HIP_SO]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", HIP_SO] + HIPCC_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -16,6 +16,9 @@
 #include <atomic>
 #include <cstdint>
 #include <mutex>
+#if !defined(LES_SIM)
+#include <dlfcn.h>
+#endif
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1269,6 +1272,128 @@ int les_hip_calib_copy(const float* d_src, float* d_dst, size_t n, int device, v
     hipLaunchKernelGGL(les::les_calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, n);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
+}
+
+// ---- multi-GPU tile exchange (include/localexp_hip.h): plan = rect table of every rank, slot layout; pack / unpack kernels; the
+// all-gather itself over an ncclComm_t handed in by the host (RCCL is resolved at run time: a single-GPU user needs no librccl)
+struct les_hip_exchange {
+    les_hip_ctx* c = nullptr;
+    int rank = 0, world = 1, nrects = 0, own_first = 0, own_n = 0, lmax = 0, max_px = 0;
+    les::XchgRect* d_rects = nullptr;
+    float* d_send = nullptr; float* d_recv = nullptr;       // buffers of les_hip_exchange_tiles, allocated on its first call
+};
+
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_allgather_fn load_nccl_allgather()
+{
+    static std::once_flag once;
+    static nccl_allgather_fn fn = nullptr;
+#if !defined(LES_SIM)
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                fn = reinterpret_cast<nccl_allgather_fn>(dlsym(h, "ncclAllGather"));
+                if (fn) break;
+            }
+        }
+    });
+#endif
+    return fn;
+}
+int xchg_chunks(int max_px) { return std::max(1, std::min(64, max_px / 4096)); }
+}  // namespace
+
+int les_hip_exchange_create(les_hip_ctx* c, int rank, int world, int n, const les_hip_rect* rects, const int* first, les_hip_exchange** out)
+{
+    if (!c || !out || world < 1 || rank < 0 || rank >= world || n < 0 || (n > 0 && !rects) || !first) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_create: bad argument");
+    *out = nullptr;
+    if (first[0] != 0 || first[world] != n) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_create: first[] must run from 0 to n");
+    std::vector<les::XchgRect> tab((size_t)n);
+    long long lmax = 0;
+    int max_px = 0;
+    for (int r = 0; r < world; r++) {
+        if (first[r + 1] < first[r]) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_create: first[] must not decrease");
+        long long off = 0;
+        for (int i = first[r]; i < first[r + 1]; i++) {
+            const les_hip_rect& q = rects[i];
+            if (q.w < 0 || q.h < 0 || (q.w > 0 && q.h > 0 && (q.x < 0 || q.y < 0 || q.x + q.w > c->p.W || q.y + q.h > c->p.H)))
+                return fail(LES_HIP_ERR_ARG, "les_hip_exchange_create: rect %d outside the image", i);
+            tab[(size_t)i] = les::XchgRect{q.x, q.y, q.w, q.h, (int)off, r};
+            off += (long long)q.w * q.h;
+            max_px = std::max(max_px, q.w * q.h);
+        }
+        lmax = std::max(lmax, off);
+    }
+    lmax = (lmax + 3) / 4 * 4;                                  // the cost block of a slot stays 16-byte aligned
+    if (lmax * 5 * world >= (1ll << 31)) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_create: exchange buffer too large");
+    HIPCHECK(hipSetDevice(c->p.device));
+    les_hip_exchange* x = new les_hip_exchange();
+    x->c = c; x->rank = rank; x->world = world; x->nrects = n; x->own_first = first[rank]; x->own_n = first[rank + 1] - first[rank];
+    x->lmax = (int)lmax; x->max_px = max_px;
+    if (n > 0) {
+        if (hipMalloc((void**)&x->d_rects, (size_t)n * sizeof(les::XchgRect)) != hipSuccess ||
+            hipMemcpy(x->d_rects, tab.data(), (size_t)n * sizeof(les::XchgRect), hipMemcpyHostToDevice) != hipSuccess) {
+            les_hip_exchange_destroy(x);
+            return fail(LES_HIP_ERR_DEVICE, "les_hip_exchange_create: upload of the rect table failed");
+        }
+    }
+    *out = x;
+    return LES_HIP_OK;
+}
+
+void les_hip_exchange_destroy(les_hip_exchange* x)
+{
+    if (!x) return;
+    if (x->c) (void)hipSetDevice(x->c->p.device);
+    if (x->d_rects) (void)hipFree(x->d_rects);
+    if (x->d_send) (void)hipFree(x->d_send);
+    if (x->d_recv) (void)hipFree(x->d_recv);
+    delete x;
+}
+
+long long les_hip_exchange_slot_floats(const les_hip_exchange* x) { return x ? 5ll * x->lmax : 0; }
+
+int les_hip_exchange_pack(les_hip_ctx* c, const les_hip_exchange* x, const les_hip_plane* d_labels, const float* d_cost, float* d_slot)
+{
+    if (!c || !x || x->c != c || !d_labels || !d_cost || !d_slot) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_pack: bad argument");
+    if (x->own_n <= 0) return LES_HIP_OK;
+    hipLaunchKernelGGL(les::les_xchg_pack_kernel, dim3(x->own_n, xchg_chunks(x->max_px)), dim3(256), 0, cur_stream(c), x->d_rects, x->own_first,
+                       reinterpret_cast<const float4*>(d_labels), d_cost, d_slot, x->lmax, c->p.W);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_exchange_unpack(les_hip_ctx* c, const les_hip_exchange* x, const float* d_recv, les_hip_plane* d_labels, float* d_cost)
+{
+    if (!c || !x || x->c != c || !d_labels || !d_cost || !d_recv) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_unpack: bad argument");
+    if (x->nrects <= 0 || x->world == 1) return LES_HIP_OK;
+    hipLaunchKernelGGL(les::les_xchg_unpack_kernel, dim3(x->nrects, xchg_chunks(x->max_px)), dim3(256), 0, cur_stream(c), x->d_rects, d_recv,
+                       reinterpret_cast<float4*>(d_labels), d_cost, x->lmax, c->p.W, x->rank);
+    HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+int les_hip_exchange_tiles(les_hip_ctx* c, les_hip_exchange* x, void* nccl_comm, les_hip_plane* d_labels, float* d_cost)
+{
+    if (!c || !x || x->c != c || !d_labels || !d_cost) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_tiles: bad argument");
+    if (x->world == 1 && !nccl_comm) return LES_HIP_OK;                                  // one rank: nothing to publish
+    if (!nccl_comm) return fail(LES_HIP_ERR_ARG, "les_hip_exchange_tiles: %d ranks need an ncclComm_t", x->world);
+    nccl_allgather_fn allgather = load_nccl_allgather();
+    if (!allgather) return fail(LES_HIP_ERR_DEVICE, "les_hip_exchange_tiles: librccl.so (ncclAllGather) not found");
+    const size_t slot = (size_t)5 * x->lmax;
+    if (slot == 0) return LES_HIP_OK;
+    if (!x->d_send) {
+        HIPCHECK(hipSetDevice(c->p.device));
+        HIPCHECK(hipMalloc((void**)&x->d_send, slot * sizeof(float)));
+        HIPCHECK(hipMalloc((void**)&x->d_recv, slot * sizeof(float) * (size_t)x->world));
+    }
+    // pack -> all-gather -> unpack, all enqueued on the calling thread's stream: no host synchronisation anywhere
+    int rc = les_hip_exchange_pack(c, x, d_labels, d_cost, x->d_send);
+    if (rc) return rc;
+    const int nrc = allgather(x->d_send, x->d_recv, slot, 7 /* ncclFloat32 */, nccl_comm, cur_stream(c));
+    if (nrc != 0) return fail(LES_HIP_ERR_DEVICE, "les_hip_exchange_tiles: ncclAllGather failed with ncclResult_t %d", nrc);
+    return les_hip_exchange_unpack(c, x, x->d_recv, d_labels, d_cost);
 }
 
 int les_hip_calib_copy_wide(const float* d_src, float* d_dst, size_t n, int device, void* stream)

@@ -759,4 +759,42 @@ __global__ void les_wta_kernel(const WtaJob* __restrict__ jobs, const float4* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Multi-GPU tile exchange: after the lock-steps of a disjoint set every rank publishes the label / cost tiles of its
+// own cells.  A rank's slot of the all-gather buffer is [labels of its pixels: float4 x lmax][costs: float x lmax]; `off` is the
+// pixel offset of a rect inside its rank's slot.  grid = (rects, row chunks).
+// ---------------------------------------------------------------------------------------------------
+struct XchgRect { int x, y, w, h; int off; int rank; };
+
+__global__ void les_xchg_pack_kernel(const XchgRect* __restrict__ rects, int first, const float4* __restrict__ labels,
+                                     const float* __restrict__ cost, float* __restrict__ slot, int lmax, int W)
+{
+    const XchgRect r = rects[first + blockIdx.x];
+    float4* sl = reinterpret_cast<float4*>(slot);
+    float* sc = slot + 4 * (size_t)lmax;
+    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < r.w * r.h; idx += (int)(blockDim.x * gridDim.y)) {
+        const int yy = idx / r.w, xx = idx - yy * r.w;
+        const size_t k = (size_t)(r.y + yy) * W + r.x + xx;
+        sl[r.off + idx] = labels[k];
+        sc[r.off + idx] = cost[k];
+    }
+}
+
+// every rect of every OTHER rank (own_rank's rects are skipped: this rank's maps already hold them)
+__global__ void les_xchg_unpack_kernel(const XchgRect* __restrict__ rects, const float* __restrict__ recv, float4* __restrict__ labels,
+                                       float* __restrict__ cost, int lmax, int W, int own_rank)
+{
+    const XchgRect r = rects[blockIdx.x];
+    if (r.rank == own_rank) return;
+    const float* slot = recv + 5 * (size_t)lmax * (size_t)r.rank;
+    const float4* sl = reinterpret_cast<const float4*>(slot);
+    const float* sc = slot + 4 * (size_t)lmax;
+    for (int idx = (int)(blockIdx.y * blockDim.x + threadIdx.x); idx < r.w * r.h; idx += (int)(blockDim.x * gridDim.y)) {
+        const int yy = idx / r.w, xx = idx - yy * r.w;
+        const size_t k = (size_t)(r.y + yy) * W + r.x + xx;
+        labels[k] = sl[r.off + idx];
+        cost[k] = sc[r.off + idx];
+    }
+}
+
 }  // namespace les

@@ -55,15 +55,6 @@ def seeds_for(n, seed):
     return np.where(x == 0, np.uint64(0xFFFFFFFF), x).astype(np.uint64)
 
 
-def _pixel_indices(rects, W):
-    parts = []
-    for r in rects:
-        ys = np.arange(r["y"], r["y"] + r["h"], dtype=np.int64)[:, None]
-        xs = np.arange(r["x"], r["x"] + r["w"], dtype=np.int64)[None, :]
-        parts.append((ys * W + xs).reshape(-1))
-    return np.concatenate(parts) if parts else np.zeros(0, np.int64)
-
-
 class _Shard:
     """One (layer, disjoint set) on one rank: prepared batch of the rank's own cells + exchange indices."""
 
@@ -82,13 +73,15 @@ class _Shard:
         self.graph_off = self.batch.graph_offsets()
         self.graph_nodes = self.batch.graph_nodes()
         self.payload = None                      # device / pinned host buffers of the graph capacities, allocated on first use
-        self.idx = [torch.from_numpy(_pixel_indices(tgt[cells[bounds[r]:bounds[r + 1]]], runner.W)).to(dev) for r in range(world)]
-        self.lmax = max(int(i.numel()) for i in self.idx)
+        # the plan of the set's tile exchange (C ABI: les_hip_exchange_*): every rank's target rects, this rank's slot layout
+        self.xchg = api.Exchange(e, rank, [tgt[cells[bounds[r]:bounds[r + 1]]] for r in range(world)]) if world > 1 else None
 
 
 class PMRunner:
-    def __init__(self, energy, layer_units, proposer_table, seed=1, rank=0, world=1, device="cuda", mode=0):
-        self.e, self.rank, self.world, self.mode = energy, rank, world, mode
+    def __init__(self, energy, layer_units, proposer_table, seed=1, rank=0, world=1, device="cuda", mode=0, group=None):
+        """rank / world: this process's place among the ranks that share THIS view's cells; group: their torch.distributed process group
+        (None = the default group).  Two-view runs on several ranks give each view its own group (stereo.FastGCStereo.run)."""
+        self.e, self.rank, self.world, self.mode, self.group = energy, rank, world, mode, group
         self.device = torch.device(device)
         if self.device.type == "cuda":
             # the torch ops of this class (exchange index_copy_, label / mask copies) run on torch's current stream: bind the
@@ -113,26 +106,27 @@ class PMRunner:
                 self.init = _Shard(self, units, shared, fr, np.arange(len(units)), seeds_for(len(units), seed + 777), target_is_unit=True)
         self.bytes_exchanged = 0
 
-    # -- exchange: one all-gather of the updated tiles of a set (labels 16 B/px + cost 4 B/px)
+    # -- exchange: one all-gather of the updated tiles of a set (labels 16 B/px + cost 4 B/px).  Pack and unpack are kernels of the
+    # library on the runner's stream; with the nccl backend the collective is enqueued on the same stream by torch, so nothing here
+    # waits on the host (gloo works on host tensors: the simulator's "device" memory is host memory).
     def _exchange(self, sh):
         if self.world == 1:
             return
         import torch.distributed as dist
-        lab, cur = self.labels.view(-1, 4), self.cur.view(-1)
-        send = torch.zeros((sh.lmax, 5), dtype=torch.float32, device=self.device)
-        own = sh.idx[self.rank]
-        send[: own.numel(), :4] = lab.index_select(0, own)
-        send[: own.numel(), 4] = cur.index_select(0, own)
-        recv = torch.empty((self.world * sh.lmax, 5), dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(recv, send)
+        x = sh.xchg
+        if x.slot_floats == 0:
+            return
+        if getattr(self, "_xbuf", None) is None or self._xbuf[0].numel() < x.slot_floats:
+            n = max(s_.xchg.slot_floats for layer in self.shards for s_ in layer) if self.shards else x.slot_floats
+            n = max(n, x.slot_floats, self.init.xchg.slot_floats if getattr(self, "init", None) is not None and self.init.xchg else 0)
+            self._xbuf = (torch.zeros(n, dtype=torch.float32, device=self.device), torch.zeros(n * self.world, dtype=torch.float32, device=self.device))
+        send, recv = self._xbuf[0][: x.slot_floats], self._xbuf[1][: x.slot_floats * self.world]
+        x.pack(self.labels.data_ptr(), self.cur.data_ptr(), send.data_ptr())
+        if self.device.type != "cuda":
+            self._sync()
+        dist.all_gather_into_tensor(recv, send, group=self.group)
         self.bytes_exchanged += recv.numel() * 4
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            idx = sh.idx[r]
-            blk = recv[r * sh.lmax: r * sh.lmax + idx.numel()]
-            lab.index_copy_(0, idx, blk[:, :4].contiguous())
-            cur.index_copy_(0, idx, blk[:, 4].contiguous())
+        x.unpack(recv.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr())
 
     def _sync(self):
         self.e.synchronize()
@@ -184,7 +178,8 @@ class PMRunner:
                             sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=m)
                             sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=self.mode, check=True, planes_on_device=True)
                             sh.batch.wta(sh.planes.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
-                self._sync()
+                if self.world == 1 or self.device.type != "cuda":
+                    self._sync()                     # (bounds the launch queue; with several ranks on GPUs the collective orders the stream itself)
                 self._exchange(sh)
 
     # -- graph-cut iterations (LES/FastGCStereo.h:171-185: the main loop, doGC == true) ----------------------------
@@ -306,7 +301,6 @@ class PMRunner:
                             self.gc_seconds[f"host_cuts_layer{li}"] += t2 - t1
                             self.gc_seconds["h2d"] += t3 - t2
                 if self.world > 1:
-                    self._sync()
                     self._exchange(sh)
                     if host_path:
                         lab_host.copy_(self.labels)
@@ -389,7 +383,7 @@ class PMRunner:
         return self.labels[..., 0] * xs + self.labels[..., 1] * ys + self.labels[..., 2]
 
     def close(self):
-        for layer in self.shards:
-            for sh in layer:
-                sh.batch.destroy()
-        self.init.batch.destroy()
+        for sh in [s_ for layer in self.shards for s_ in layer] + [self.init]:
+            sh.batch.destroy()
+            if sh.xchg is not None:
+                sh.xchg.destroy()

@@ -75,8 +75,23 @@ class FastGCStereo:
         start labelling (the reference's `labeling` argument; every view starts from it, as in the reference)."""
         t0 = time.perf_counter()
         self.eval_seconds = 0.0
-        runners = {m: pm.PMRunner(self.e, self.units, self.table, seed=self.seed + 7919 * m, rank=self.rank, world=self.world,
-                                  device=self.device, mode=m) for m in viewModes}
+        # Several ranks and two views: the views are independent until the post-processing (LES/FastGCStereo.h:172-185), so the ranks are
+        # split into one group per view -- the first ceil(world / 2) ranks advance the left view, the others the right one -- and each
+        # group shards the cells of ITS view.  A coarse layer has only 4-6 cells per disjoint set (SURVEY 8 geometry table): spread
+        # over world / 2 ranks instead of world, and the two views no longer take turns.  The groups meet once, before the
+        # post-processing: one broadcast per view of its final label map.
+        all_views = tuple(viewModes)
+        view_group, view_rank, view_world, view_root = None, self.rank, self.world, {}
+        if self.world > 1 and len(all_views) == 2:
+            import torch.distributed as dist
+            n0 = (self.world + 1) // 2
+            groups = [dist.new_group(list(range(0, n0))), dist.new_group(list(range(n0, self.world)))]      # (every rank creates both)
+            mine = 0 if self.rank < n0 else 1
+            view_group, view_rank, view_world = groups[mine], self.rank - (0 if mine == 0 else n0), (n0 if mine == 0 else self.world - n0)
+            view_root = {all_views[0]: 0, all_views[1]: n0}
+            viewModes = (all_views[mine],)
+        runners = {m: pm.PMRunner(self.e, self.units, self.table, seed=self.seed + 7919 * m, rank=view_rank, world=view_world,
+                                  device=self.device, mode=m, group=view_group) for m in viewModes}
         g = gc.GraphCut(self.imL, self.imR, lambda_=self.p["lambda_"], th_smooth=self.p["th_smooth"], omega=self.p["omega"],
                         epsilon=self.p["epsilon"]) if maxIteration > 0 else None
         for m in viewModes:
@@ -153,11 +168,23 @@ class FastGCStereo:
                 self.gc_max_gap = max(self.gc_max_gap, runners[m].gc_max_gap)
                 for k, v in runners[m].gc_seconds.items():
                     self.gc_seconds[k] = self.gc_seconds.get(k, 0.0) + v
-        raw = runners[0].labels.cpu().numpy().copy() if 0 in runners else None
-        if len(viewModes) == 2:
-            self.e.post_process(runners[0].labels.data_ptr(), runners[1].labels.data_ptr(), 1.5, self.p["omega"])     # LES/FastGCStereo.h:202
-            self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
-        lab = runners[0].labels.cpu().numpy().copy() if 0 in runners else None
+        if view_root:
+            # the view groups meet: every rank receives both final label maps (16 B/px each) from the first rank of each group
+            import torch.distributed as dist
+            H_, W_ = self.e.H, self.e.W
+            other = {m: torch.zeros((H_, W_, 4), dtype=torch.float32, device=torch.device(self.device)) for m in all_views if m not in runners}
+            final = {m: (runners[m].labels if m in runners else other[m]) for m in all_views}
+            for m in all_views:
+                dist.broadcast(final[m], src=view_root[m])
+        else:
+            final = {m: runners[m].labels for m in all_views}
+        raw = final[0].cpu().numpy().copy() if 0 in final else None
+        if len(all_views) == 2:
+            self.e.post_process(final[all_views[0]].data_ptr(), final[all_views[1]].data_ptr(), 1.5, self.p["omega"])     # LES/FastGCStereo.h:202
+            if 0 in runners:
+                self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
+            # (the rows of the log belong to the ranks of the left view's group)
+        lab = final[0].cpu().numpy().copy() if 0 in final else None
         self.seconds = time.perf_counter() - t0 - self.eval_seconds          # the reference's clock: evaluation excluded
         for r in runners.values():
             r.close()

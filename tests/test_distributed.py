@@ -20,26 +20,41 @@ def test_python_layer_geometry_matches_oracle(oracle_mod):
         assert len(sets) == len(L.sets) and all(np.array_equal(a, b) for a, b in zip(sets, L.sets))
 
 
-def _run(world, out, H=64, W=88, D=10, iters=1, gc_iters=0, kernel=None):
+_CACHE = {}
+
+
+def _run(world, out, H=64, W=88, D=10, iters=1, gc_iters=0, kernel=None, worker="dist_worker.py", port=29517):
+    """(single-rank reference runs are cached per configuration: several tests compare against the same one)"""
+    key = (H, W, D, iters, gc_iters, kernel, worker)
+    if world == 1 and key in _CACHE:
+        return _CACHE[key]
+    res = _run_uncached(world, out, H, W, D, iters, gc_iters, kernel, worker, port)
+    if world == 1:
+        res = {k: res[k] for k in res.files}
+        _CACHE[key] = res
+    return res
+
+
+def _run_uncached(world, out, H, W, D, iters, gc_iters, kernel, worker, port):
     from localexpstereo_amd import build
     lib = build.build_sim()
     env = dict(os.environ, OMP_NUM_THREADS="2")
     if kernel:
         env["LES_HIP_KERNEL"] = kernel       # "strip": the fiber simulator runs the 256-thread strip kernel ~4x faster than the 768-thread march kernel
-    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    worker = os.path.join(ROOT, "tests", worker)
     args = [out, lib, str(H), str(W), str(D), str(iters), str(gc_iters)]
     if world == 1:
         cmd = [sys.executable, worker] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-               "--master-port", "29517", worker] + args
+               "--master-port", str(port), worker] + args
     subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     return np.load(out)
 
 
 def test_two_ranks_equal_one_rank(tmp_path, oracle_mod):
-    one = _run(1, str(tmp_path / "one.npz"))
-    two = _run(2, str(tmp_path / "two.npz"))
+    one = _run(1, str(tmp_path / "one.npz"), H=40, W=56, D=8)
+    two = _run(2, str(tmp_path / "two.npz"), H=40, W=56, D=8)
     assert int(one["bytes_exchanged"]) == 0 and int(two["bytes_exchanged"]) > 0
     assert one["labels"].tobytes() == two["labels"].tobytes()
     assert one["cur"].tobytes() == two["cur"].tobytes()
@@ -59,3 +74,27 @@ def test_two_ranks_equal_one_rank_graph_cut(tmp_path, oracle_mod):
     assert one["cur"].tobytes() == two["cur"].tobytes()
     assert one["host_labels"].tobytes() == one["labels"].tobytes()
     assert float(one["energy"]) == float(two["energy"]) and float(one["energy"]) > 0
+
+
+def test_four_ranks_equal_one_rank(tmp_path, oracle_mod):
+    """world_size 4: bands of cells per rank, the tile exchange through the C ABI's pack / unpack kernels (some ranks own no cell of a
+    coarse set: empty slots) -> the single-rank result bit for bit."""
+    one = _run(1, str(tmp_path / "one.npz"), H=48, W=64, iters=1, gc_iters=1, kernel="strip")      # (the reference run of the test above)
+    four = _run(4, str(tmp_path / "four.npz"), H=48, W=64, iters=1, gc_iters=1, kernel="strip", port=29519)
+    assert int(four["bytes_exchanged"]) > 0
+    assert one["labels"].tobytes() == four["labels"].tobytes()
+    assert one["cur"].tobytes() == four["cur"].tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_views_view_split_equals_one_rank(tmp_path, oracle_mod, world):
+    """BASELINE configs[3] (doDual on several GPUs): the ranks are split into one group per view (world 2: one rank per view; world 4:
+    two ranks per view, which also shard that view's cells), PatchMatch + graph-cut iterations, then one broadcast per view and the
+    left-right post-processing on every rank -> labelling and raw labelling of a single rank bit for bit."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    one = _run(1, str(tmp_path / "one.npz"), H=36, W=48, D=6, iters=1, gc_iters=1, kernel="strip", worker="dist_worker_dual.py")
+    many = _run(world, str(tmp_path / "many.npz"), H=36, W=48, D=6, iters=1, gc_iters=1, kernel="strip", worker="dist_worker_dual.py", port=29521 + world)
+    assert one["raw"].tobytes() == many["raw"].tobytes()
+    assert one["lab"].tobytes() == many["lab"].tobytes()
+    assert not np.array_equal(one["lab"], one["raw"])            # the post-processing did something

@@ -7,5 +7,5 @@
 set -e
 cd "$(dirname "$0")/../localexpstereo_amd/csrc"
 name=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared "$@" les_hip.hip -o libles_$name.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared "$@" les_hip.hip -o libles_$name.so -ldl
 echo "built localexpstereo_amd/csrc/libles_$name.so"
