@@ -1097,6 +1097,80 @@ def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40):
     return len(shapes)
 
 
+def case_exchange_pack_unpack(pr, seed=2):
+    """les_hip_exchange_pack / _unpack (the multi-GPU tile exchange behind the C ABI) against a numpy restatement of the slot layout:
+    three ranks' rect lists, this process plays rank 1; its slot must hold its own tiles, and unpacking a gathered buffer built with
+    numpy from ANOTHER pair of maps must overwrite exactly the other ranks' tiles and nothing else."""
+    rng = np.random.default_rng(seed)
+    H, W = pr.H, pr.W
+    e = pr.e
+    def rand_rects(n):
+        out = []
+        for _ in range(n):
+            w, h = int(rng.integers(1, min(40, W))), int(rng.integers(1, min(30, H)))
+            out.append((int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h))
+        return np.array(out, np.int32).reshape(-1, 4)
+    # disjoint tiles per rank are what the optimiser produces; overlapping ones are fine for pack and make unpack order-dependent, so
+    # the test uses a tiling: vertical bands of the image, dealt to the ranks
+    bands = np.linspace(0, W, 8).astype(int)
+    rects = [[], [], []]
+    for i in range(7):
+        x0, x1 = int(bands[i]), int(bands[i + 1])
+        ys = np.sort(rng.choice(np.arange(1, H), 2, replace=False))
+        for (y0, y1) in ((0, int(ys[0])), (int(ys[0]), int(ys[1])), (int(ys[1]), H)):
+            rects[int(rng.integers(0, 3))].append((x0, y0, x1 - x0, y1 - y0))
+    rects[2].append((0, 0, 0, 0))                                             # an empty rect is legal
+    rects = [np.array(r, np.int32).reshape(-1, 4) for r in rects]
+    x = api.Exchange(e, 1, rects)
+    npx = [int(sum(int(r[2]) * int(r[3]) for r in rr)) for rr in rects]
+    lmax = (max(npx) + 3) // 4 * 4
+    assert x.slot_floats == 5 * lmax
+    lab = rng.normal(size=(H, W, 4)).astype(np.float32)
+    cost = rng.normal(size=(H, W)).astype(np.float32)
+    other_lab = rng.normal(size=(H, W, 4)).astype(np.float32)
+    other_cost = rng.normal(size=(H, W)).astype(np.float32)
+
+    def np_slot(rr, L, Cm):
+        sl = np.zeros(5 * lmax, np.float32)
+        off = 0
+        for (rx, ry, rw, rh) in rr:
+            n = int(rw) * int(rh)
+            sl[4 * off: 4 * (off + n)] = L[ry:ry + rh, rx:rx + rw].reshape(-1)
+            sl[4 * lmax + off: 4 * lmax + off + n] = Cm[ry:ry + rh, rx:rx + rw].reshape(-1)
+            off += n
+        return sl
+    d_lab, d_cost = api.DeviceBuffer(e, lab.nbytes), api.DeviceBuffer(e, cost.nbytes)
+    d_slot, d_recv = api.DeviceBuffer(e, 20 * lmax), api.DeviceBuffer(e, 60 * lmax)
+    d_lab.upload(lab); d_cost.upload(cost); d_slot.fill(0)
+    x.pack(d_lab.ptr, d_cost.ptr, d_slot.ptr)
+    e.synchronize()
+    got = d_slot.download((5 * lmax,), np.float32)
+    ref = np_slot(rects[1], lab, cost)
+    used = npx[1]
+    assert np.array_equal(got[: 4 * used], ref[: 4 * used]) and np.array_equal(got[4 * lmax: 4 * lmax + used], ref[4 * lmax: 4 * lmax + used])
+    gathered = np.concatenate([np_slot(rects[0], other_lab, other_cost), np.full(5 * lmax, np.nan, np.float32), np_slot(rects[2], other_lab, other_cost)])
+    d_recv.upload(gathered)
+    x.unpack(d_recv.ptr, d_lab.ptr, d_cost.ptr)
+    e.synchronize()
+    lab2, cost2 = d_lab.download((H, W, 4), np.float32), d_cost.download((H, W), np.float32)
+    exp_lab, exp_cost = lab.copy(), cost.copy()
+    for r in (0, 2):
+        for (rx, ry, rw, rh) in rects[r]:
+            exp_lab[ry:ry + rh, rx:rx + rw] = other_lab[ry:ry + rh, rx:rx + rw]
+            exp_cost[ry:ry + rh, rx:rx + rw] = other_cost[ry:ry + rh, rx:rx + rw]
+    assert np.array_equal(lab2, exp_lab) and np.array_equal(cost2, exp_cost)
+    # errors: a rect outside the image, a first[] table that does not cover the rects
+    try:
+        api.Exchange(e, 0, [np.array([(W - 2, 0, 5, 5)], np.int32)])
+        raise AssertionError("a rect outside the image was accepted")
+    except api.LesHipError as ex:
+        assert "outside the image" in str(ex)
+    for b_ in (d_lab, d_cost, d_slot, d_recv):
+        b_.free()
+    x.destroy()
+    return sum(npx)
+
+
 def case_stereo_driver(lib, device, units=(16,), pmInit=1, maxIteration=1):
     """The Python FastGCStereo mirror end to end on the (padded) cones crop with config 1's energy, two views:
     PatchMatch iteration(s), graph-cut iteration(s), left-right post-processing, Evaluator rows."""

@@ -367,6 +367,48 @@ def test_gpu_device_maxflow_against_independent_checkers(mid):
     print(f"device max-flow vs brute force: {n} cells of at most 4 x 4 nodes, canonical cut reproduced exactly")
 
 
+def test_gpu_exchange_pack_unpack(mid):
+    assert pc.case_exchange_pack_unpack(mid) > 0
+
+
+def test_gpu_exchange_tiles_over_rccl(mid):
+    """les_hip_exchange_tiles on a REAL RCCL communicator created by the host (here: ctypes on librccl, one rank -- the box has one GPU):
+    the library resolves ncclAllGather itself, packs, gathers and unpacks on the context's stream.  With one rank the maps must come
+    back unchanged; the multi-rank semantics of pack / unpack are covered by case_exchange_pack_unpack and the world-2/4 gloo tests."""
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        e = mid.e
+        rects = np.array([(3, 5, 40, 30), (100, 200, 45, 45), (0, 0, 1, 1)], np.int32)
+        x = pc.api.Exchange(e, 0, [rects])
+        rng = np.random.default_rng(0)
+        lab, cost = rng.normal(size=(mid.H, mid.W, 4)).astype(np.float32), rng.normal(size=(mid.H, mid.W)).astype(np.float32)
+        d_lab, d_cost = pc.api.DeviceBuffer(e, lab.nbytes), pc.api.DeviceBuffer(e, cost.nbytes)
+        d_lab.upload(lab); d_cost.upload(cost)
+        for _ in range(3):
+            x.tiles(comm.value, d_lab.ptr, d_cost.ptr)
+        e.synchronize()
+        assert np.array_equal(d_lab.download(lab.shape, np.float32), lab) and np.array_equal(d_cost.download(cost.shape, np.float32), cost)
+        with pytest.raises(pc.api.LesHipError, match="need an ncclComm_t"):
+            x2 = pc.api.Exchange(e, 0, [rects, rects[:1]])
+            x2.tiles(0, d_lab.ptr, d_cost.ptr)
+        d_lab.free(); d_cost.free(); x.destroy()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_gpu_device_cuts_fall_back_to_the_host(oracle_mod, monkeypatch):
     """A device max-flow that gives up (iteration limit 0) reports every cell, the lock-step is then cut on the host: the iteration
     must equal, bit for bit, the one with device cuts switched off."""

@@ -210,6 +210,10 @@ def test_sim_device_maxflow_against_independent_checkers(cones):
     pc.case_device_maxflow_vs_brute_force(cones, seed=9, ncells=12)
 
 
+def test_sim_exchange_pack_unpack(cones):
+    assert pc.case_exchange_pack_unpack(cones) > 0
+
+
 def test_sim_graph_cut_iterations(sim_lib, oracle_mod, monkeypatch):
     """PatchMatch + graph-cut iterations through the Python driver: simulator proposals / unary costs, host cuts.
     (Driver and host-cut logic are under test: the fiber simulator runs them on the 256-thread strip kernel, ~4x faster than on the
