@@ -112,6 +112,34 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     });
     return flow;
 }
+// Row bands of the parallel first max-flow phase: only for large regions (the coarsest layer: 4-6 cells of ~400 x 400 nodes per
+// lock-step, which leave most of the host idle), up to 8 bands.  Cells x bands may exceed the CPUs the process is granted (a cgroup
+// quota of 16 on the MI355X boxes): the helpers of such a lock-step then sleep instead of spinning between phases (tuneBandSpin).
+// The band count is a function of the region size ONLY (not of the machine or of how many cells a rank happens to cut in the
+// lock-step): the search order inside a cut -- and with float capacities possibly a tie between equal-energy cuts -- must not
+// depend on the host or on the world size.
+inline int bandsFor(const Rect& region, int /*cells_in_lockstep*/ = 0)
+{
+    const long long nodes = (long long)region.width * region.height;
+    if (nodes < 40000) return 1;
+    return (int)std::max<long long>(2, std::min<long long>(8, nodes / 20000));
+}
+
+// idle-helper policy of a lock-step of n cells (BandPool::spinLimit): spin only while every thread that could run has a CPU
+template <class RegionAt>
+inline void tuneBandSpin(int n, int team, RegionAt&& region_at)
+{
+    long long want = 0;
+    int big = 0;
+    for (int i = 0; i < n; i++) {
+        const int b = bandsFor(region_at(i), n);
+        if (b > 1) { want += b; big++; }
+    }
+    // at most `team` cells are cut at once
+    if (big > team && big > 0) want = want * team / big;
+    BandPool::spinLimit().store(want > cpuBudget() ? 64 : 20000, std::memory_order_relaxed);
+}
+
 inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, std::vector<uint8_t>& updateMask)
 {
     updateMask.resize((size_t)region.width * region.height);

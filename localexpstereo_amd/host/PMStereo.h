@@ -264,7 +264,8 @@ public:
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
                                 const auto& L = layermng.layers[li];
-                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : std::min(24, omp_get_max_threads())));
+                                // team of the host cuts: one thread per cell, at most 24, never more than the CPUs the process is granted
+                                const int nthreads = std::max(1, std::min(sb.n, hostThreads > 0 ? hostThreads : std::min({24, omp_get_max_threads(), std::max(1, cpuBudget())})));
                                 std::chrono::steady_clock::time_point tB, tC;
                                 if (devGraph) {
                                     const long long nodes = les_hip_batch_graph_nodes(sb.b);
@@ -305,10 +306,13 @@ public:
                                     if (ok) chk(les_hip_memcpy_d2h(ctx, payload.data(), d_payload, (size_t)nodes * 5 * sizeof(float)));
                                     if (!ok) break;
                                     tB = std::chrono::steady_clock::now();
+                                    // large cells (the coarser layers) split their max-flow over row bands on helper threads, like
+                                    // les_gc_solve_prebuilt does for non-C++ hosts (ExpansionMove.h: bandsFor / tuneBandSpin)
+                                    tuneBandSpin(sb.n, nthreads, [&](int n) { return L.sharedRegions[sb.cells[n]]; });
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
                                     for (int n = 0; n < sb.n; n++) {
                                         const Rect& region = L.sharedRegions[sb.cells[n]];
-                                        expansionMovePrebuilt(payload.data() + 5 * goff[n], 0.0, region, masks.data() + goff[n]);
+                                        expansionMovePrebuilt(payload.data() + 5 * goff[n], 0.0, region, masks.data() + goff[n], bandsFor(region, sb.n));
                                     }
                                     tC = std::chrono::steady_clock::now();
                                     chk(les_hip_memcpy_h2d(ctx, d_masks, masks.data(), (size_t)nodes));
