@@ -100,14 +100,19 @@ const StripEntry* find_strip(int R)
 
 // ---- the fixed-point march kernel (les_march.h): (radius, columns per job slot, job slots per workgroup, rows per block)
 typedef void (*MarchKernel)(les::Geom, les::MarchView, const les::Job*, const float4*, float*, int, int);
-struct MarchEntry { int R; int TW; int NJ; int NT; MarchKernel fn; };
+struct MarchEntry { int R; int TW; int NJ; int NT; int BY; MarchKernel fn; };
 #define LES_MARCH_ENTRY(R_, WGC_, NJ_, BY_) \
-    { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, les::les_march_kernel<R_, WGC_, NJ_, BY_> }
+    { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, BY_, les::les_march_kernel<R_, WGC_, NJ_, BY_> }
 // two geometries per radius: wide jobs (216 output columns: whole-image hypothesis slabs, layer-1/2 cells) and two narrow jobs
 // per workgroup (88 output columns each: layer-0 cells); both run 12 waves per workgroup
+// Radii: 10 (windR 20 / 21, the reference's default in both of its modes) and 7 (windR 14 / 15).  The pipeline needs 2R + 1 = 3 x BY rows per
+// ring (three ticks per unrolled loop iteration, three stage-2 buffers) with BY <= 8 rows per prefix pass, which 2R + 1 = 21 and 15 meet;
+// other radii run the strip kernel (R = 12 would need a 100-register ring in role D, R = 5 a block height of 11).
 const MarchEntry kMarch[] = {
     LES_MARCH_ENTRY(10, 256, 1, 7),
     LES_MARCH_ENTRY(10, 128, 2, 7),
+    LES_MARCH_ENTRY(7, 256, 1, 5),
+    LES_MARCH_ENTRY(7, 128, 2, 5),
 };
 static_assert((2 * 10 + 1) * (2 * 10 + 1) * (1ll << les::kMarchPB) < (1ll << 31), "stage-1 box sums must fit int32");
 // wide != 0: the entry with the widest jobs, else the one with the narrowest
@@ -327,7 +332,7 @@ bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, cons
                 }
                 if (njobs == 0) continue;
                 const long long wgs = (njobs + e->NJ - 1) / e->NJ;
-                const double ticks = (double)((rows + 4 * R + 6) / 7 + 3);
+                const double ticks = (double)((rows + 4 * R + e->BY - 1) / e->BY + 3);
                 // a partially filled last round costs as much as a full one; narrow jobs that leave most lanes idle cost the same tick
                 const double cost = (double)((wgs + ncu - 1) / ncu) * ticks * (1.0 + 1e-3 * (double)wgs / ncu) + (ro == (1 << 30) ? 0.0 : 1e-6);
                 if (cost < best) { best = cost; m = e; max_rows = ro; }

@@ -195,18 +195,25 @@ __device__ __forceinline__ void st_sbase(T* base, uint32_t byte_off, T v) { LES_
 // the rest of the block is still being consumed.  Written as plain C++ loads, the register allocator lands every reload in a
 // fresh tuple and copies it to the loop-carried one right away, i.e. waits for the load it has just issued.  The loads are
 // therefore issued as inline assembly with the destination TIED to the variable, and the vmcnt bookkeeping for them is done
-// by hand (this role issues no other vector-memory instruction): LES_STATS_WAIT(n, rows...) waits until at most n of this
+// by hand (this role issues no other vector-memory instruction): march_stats_wait3/6<n>(rows...) waits until at most n of this
 // wave's loads are outstanding and, by naming the rows as read-write operands, keeps their uses behind the wait.
 #if defined(LES_SIM)
 typedef float4 mstat4;
 #define LES_STATS_LOAD(dst, base, off, IMM) ((dst) = *(const float4*)((const char*)(base) + (off) + (IMM)))
-#define LES_STATS_WAIT3(n, r) ((void)0)
-#define LES_STATS_WAIT6(n, r, q) ((void)0)
+template <int N>
+__device__ inline void march_stats_wait3(float4 (&r)[3]) { (void)r; }
+template <int N>
+__device__ inline void march_stats_wait6(float4 (&r)[3], float4 (&q)[3]) { (void)r; (void)q; }
 #else
 typedef float mstat4 __attribute__((ext_vector_type(4)));
 #define LES_STATS_LOAD(dst, base, off, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "+v"(dst) : "v"(off), "s"(base))
-#define LES_STATS_WAIT3(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]))
-#define LES_STATS_WAIT6(n, r, q) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]))
+template <int N>
+__device__ __forceinline__ void march_stats_wait3(mstat4 (&r)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void march_stats_wait6(mstat4 (&r)[3], mstat4 (&q)[3])
+{
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : "n"(N));
+}
 #endif
 
 // measurement switches (ablations: the output is meaningless, the time shows what a resource costs): 1 role C issues no statistics
@@ -487,12 +494,12 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     LES_MARCH_SCHED_FENCE();
                     // loads are in flight in issue order: the BY rows of the previous tick (or of the initial issue), then the rows
                     // of this tick's earlier stages.  Younger than the last row of this stage: 3 loads for each of the other BY - N rows.
-                    static_assert(GC == 2 && BY == 7, "vmcnt bookkeeping below is written for stages of two rows and a block of seven");
+                    static_assert(GC == 2, "vmcnt bookkeeping below is written for stages of two rows");
                     {
                         mstat4 (&ra)[3] = st[LO];
                         mstat4 (&rb)[3] = st[LO + N - 1];
-                        if constexpr (N == 2) LES_STATS_WAIT6(15, ra, rb);
-                        else LES_STATS_WAIT3(18, ra);
+                        if constexpr (N == 2) march_stats_wait6<3 * (BY - 2)>(ra, rb);
+                        else march_stats_wait3<3 * (BY - 1)>(ra);
                     }
                     static_for<N>([&](auto jtag) {
                         constexpr int j = decltype(jtag)::value;

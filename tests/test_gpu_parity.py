@@ -89,10 +89,13 @@ def test_gpu_wta(mid):
 def test_gpu_other_radii(oracle_mod):
     # guided-filter radius = windR / 2: every radius instantiated in csrc/les_hip.hip (1..10, 12, 15)
     for windR, eps, th in ((2, 1e-2, 0.5), (4, 1e-3, 0.8), (6, 1e-4, 0.5), (8, 1e-4, 0.5), (10, 1e-4, 0.5), (12, 1e-4, 0.3),
-                           (14, 1e-4, 0.5), (16, 1e-5, 1.5), (18, 1e-4, 0.5), (24, 1e-4, 0.5), (30, 1e-3, 0.5)):
+                           (14, 1e-4, 0.5), (15, 1e-4, 0.5), (16, 1e-5, 1.5), (18, 1e-4, 0.5), (20, 1e-4, 0.5), (24, 1e-4, 0.5), (30, 1e-3, 0.5)):
         pr = pc.synth_pair(None, 90, 130, 10, windR=windR, eps=eps, th_col=th)
         try:
             layer = pc.om.Layer(pr.W, pr.H, windR, 11)
+            b = pc.api.Batch(pr.e, layer.filter[layer.sets[0]], layer.shared[layer.sets[0]])
+            assert b.kernel_kind(0) == (1 if windR // 2 in (7, 10) else 0), windR       # radii 7 and 10 are served by the march kernel
+            b.destroy()
             for s in (0, 6):
                 cells = layer.sets[s]
                 planes = pc.random_planes(len(cells), pr.D, pr.H, pr.W, 4 + s)

@@ -6,10 +6,10 @@
 # is what bench.py quotes as roofline.traffic.  Usage: bash tools/collect_profiles.sh [tag]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-round2}
+TAG=${1:-round3}
 O=gpurun_out/prof; mkdir -p $O
-B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0"
-rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --steps 100 --warmup 5 --cpu-planes 0 --sub-steps 0 > $O/stats.log 2>&1     # enough launches that the cold first ones do not weigh on the average
+B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0 --e2e 0"
+rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --steps 100 --warmup 5 --cpu-planes 0 --sub-steps 0 --e2e 0 > $O/stats.log 2>&1     # enough launches that the cold first ones do not weigh on the average
 python tools/prof_summary.py $O/stats --md > $O/${TAG}_kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_$c -- $B > $O/pmc_$c.log 2>&1
@@ -21,6 +21,12 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_
 python tools/prof_summary.py $O/pmc_sq les_march_kernel --md > $O/pmc_sq.md
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $O/pmc_lds -- $B > $O/pmc_lds.log 2>&1
 python tools/prof_summary.py $O/pmc_lds les_march_kernel --md > $O/pmc_lds.md
+# the optimiser's geometry (H3: 240 cell-batched launches per step) and the end-to-end run (MidV3 loop, one view): kernel-trace stats
+rocprofv3 --kernel-trace --stats -d $O/h3 -- python bench.py --workload h3 --steps 20 --warmup 2 --cpu-planes 0 --sub-steps 0 --e2e 0 > $O/h3.log 2>&1
+python tools/prof_summary.py $O/h3 --md > $O/${TAG}_h3_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d $O/e2e -- python tools/e2e_bench.py > $O/e2e.log 2>&1
+python tools/prof_summary.py $O/e2e --md > $O/${TAG}_e2e_kernel_stats.md
+rm -rf $O/h3 $O/e2e
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/cal_FETCH_SIZE $O/cal_WRITE_SIZE $O/pmc_sq $O/pmc_lds
 python - "$O" "$TAG" <<'PY'
 import json, re, sys, os
