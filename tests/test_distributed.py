@@ -53,8 +53,8 @@ def _run_uncached(world, out, H, W, D, iters, gc_iters, kernel, worker, port):
 
 
 def test_two_ranks_equal_one_rank(tmp_path, oracle_mod):
-    one = _run(1, str(tmp_path / "one.npz"), H=40, W=56, D=8)
-    two = _run(2, str(tmp_path / "two.npz"), H=40, W=56, D=8)
+    one = _run(1, str(tmp_path / "one.npz"), H=36, W=50, D=8)
+    two = _run(2, str(tmp_path / "two.npz"), H=36, W=50, D=8)
     assert int(one["bytes_exchanged"]) == 0 and int(two["bytes_exchanged"]) > 0
     assert one["labels"].tobytes() == two["labels"].tobytes()
     assert one["cur"].tobytes() == two["cur"].tobytes()
