@@ -19,6 +19,7 @@
 #include <omp.h>
 
 #include <chrono>
+#include <functional>
 #include <memory>
 
 #include "ExpansionMove.h"
@@ -178,37 +179,73 @@ public:
         bool ok = true;
         auto chk = [&](int rc) { if (rc != LES_HIP_OK) { if (ok) fprintf(stderr, "PMStereo::runDevice: %s\n", les_hip_last_error()); ok = false; } };
         // prepared geometry: one batch per (layer, disjoint set) + the init batch (unit +- windR -> unit)
-        struct SetBatch { les_hip_batch* b = nullptr; uint64_t* rng = nullptr; les_hip_plane* planes = nullptr; int n = 0; std::vector<int> cells; };
+        // Several ranks (one process per GPU): the cells of every disjoint set are dealt out in contiguous bands, rank r owns
+        // cells [n r / world, n (r + 1) / world) of the set; volume, statistics and maps are replicated, and after a set's lock-steps the tiles
+        // (target rects) of all ranks are published with one all-gather (les_hip_exchange_*).  Only with device-built graphs: the solution
+        // then lives on the device and the host keeps no state that would have to follow the exchange.
+        if (world > 1 && maxIteration > 0 && (!deviceGraph || checkFlowEnergy)) { fprintf(stderr, "PMStereo::runDevice: several ranks need deviceGraph and no self-check\n"); return false; }
+        if (world > 1 && viewModes.size() > 1) { fprintf(stderr, "PMStereo::runDevice: with several ranks give each view its own group of ranks (one view per call)\n"); return false; }
+        struct SetBatch { les_hip_batch* b = nullptr; uint64_t* rng = nullptr; les_hip_plane* planes = nullptr; int n = 0; std::vector<int> cells; les_hip_exchange* x = nullptr; };
         std::vector<std::vector<SetBatch>> batches(layermng.layers.size());
-        auto make = [&](const std::vector<Rect>& fr, const std::vector<Rect>& tr, const std::vector<Rect>& un, const std::vector<uint64_t>& st) {
+        // all = the indices of the set's cells into the layer's rect arrays; tr / fr / un / st are indexed by cell
+        auto make = [&](const std::vector<int>& all, const std::vector<Rect>& frs, const std::vector<Rect>& trs, const std::vector<Rect>& uns, const std::vector<uint64_t>& sts) {
             SetBatch sb;
-            sb.n = (int)fr.size();
+            const int n = (int)all.size();
+            std::vector<int> first((size_t)world + 1);
+            for (int r = 0; r <= world; r++) first[(size_t)r] = (int)((long long)n * r / world);
+            std::vector<Rect> fr, tr, un;
+            std::vector<uint64_t> st;
+            for (int i = first[(size_t)rank]; i < first[(size_t)rank + 1]; i++) {
+                const int c = all[(size_t)i];
+                sb.cells.push_back(c); fr.push_back(frs[(size_t)c]); tr.push_back(trs[(size_t)c]); un.push_back(uns[(size_t)c]); st.push_back(sts[(size_t)c]);
+            }
+            sb.n = (int)sb.cells.size();
             chk(les_hip_batch_create(ctx, sb.n, reinterpret_cast<const les_hip_rect*>(fr.data()), reinterpret_cast<const les_hip_rect*>(tr.data()), 0, &sb.b));
-            if (sb.b) chk(les_hip_batch_set_units(ctx, sb.b, reinterpret_cast<const les_hip_rect*>(un.data())));
+            if (sb.b && sb.n > 0) chk(les_hip_batch_set_units(ctx, sb.b, reinterpret_cast<const les_hip_rect*>(un.data())));
             chk(les_hip_malloc(ctx, (void**)&sb.rng, sizeof(uint64_t) * std::max(1, sb.n)));
             chk(les_hip_malloc(ctx, (void**)&sb.planes, sizeof(les_hip_plane) * std::max(1, sb.n)));
-            if (ok) chk(les_hip_memcpy_h2d(ctx, sb.rng, st.data(), sizeof(uint64_t) * sb.n));
+            if (ok && sb.n > 0) chk(les_hip_memcpy_h2d(ctx, sb.rng, st.data(), sizeof(uint64_t) * sb.n));
+            if (world > 1) {
+                std::vector<Rect> every;
+                for (int c : all) every.push_back(trs[(size_t)c]);
+                chk(les_hip_exchange_create(ctx, rank, world, n, reinterpret_cast<const les_hip_rect*>(every.data()), first.data(), &sb.x));
+            }
             return sb;
+        };
+        // publish the tiles of the set this rank updated: on the host's RCCL communicator, or through gatherFn (another transport / tests)
+        float *d_xsend = nullptr, *d_xrecv = nullptr;
+        long long xcap = 0;
+        auto exchange = [&](SetBatch& sb, les_hip_plane* d_lab, float* d_cost) {
+            if (world == 1 || !sb.x || !ok) return;
+            if (!gatherFn) { chk(les_hip_exchange_tiles(ctx, sb.x, ncclComm, d_lab, d_cost)); return; }
+            const long long slot = les_hip_exchange_slot_floats(sb.x);
+            if (slot == 0) return;
+            if (slot > xcap) {
+                if (d_xsend) les_hip_free(ctx, d_xsend);
+                if (d_xrecv) les_hip_free(ctx, d_xrecv);
+                d_xsend = d_xrecv = nullptr;
+                xcap = slot;
+                chk(les_hip_malloc(ctx, (void**)&d_xsend, sizeof(float) * (size_t)slot));
+                chk(les_hip_malloc(ctx, (void**)&d_xrecv, sizeof(float) * (size_t)slot * (size_t)world));
+            }
+            chk(les_hip_exchange_pack(ctx, sb.x, d_lab, d_cost, d_xsend));
+            chk(les_hip_synchronize(ctx));
+            if (ok) gatherFn(rank, d_xsend, d_xrecv, slot);
+            chk(les_hip_exchange_unpack(ctx, sb.x, d_xrecv, d_lab, d_cost));
         };
         const Rect image(0, 0, width, height);
         for (size_t li = 0; li < layermng.layers.size() && ok; li++) {
             const auto& L = layermng.layers[li];
-            for (const auto& set : L.disjointRegionSets) {
-                std::vector<Rect> fr, tr, un;
-                std::vector<uint64_t> st;
-                for (int r : set) { fr.push_back(L.filterRegions[r]); tr.push_back(L.sharedRegions[r]); un.push_back(L.unitRegions[r]); st.push_back(rngStates[li][r]); }
-                SetBatch sb = make(fr, tr, un, st);
-                sb.cells = set;
-                batches[li].push_back(sb);
-            }
+            for (const auto& set : L.disjointRegionSets) batches[li].push_back(make(set, L.filterRegions, L.sharedRegions, L.unitRegions, rngStates[li]));
         }
         SetBatch init;
         {
             const auto& L = layermng.layers[0];
             std::vector<Rect> fr;
+            std::vector<int> all(L.unitRegions.size());
             const int R = params.windR;
-            for (const Rect& u : L.unitRegions) fr.push_back(Rect(u.x - R, u.y - R, u.width + 2 * R, u.height + 2 * R) & image);
-            init = make(fr, L.unitRegions, L.unitRegions, rngStates[0]);
+            for (size_t i = 0; i < L.unitRegions.size(); i++) { const Rect& u = L.unitRegions[i]; all[i] = (int)i; fr.push_back(Rect(u.x - R, u.y - R, u.width + 2 * R, u.height + 2 * R) & image); }
+            init = make(all, fr, L.unitRegions, L.unitRegions, rngStates[0]);
         }
         les_hip_plane* d_labels = nullptr;
         float *d_cur = nullptr, *d_prop = nullptr;
@@ -220,19 +257,25 @@ public:
             if (!ok) break;
             // initCurrentFast on the device: random label per layer-0 cell, cost of its unit region
             chk(les_hip_memset(ctx, d_labels, 0, P * sizeof(les_hip_plane)));
-            chk(les_hip_batch_propose(ctx, init.b, LES_HIP_PROPOSE_INIT, 0, d_labels, init.rng, init.planes));
-            chk(les_hip_batch_run(ctx, init.b, mode, init.planes, 1, d_cur, 1));
+            chk(les_hip_memset(ctx, d_cur, 0, P * sizeof(float)));
+            if (init.n > 0) {
+                chk(les_hip_batch_propose(ctx, init.b, LES_HIP_PROPOSE_INIT, 0, d_labels, init.rng, init.planes));
+                chk(les_hip_batch_run(ctx, init.b, mode, init.planes, 1, d_cur, 1));
+            }
+            exchange(init, d_labels, d_cur);
             for (int iteration = 0; iteration < pmInit && ok; iteration++)
                 for (size_t li = 0; li < batches.size(); li++)
-                    for (SetBatch& sb : batches[li])
+                    for (SetBatch& sb : batches[li]) {
                         for (const ProposerSpec& spec : layerProposers[li])
-                            for (int it = 0; it < spec.K; it++) {
+                            for (int it = 0; it < spec.K && sb.n > 0; it++) {
                                 const int m = iteration + it;
                                 if (spec.kind == LES_HIP_PROPOSE_RANDOM && randomWidth(m) < 0.1) break;      // LES/Proposer.h:149-152
                                 chk(les_hip_batch_propose(ctx, sb.b, spec.kind, m, d_labels, sb.rng, sb.planes));
                                 chk(les_hip_batch_run(ctx, sb.b, mode, sb.planes, 1, d_prop, 1));
                                 chk(les_hip_batch_wta(ctx, sb.b, sb.planes, d_cur, d_prop, d_labels));
                             }
+                        exchange(sb, d_labels, d_cur);
+                    }
             chk(les_hip_synchronize(ctx));
             if (ok) {
                 chk(les_hip_memcpy_d2h(ctx, currentLabeling_[mode].data.data(), d_labels, P * sizeof(les_hip_plane)));
@@ -255,9 +298,9 @@ public:
             const bool devGraph = deviceGraph && !checkFlowEnergy;
             for (int iteration = 0; iteration < maxIteration && ok; iteration++)
                 for (size_t li = 0; li < batches.size(); li++)
-                    for (SetBatch& sb : batches[li])
+                    for (SetBatch& sb : batches[li]) {
                         for (const ProposerSpec& spec : layerProposers[li])
-                            for (int it = 0; it < spec.K && ok; it++) {
+                            for (int it = 0; it < spec.K && ok && sb.n > 0; it++) {
                                 const int m = iteration + it;
                                 if (spec.kind == LES_HIP_PROPOSE_RANDOM && randomWidth(m) < 0.1) break;
                                 const auto tA = std::chrono::steady_clock::now();
@@ -338,6 +381,8 @@ public:
                                 gcSeconds[2] += std::chrono::duration<double>(tD - tC).count();
                                 gcLockSteps++;
                             }
+                        exchange(sb, d_labels, d_cur);
+                    }
             if (devGraph && maxIteration > 0 && ok) {
                 chk(les_hip_synchronize(ctx));
                 chk(les_hip_memcpy_d2h(ctx, currentLabeling_[mode].data.data(), d_labels, P * sizeof(les_hip_plane)));
@@ -351,8 +396,10 @@ public:
         if (ok && viewModes.size() == 2) ok = postProcess(1.5f);
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (auto& lb : batches)
-            for (SetBatch& sb : lb) { les_hip_batch_destroy(sb.b); les_hip_free(ctx, sb.rng); les_hip_free(ctx, sb.planes); }
-        les_hip_batch_destroy(init.b); les_hip_free(ctx, init.rng); les_hip_free(ctx, init.planes);
+            for (SetBatch& sb : lb) { les_hip_batch_destroy(sb.b); les_hip_free(ctx, sb.rng); les_hip_free(ctx, sb.planes); les_hip_exchange_destroy(sb.x); }
+        les_hip_batch_destroy(init.b); les_hip_free(ctx, init.rng); les_hip_free(ctx, init.planes); les_hip_exchange_destroy(init.x);
+        if (d_xsend) les_hip_free(ctx, d_xsend);
+        if (d_xrecv) les_hip_free(ctx, d_xrecv);
         les_hip_free(ctx, d_labels); les_hip_free(ctx, d_cur); les_hip_free(ctx, d_prop);
         return ok;
     }
@@ -408,6 +455,13 @@ public:
     bool deviceCuts = true;             // runDevice: cells of at most LES_HIP_MAXFLOW_MAX_NODES nodes are cut on the GPU as well
     long gcCellsCutOnDevice = 0;
     int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: at most 24 and one per cell -- larger teams are slower)
+    // runDevice on several GPUs (one process -- or, in the self-test, one host thread -- per GPU): this rank's place among the ranks that share
+    // the view's cells, and the transport of the per-set tile exchange: the host's ncclComm_t (RCCL; les_hip_exchange_tiles enqueues pack,
+    // ncclAllGather and unpack on the context's stream) or, when set, gatherFn(rank, d_send, d_recv, slot_floats), which must leave every
+    // rank's slot in d_recv[r * slot_floats ..] (another transport; les_host_demo's two-ranks-on-one-GPU self-test).
+    int rank = 0, world = 1;
+    void* ncclComm = nullptr;
+    std::function<void(int, const float*, float*, long long)> gatherFn;
 
 private:
     static uint64_t splitmix(uint64_t x)

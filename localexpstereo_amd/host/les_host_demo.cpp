@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <memory>
 
 #include "MaxFlow.h"
@@ -263,6 +266,72 @@ static int cmd_full(int argc, char** argv)
     return fail;
 }
 
+// Two ranks of the sharded device driver on ONE GPU (two host threads, two contexts), the per-set tile exchange going through
+// les_hip_exchange_pack / _unpack and a loop-back transport in host memory instead of RCCL: the result of every rank must equal the
+// single-rank run bit for bit.  (On a multi-GPU node the same driver runs with one process per GPU and PMStereo::ncclComm.)
+static int cmd_ranks(int argc, char** argv)
+{
+    const int W = argc > 2 ? atoi(argv[2]) : 240, H = argc > 3 ? atoi(argv[3]) : 160, D = argc > 4 ? atoi(argv[4]) : 32;
+    const int world = argc > 5 ? atoi(argv[5]) : 2;
+    Scene s = make_scene(W, H, D);
+    Parameters param(1.0f, 20, "GF", 1e-4f);
+    param.th_col = 0.5f;
+    const float maxdisp = (float)D - 1;
+    auto build = [&]() {
+        auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
+        st->setSeed(7);
+        st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp));
+        st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
+        st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+        return st;
+    };
+    auto one = build();
+    double sec1 = 0;
+    if (!one->runDevice(1, {0}, &sec1, 1)) { printf("FAIL: runDevice (one rank)\n"); return 1; }
+    // loop-back "all-gather": every rank stages its slot in host memory, a barrier, every rank uploads all slots
+    struct Loop {
+        std::mutex m; std::condition_variable cv; int arrived = 0, gen = 0, world = 1;
+        std::vector<std::vector<float>> slots;
+        void barrier() { std::unique_lock<std::mutex> lk(m); const int g = gen; if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+    } loop;
+    loop.world = world; loop.slots.resize((size_t)world);
+    std::vector<std::unique_ptr<PMStereo>> ranks((size_t)world);
+    std::vector<int> okv((size_t)world, 0);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; r++)
+        threads.emplace_back([&, r] {
+            auto st = build();
+            st->rank = r; st->world = world;
+            les_hip_ctx* c = static_cast<const HipCostVolumeEnergy&>(st->getEnergyInstance()).handle();
+            st->gatherFn = [&loop, c, world](int rank, const float* d_send, float* d_recv, long long slot) {
+                loop.slots[(size_t)rank].resize((size_t)slot);
+                les_hip_memcpy_d2h(c, loop.slots[(size_t)rank].data(), d_send, sizeof(float) * (size_t)slot);
+                loop.barrier();
+                for (int q = 0; q < world; q++) les_hip_memcpy_h2d(c, d_recv + (size_t)q * (size_t)slot, loop.slots[(size_t)q].data(), sizeof(float) * (size_t)slot);
+                loop.barrier();
+            };
+            double sec = 0;
+            okv[(size_t)r] = st->runDevice(1, {0}, &sec, 1) ? 1 : 0;
+            ranks[(size_t)r] = std::move(st);
+        });
+    for (auto& t : threads) t.join();
+    int fail = 0;
+    for (int r = 0; r < world; r++) {
+        if (!okv[(size_t)r]) { printf("FAIL: runDevice (rank %d of %d)\n", r, world); fail = 1; continue; }
+        size_t diff = 0, dcost = 0;
+        for (size_t i = 0; i < one->currentLabeling_[0].data.size(); i++) {
+            diff += !(ranks[(size_t)r]->currentLabeling_[0].data[i] == one->currentLabeling_[0].data[i]);
+            dcost += ranks[(size_t)r]->currentCost_[0].data[i] != one->currentCost_[0].data[i];
+        }
+        printf("rank %d of %d: %zu label and %zu cost differences against the single-rank run (%ld cells cut on this rank's GPU, %ld lock-steps)\n", r, world, diff,
+               dcost, ranks[(size_t)r]->gcCellsCutOnDevice, ranks[(size_t)r]->gcLockSteps);
+        if (diff || dcost) fail = 1;
+    }
+    printf("single rank: E=%.1f bad1.0=%.2f%% (%.3f s)\n", one->totalEnergy(0), bad_pixels(one->computeDisparities(0), s, 1.0f), sec1);
+    printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
+    return fail;
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "layers")) return cmd_layers(argc, argv);
@@ -270,6 +339,14 @@ int main(int argc, char** argv)
     if (argc >= 2 && !strcmp(argv[1], "run")) {
         try {
             return cmd_run(argc, argv);
+        } catch (const std::exception& e) {
+            printf("les_host_demo: %s\n", e.what());
+            return 3;
+        }
+    }
+    if (argc >= 2 && !strcmp(argv[1], "ranks")) {
+        try {
+            return cmd_ranks(argc, argv);
         } catch (const std::exception& e) {
             printf("les_host_demo: %s\n", e.what());
             return 3;
@@ -283,6 +360,6 @@ int main(int argc, char** argv)
             return 3;
         }
     }
-    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters] | full [W H D iters pmInit]\n");
+    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters] | full [W H D iters pmInit] | ranks [W H D world]\n");
     return 2;
 }

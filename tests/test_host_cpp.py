@@ -62,6 +62,17 @@ def test_host_demo_full_size_on_gpu(demo):
     assert sec < 30.0, sec          # (15 s on the MI355X box: 13.5 s of it are the host cuts of layers 1-2 on this scene's graphs, 1.3 s the GPU side)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_demo_sharded_ranks_on_one_gpu(demo, world):
+    """The C++ host's multi-rank path (PMStereo::runDevice with rank / world: bands of cells per rank, per-set tile exchange through
+    les_hip_exchange_pack / _unpack) with 2 and 3 ranks as host threads on the one GPU and a loop-back transport: PatchMatch + graph-cut
+    iteration, every rank bit-equal to the single-rank run."""
+    r = subprocess.run([demo, "ranks", "240", "160", "32", str(world)], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
+
+
 def test_host_graph_cut_selfcheck(demo):
     """Local expansion moves on the host (ExpansionMove.h over MaxFlow.h): brute-force optimality on tiny regions, the
     reference's flow == energy self-check (LES/FastGCStereo.h:561-594) on every move, monotone energy, convergence."""
