@@ -187,7 +187,15 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
 #define LES_PIN_U32(x) asm volatile("" : "+v"(x))
 #endif
 template <class T>
-__device__ __forceinline__ T ld_sbase(const T* base, uint32_t byte_off) { LES_PIN_U32(byte_off); return *(const T*)((const char*)base + byte_off); }
+__device__ __forceinline__ T ld_sbase(const T* base, uint32_t byte_off)
+{
+    LES_PIN_U32(byte_off);
+#if defined(LES_VOL_NT) && !defined(LES_SIM)
+    return __builtin_nontemporal_load((const T*)((const char*)base + byte_off));      // measurement switch: streaming loads of volume / guide rows
+#else
+    return *(const T*)((const char*)base + byte_off);
+#endif
+}
 template <class T>
 __device__ __forceinline__ void st_sbase(T* base, uint32_t byte_off, T v) { LES_PIN_U32(byte_off); *(T*)((char*)base + byte_off) = v; }
 
@@ -206,7 +214,10 @@ template <int N>
 __device__ inline void march_stats_wait6(float4 (&r)[3], float4 (&q)[3]) { (void)r; (void)q; }
 #else
 typedef float mstat4 __attribute__((ext_vector_type(4)));
-#define LES_STATS_LOAD(dst, base, off, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "+v"(dst) : "v"(off), "s"(base))
+#ifndef LES_STATS_POLICY
+#define LES_STATS_POLICY ""        // cache-policy bits of the statistics loads (measurement switch: " nt", " sc0", " sc1", " sc0 sc1")
+#endif
+#define LES_STATS_LOAD(dst, base, off, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM LES_STATS_POLICY : "+v"(dst) : "v"(off), "s"(base))
 template <int N>
 __device__ __forceinline__ void march_stats_wait3(mstat4 (&r)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : "n"(N)); }
 template <int N>
