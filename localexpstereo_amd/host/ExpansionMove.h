@@ -13,6 +13,7 @@
 
 #include "BandPool.h"
 #include "GridMaxFlow.h"
+#include "GridPushRelabel.h"
 #include "StereoEnergy.h"
 
 namespace les_host {
@@ -89,6 +90,29 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
 // include/localexp_hip.h: les_hip_batch_expansion_graph).
 // mask: region.width * region.height bytes (255 = take the proposal).  The solver object is reused per thread.
 // bands > 1: parallel first phase of the max-flow on that many row bands (large regions when few cells share a lock-step)
+// Solver policy for device-built graphs.  Boykov-Kolmogorov (GridMaxFlow.h, band-parallel first phase for large cells) is the faster
+// solver on the common, easy moves; on the moves where a large part of a coarse cell switches it degrades (tools/cpp/prbench.cpp: 250 ms
+// against 90 ms for push-relabel on a 387 x 387 cell).  So cells of at least pushRelabelMinNodes() nodes get a work budget of
+// kBkOpsPerNode search operations per node; when it runs out, the flow routed so far is kept and FIFO push-relabel (GridPushRelabel.h)
+// finishes on the residual graph.  Both return the canonical cut; budget and threshold are functions of the region size only, so every
+// rank and every host cuts a given cell the same way.  LES_GC_PUSH_RELABEL_MIN_NODES overrides the threshold (0: never switch),
+// LES_GC_BK_OPS_PER_NODE the budget (A/B measurements).
+inline long long pushRelabelMinNodes()
+{
+    static const long long v = [] {
+        const char* e = getenv("LES_GC_PUSH_RELABEL_MIN_NODES");
+        if (!e) return 10000ll;
+        const long long x = atoll(e);
+        return x <= 0 ? (1ll << 62) : x;
+    }();
+    return v;
+}
+inline double bkOpsPerNode()
+{
+    static const double v = [] { const char* e = getenv("LES_GC_BK_OPS_PER_NODE"); return e ? atof(e) : 12.0; }();
+    return v;
+}
+
 inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, uint8_t* mask, int bands = 1)
 {
     static thread_local GridMaxFlow graph_tls;
@@ -105,7 +129,26 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
             for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
     });
     graph.set_base_flow(base_flow);
-    const double flow = graph.maxflow(bands);
+    const bool budgeted = (long long)w * h >= pushRelabelMinNodes();
+    const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0);
+    if (graph.exhausted()) {
+        // a hard move: push-relabel continues from the feasible flow found so far
+        static thread_local GridPushRelabel pr_tls;
+        GridPushRelabel& pr = pr_tls;
+        pr.reset_for_load(w, h);
+        rows_parallel([&](int y0, int y1) {
+            float rc8[8], tr;
+            for (int y = y0; y < y1; y++)
+                for (int x = 0; x < w; x++) { graph.residual(x, y, rc8, &tr); pr.load_residual(x, y, rc8, tr); }
+        });
+        pr.set_base_flow(flow);
+        const double total = pr.maxflow();
+        rows_parallel([&](int y0, int y1) {
+            for (int y = y0; y < y1; y++)
+                for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = pr.what_segment(x, y) == GridPushRelabel::SOURCE ? 255 : 0;
+        });
+        return total;
+    }
     rows_parallel([&](int y0, int y1) {
         for (int y = y0; y < y1; y++)
             for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;

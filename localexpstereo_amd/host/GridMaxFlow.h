@@ -95,13 +95,18 @@ public:
     // valid), then one search continues on the whole graph from the union of the trees with the nodes next to the band
     // borders re-activated (the standard "capacities increased, reuse the trees" continuation).  The final flow is a
     // maximum flow of the whole graph, so the cut read-out is the same as for bands == 1.
-    double maxflow(int bands = 1)
+    // ops_per_node > 0: give up after that much search work per node (hard instances: the caller continues with push-relabel on the
+    // residual graph, see exhausted() / residual()); the band searches of the parallel first phase get the same allowance per band node
+    double maxflow(int bands = 1, double ops_per_node = 0.0)
     {
+        exhausted_ = false;
         if (bands > h_ / 8) bands = h_ / 8;                      // at least 8 rows per band
         if (bands > 64) bands = 64;
+        const long long budget = ops_per_node > 0 ? (long long)(ops_per_node * w_ * h_) + 1 : 0;
         if (bands <= 1) {
+            main_.budget = budget;
             init_trees(main_, 0, h_);
-            search(main_);
+            exhausted_ = !search(main_);
             return flow_ + main_.flow;
         }
         std::vector<int> row0(bands + 1);
@@ -113,8 +118,9 @@ public:
         std::vector<Ctx> ctx(bands);
         BandPool::mine().run(bands, [&](int b) {
             ctx[b].band = b;
+            ctx[b].budget = budget > 0 ? budget * (row0[b + 1] - row0[b]) / h_ + 1 : 0;
             init_trees(ctx[b], row0[b], row0[b + 1]);
-            search(ctx[b]);
+            search(ctx[b]);                                      // (a band that runs out of budget just leaves more for the whole-graph search)
         });
         // continuation on the whole graph
         main_ = Ctx();
@@ -129,8 +135,18 @@ public:
                     if (nodes_[i].parent != P_NONE) set_active(main_, i);
                 }
             }
-        search(main_);
+        main_.budget = budget;
+        exhausted_ = !search(main_);
         return flow_ + main_.flow;
+    }
+    // after maxflow(..., ops_per_node): true = the budget ran out; the return value is then the flow routed so far and residual(x, y)
+    // the remaining problem (8 residual capacities E W S N SW NE SE NW + the terminal residual)
+    bool exhausted() const { return exhausted_; }
+    void residual(int x, int y, float* rc8, float* tr) const
+    {
+        const Node& n = nodes_[id(x, y)];
+        for (int k = 0; k < 8; k++) rc8[k] = n.rc[k];
+        *tr = n.tr;
     }
 
     termtype what_segment(int x, int y) const
@@ -163,11 +179,13 @@ private:
         int epoch = 0;                             // marks older than this come from another clock: not used by the re-parenting heuristic
         double flow = 0;
         int band = -1;                             // >= 0: restricted to this band
+        long long ops = 0, budget = 0;             // work done (grow steps, adoptions, steps of origin walks) / allowed (0: unlimited)
     };
 
     int w_, h_, pw_;
     int off_[8];
     double flow_;                                  // flow routed by the t-links while the graph was built
+    bool exhausted_ = false;
     std::vector<Node> nodes_;
     Ctx main_;
 
@@ -215,10 +233,16 @@ private:
     }
     void make_orphan(Ctx& c, int i) { nodes_[i].parent = P_ORPHAN; c.orphans.push_back(i); }
 
-    void search(Ctx& c)
+    // -> false when the work budget ran out (the flow routed so far is a feasible flow: the residual graph is a valid max-flow problem)
+    bool search(Ctx& c)
     {
         int current = NONE_NODE;
         for (;;) {
+            if (c.budget > 0 && c.ops > c.budget) {
+                if (current != NONE_NODE) nodes_[current].next_active = NOT_QUEUED;
+                return false;
+            }
+            c.ops++;
             int i = current;
             if (i != NONE_NODE) {
                 nodes_[i].next_active = NOT_QUEUED;
@@ -269,6 +293,7 @@ private:
                 c.orphan_head = 0;
             } else current = NONE_NODE;
         }
+        return true;
     }
 
     void augment(Ctx& c, int s, int k)
@@ -325,6 +350,7 @@ private:
     {
         int d = 0, k = j;
         for (;;) {
+            c.ops++;
             if (nodes_[k].ts == c.time) { d += nodes_[k].dist; break; }
             const int p = nodes_[k].parent;
             d++;
@@ -343,6 +369,7 @@ private:
     template <bool SINKTREE>
     void adopt(Ctx& c, int i)
     {
+        c.ops++;
         Node& ni = nodes_[i];
         int best = -1, best_d = std::numeric_limits<int>::max();
         for (int k = 0; k < 8; k++) {

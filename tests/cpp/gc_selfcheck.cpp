@@ -129,6 +129,85 @@ static int grid_vs_generic()
     return fail;
 }
 
+// GridPushRelabel (the solver of the coarsest layer's cells) against GridMaxFlow on random graphs in the device payload format (terminal
+// residual + caps E, S, SW, SE): integer-valued capacities keep the arithmetic exact, so flow and segments must be IDENTICAL -- the cut with
+// the largest source side is unique -- for tiny grids, single rows / columns, grids with no arcs, with only one kind of terminal, with huge
+// terminals next to small capacities, and for grids of a few thousand nodes where relabelling periods and gaps occur.
+static int push_relabel_vs_bk()
+{
+    RNG rng(4711);
+    int fail = 0, trials = 0, hybrids = 0, exhausted_none = 0;
+    const int shapes[][2] = {{1, 1}, {2, 1}, {1, 7}, {9, 1}, {2, 2}, {5, 3}, {16, 12}, {33, 27}, {64, 48}, {97, 61}, {120, 90}};
+    for (const auto& sh : shapes)
+        for (int variant = 0; variant < 6; variant++, trials++) {
+            const int w = sh[0], h = sh[1];
+            std::vector<float> pay((size_t)5 * w * h, 0.f);
+            const int range = variant == 1 ? 3 : 40;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    float* p = &pay[5 * ((size_t)y * w + x)];
+                    p[0] = (float)(rng.uniform(0, 2 * range + 1) - range);
+                    if (variant == 2) p[0] = std::fabs(p[0]);                       // only sources
+                    if (variant == 3) p[0] = -std::fabs(p[0]);                      // only sinks
+                    if (variant == 4 && rng.uniform(0, 4) == 0) p[0] = rng.uniform(0, 2) ? 1048576.f : -1048576.f;
+                    const int dx[4] = {1, 0, -1, 1}, dy[4] = {0, 1, 1, 1};
+                    for (int k = 0; k < 4; k++) {
+                        const int xx = x + dx[k], yy = y + dy[k];
+                        if (xx < 0 || xx >= w || yy >= h) continue;
+                        p[1 + k] = variant == 5 ? 0.f : (float)rng.uniform(0, rng.uniform(0, 3) ? range / 2 + 1 : 1);
+                    }
+                }
+            GridMaxFlow bk;
+            GridPushRelabel pr;
+            bk.reset_for_load(w, h); pr.reset_for_load(w, h);
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) { bk.load_node(x, y, &pay[5 * ((size_t)y * w + x)]); pr.load_node(x, y, &pay[5 * ((size_t)y * w + x)]); }
+            const double fb = bk.maxflow(), fp = pr.maxflow();
+            int diff = 0;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) diff += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
+            if (fb != fp || diff) { printf("FAIL push-relabel vs BK %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", w, h, variant, fp, fb, diff); fail = 1; }
+            // the hybrid of expansionMovePrebuilt: BK until a (here: tiny) work budget runs out, push-relabel on the residual graph
+            for (double budget : {0.25, 1.5}) {
+                GridMaxFlow part;
+                part.reset_for_load(w, h);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) part.load_node(x, y, &pay[5 * ((size_t)y * w + x)]);
+                const double f1 = part.maxflow(1, budget);
+                if (!part.exhausted()) { exhausted_none++; if (f1 != fb) { printf("FAIL budgeted BK finished with another flow\n"); fail = 1; } continue; }
+                GridPushRelabel rest;
+                rest.reset_for_load(w, h);
+                float rc8[8], tr;
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) { part.residual(x, y, rc8, &tr); rest.load_residual(x, y, rc8, tr); }
+                rest.set_base_flow(f1);
+                const double f2 = rest.maxflow();
+                int d2 = 0;
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) d2 += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (rest.what_segment(x, y) == GridPushRelabel::SOURCE);
+                hybrids++;
+                if (f2 != fb || d2) { printf("FAIL BK(%.2f ops/node) + push-relabel %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", budget, w, h, variant, f2, fb, d2); fail = 1; }
+            }
+        }
+    // through the dispatcher the drivers call: forced to either solver, same mask
+    {
+        const int w = 70, h = 50;
+        std::vector<float> pay((size_t)5 * w * h, 0.f);
+        for (size_t i = 0; i < pay.size(); i++) pay[i] = (float)rng.uniform(0, 9) - ((i % 5 == 0) ? 4.f : 0.f);
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { float* p = &pay[5 * ((size_t)y * w + x)]; if (x + 1 >= w) p[1] = p[4] = 0; if (y + 1 >= h) p[2] = p[3] = p[4] = 0; if (x == 0) p[3] = 0; }
+        GridPushRelabel pr; pr.reset_for_load(w, h);
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) pr.load_node(x, y, &pay[5 * ((size_t)y * w + x)]);
+        const double fp = pr.maxflow();
+        std::vector<uint8_t> mask;
+        const double fb = expansionMovePrebuilt(pay.data(), 0.0, Rect(0, 0, w, h), mask);
+        int diff = 0;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) diff += (mask[(size_t)y * w + x] != 0) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
+        if (fb != fp || diff) { printf("FAIL push-relabel vs expansionMovePrebuilt: flow %.1f vs %.1f, %d differences\n", fp, fb, diff); fail = 1; }
+    }
+    printf("push-relabel vs Boykov-Kolmogorov: %d random grids %s; %d of them also cut as BK-with-a-budget + push-relabel on the residual graph\n", trials, fail ? "FAILED" : "identical", hybrids);
+    return fail;
+}
+
 // band-parallel first phase vs the plain search on larger random grids: identical flow and identical segments
 static int banded_vs_plain()
 {
@@ -259,6 +338,7 @@ int main(int argc, char** argv)
         fail |= brute_force(tiny, param, 7.0f);
         fail |= grid_vs_generic();
         fail |= banded_vs_plain();
+        fail |= push_relabel_vs_bk();
         fail |= band_pool_check();
     }
     PMStereo st(W, H, param, maxd);

@@ -1,7 +1,9 @@
 """C++ host side above the C ABI (localexpstereo_amd/host/): LayerManager geometry against the oracle
 (no GPU needed) and the les_host_demo end-to-end run (drop-in operator from OpenMP threads + device-
 resident PatchMatch iterations) on the MI355X."""
+import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -71,6 +73,48 @@ def test_host_demo_sharded_ranks_on_one_gpu(demo, world):
     r = subprocess.run([demo, "ranks", "240", "160", "32", str(world)], capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
+
+
+def test_push_relabel_equals_bk_on_real_graphs(monkeypatch):
+    """Two 129 x 129 crops of a coarse-layer lock-step dumped from the Adirondack-shape run (89 % and 20 % of the nodes switch: the hard
+    kind): the push-relabel solver and the Boykov-Kolmogorov solver of liblocalexp_host.so must return the same mask and the same flow,
+    and the mask must be a minimum cut according to networkx."""
+    import importlib
+    import networkx as nx
+    from localexpstereo_amd import api, build
+    build.build_host_lib()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cells.npz"))
+    res = {}
+    for solver, thr in (("bk", "0"), ("pr", "1")):
+        # the threshold is read once per process: run each solver in its own interpreter
+        code = ("import numpy as np, sys; from localexpstereo_amd import gc as lgc, api\n"
+                "z = np.load(sys.argv[1]); out = {}\n"
+                "for k in z.files:\n"
+                "    p = np.ascontiguousarray(z[k].reshape(-1), np.float32); h, w = z[k].shape[:2]\n"
+                "    m = np.zeros(w * h, np.uint8); f = np.zeros(1)\n"
+                "    lgc.solve_prebuilt(api._rects(np.array([(0, 0, w, h)], np.int32)), p, np.array([0], np.int64), m, nthreads=1, flows_out=f)\n"
+                "    out[k + '_mask'] = m; out[k + '_flow'] = f\n"
+                "np.savez(sys.argv[2], **out)\n")
+        outp = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hard_cells_{solver}.npz")
+        env = dict(os.environ, LES_GC_PUSH_RELABEL_MIN_NODES=thr, LES_GC_BK_OPS_PER_NODE="1")     # ("pr": the budget of the BK phase runs out at once)
+        subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(__file__), "golden", "hard_cells.npz"), outp], check=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        res[solver] = np.load(outp)
+    for k in z.files:
+        mb, mp = res["bk"][k + "_mask"], res["pr"][k + "_mask"]
+        assert np.array_equal(mb != 0, mp != 0), f"{k}: {int(((mb != 0) != (mp != 0)).sum())} nodes differ between the two solvers"
+        fb, fp = float(res["bk"][k + "_flow"][0]), float(res["pr"][k + "_flow"][0])
+        assert abs(fb - fp) <= 1e-6 * abs(fb), (fb, fp)
+        assert 0 < (mp != 0).mean() < 1
+    # independent check of one of them: networkx max-flow value == flow, and the mask is a cut of that capacity
+    from tests import parity_cases as pc
+    k = "cell5"
+    h, w = z[k].shape[:2]
+    ref_flow, ref_src = pc._grid_graph_reference(z[k].reshape(-1, 5), w, h)
+    assert abs(ref_flow - float(res["pr"][k + "_flow"][0])) <= 1e-5 * ref_flow
+    cap = pc._cut_capacity(z[k].reshape(-1, 5), w, h, res["pr"][k + "_mask"] != 0)
+    assert abs(cap - ref_flow) <= 1e-5 * ref_flow
+    assert int(((res["pr"][k + "_mask"] != 0) != ref_src).sum()) <= 2            # (float ties only)
 
 
 def test_host_graph_cut_selfcheck(demo):
