@@ -116,15 +116,20 @@ public:
                 for (int x = 0; x < w_; x++) nodes_[id(x, y)].band = (uint8_t)b;
         markPadding();
         std::vector<Ctx> ctx(bands);
+        std::vector<char> band_done(bands, 1);
         BandPool::mine().run(bands, [&](int b) {
             ctx[b].band = b;
             ctx[b].budget = budget > 0 ? budget * (row0[b + 1] - row0[b]) / h_ + 1 : 0;
             init_trees(ctx[b], row0[b], row0[b + 1]);
-            search(ctx[b]);                                      // (a band that runs out of budget just leaves more for the whole-graph search)
+            band_done[b] = search(ctx[b]) ? 1 : 0;
         });
         // continuation on the whole graph
         main_ = Ctx();
         for (int b = 0; b < bands; b++) { main_.flow += ctx[b].flow; main_.time = std::max(main_.time, ctx[b].time); }
+        // A band that ran out of budget still has active nodes inside, which the continuation below (it re-activates the band borders only)
+        // would never visit: the instance is a hard one anyway -- hand the feasible flow found so far to the caller's other solver.
+        for (int b = 0; b < bands; b++)
+            if (!band_done[b]) { exhausted_ = true; return flow_ + main_.flow; }
         main_.time += 1;
         main_.epoch = main_.time;
         for (int b = 1; b < bands; b++)

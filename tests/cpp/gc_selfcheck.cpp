@@ -168,12 +168,13 @@ static int push_relabel_vs_bk()
                 for (int x = 0; x < w; x++) diff += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
             if (fb != fp || diff) { printf("FAIL push-relabel vs BK %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", w, h, variant, fp, fb, diff); fail = 1; }
             // the hybrid of expansionMovePrebuilt: BK until a (here: tiny) work budget runs out, push-relabel on the residual graph
-            for (double budget : {0.25, 1.5}) {
+            for (double budget : {0.25, 1.5, 4.0}) {
                 GridMaxFlow part;
                 part.reset_for_load(w, h);
                 for (int y = 0; y < h; y++)
                     for (int x = 0; x < w; x++) part.load_node(x, y, &pay[5 * ((size_t)y * w + x)]);
-                const double f1 = part.maxflow(1, budget);
+                // (larger grids: with the band-parallel first phase, whose bands have their own share of the budget)
+                const double f1 = part.maxflow(h >= 48 ? 4 : 1, budget);
                 if (!part.exhausted()) { exhausted_none++; if (f1 != fb) { printf("FAIL budgeted BK finished with another flow\n"); fail = 1; } continue; }
                 GridPushRelabel rest;
                 rest.reset_for_load(w, h);

@@ -659,8 +659,9 @@ def test_adirondack_shape_midv3_end_to_end(dual):
     en = [r["energy"] for r in st.log[3:8]]
     assert all(b <= a * (1 + 1e-6) for a, b in zip(en, en[1:]))
     # north_star's orientation target is 10 s; measured on the MI355X box (round 3, hard cuts finished by push-relabel): 2.5 s (one view),
-    # 5.5 s (two views + post-processing).  The bounds leave room for the box-to-box spread of the pool (its host grants 16 CPUs to the cuts).
-    assert wall < (7.0 if dual else 4.0), f"Adirondack-shape run (dual={dual}) took {wall:.1f} s"
+    # 6.6 s (two views + post-processing; 8.4 s with Boykov-Kolmogorov alone).  The bounds leave room for the box-to-box spread of the pool
+    # (its host grants 16 CPUs to the cuts).
+    assert wall < (8.0 if dual else 4.0), f"Adirondack-shape run (dual={dual}) took {wall:.1f} s"
 
 
 def test_two_ranks_rccl_equal_one_rank(tmp_path):

@@ -47,9 +47,11 @@ struct GridPR {
     bool inside(int i) const { const int x = i % pw, y = i / pw; return x >= 1 && x <= w && y >= 1 && y <= h; }
 
     // exact residual distances to the sink (BFS over reversed residual arcs)
+    double t_glob = 0;
     void global_relabel()
     {
         globals++;
+        auto tg0 = clk::now();
         std::vector<int>& bq = bfs;
         bq.clear();
         for (int y = 1; y <= h; y++)
@@ -70,6 +72,7 @@ struct GridPR {
         std::fill(cnt.begin(), cnt.end(), 0);
         for (int y = 1; y <= h; y++)
             for (int x = 1; x <= w; x++) { const int dd = d[y * pw + x]; if (dd < BIG) cnt[dd]++; }
+        t_glob += std::chrono::duration<double>(clk::now() - tg0).count();
     }
     std::vector<int> bfs;
 
@@ -233,7 +236,7 @@ int main(int argc, char** argv)
         flow_pr = getenv("PR_HL") ? g.run_hl() : g.run();
         for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) mask2[(size_t)y * w + x] = g.is_source(x, y) ? 255 : 0;
         pr = std::min(pr, std::chrono::duration<double>(clk::now() - t0).count());
-        rel = g.relabels; pu = g.pushes; gl = g.globals; printf("gaps %lld ", g.gaps);
+        rel = g.relabels; pu = g.pushes; gl = g.globals; printf("global relabel time %.2f ms ", g.t_glob * 1e3); printf("gaps %lld ", g.gaps);
     }
     size_t diff = 0, ch = 0;
     for (size_t i = 0; i < mask.size(); i++) { diff += (mask[i] != 0) != (mask2[i] != 0); ch += mask[i] != 0; }
