@@ -130,7 +130,8 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     });
     graph.set_base_flow(base_flow);
     const bool budgeted = (long long)w * h >= pushRelabelMinNodes();
-    const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0);
+    static const double band_ops = [] { const char* e = getenv("LES_GC_BK_BAND_OPS_PER_NODE"); return e ? atof(e) : -1.0; }();
+    const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0, band_ops);
     if (graph.exhausted()) {
         // a hard move: push-relabel continues from the feasible flow found so far
         static thread_local GridPushRelabel pr_tls;

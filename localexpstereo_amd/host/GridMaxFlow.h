@@ -97,8 +97,9 @@ public:
     // maximum flow of the whole graph, so the cut read-out is the same as for bands == 1.
     // ops_per_node > 0: give up after that much search work per node (hard instances: the caller continues with push-relabel on the
     // residual graph, see exhausted() / residual()); the band searches of the parallel first phase get the same allowance per band node
-    double maxflow(int bands = 1, double ops_per_node = 0.0)
+    double maxflow(int bands = 1, double ops_per_node = 0.0, double band_ops_per_node = -1.0)
     {
+        if (band_ops_per_node < 0) band_ops_per_node = ops_per_node;
         exhausted_ = false;
         if (bands > h_ / 8) bands = h_ / 8;                      // at least 8 rows per band
         if (bands > 64) bands = 64;
@@ -119,7 +120,7 @@ public:
         std::vector<char> band_done(bands, 1);
         BandPool::mine().run(bands, [&](int b) {
             ctx[b].band = b;
-            ctx[b].budget = budget > 0 ? budget * (row0[b + 1] - row0[b]) / h_ + 1 : 0;
+            ctx[b].budget = budget > 0 ? (long long)(band_ops_per_node * w_ * (row0[b + 1] - row0[b])) + 1 : 0;
             init_trees(ctx[b], row0[b], row0[b + 1]);
             band_done[b] = search(ctx[b]) ? 1 : 0;
         });
