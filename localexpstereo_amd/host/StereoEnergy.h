@@ -79,32 +79,19 @@ public:
                                          std::array<std::vector<float>, 8>& cost10, int mode = 0) const
     {
         const size_t n = (size_t)region.width * region.height;
-        auto dot = [](const Plane& l, float x, float y) { return ((l.a * x + l.b * y) + l.c * 1.0f) + l.v * 0.0f; };   // channelDot / channelSum order
         for (int k : {(int)NB_GE, (int)NB_EG, (int)NB_LG, (int)NB_GG}) {
             cost00[k].assign(n, 0.f); cost01[k].assign(n, 0.f); cost10[k].assign(n, 0.f);
             for (int y = 0; y < region.height; y++)
                 for (int x = 0; x < region.width; x++) {
-                    const int ex = region.x + x, ey = region.y + y;
-                    const int lx = ex + neighbors[k].x, ly = ey + neighbors[k].y;
-                    const bool inside = lx >= 0 && lx < width && ly >= 0 && ly < height;
-                    const Plane l0_ee = labeling0.at(ey, ex);
-                    const Plane l0_le = inside ? labeling0.at(ly, lx) : Plane();
-                    const float fx = (float)ex, fy = (float)ey, gx = (float)lx, gy = (float)ly;
-                    const float d0_ee_at_ee = dot(l0_ee, fx, fy), d0_le_at_ee = dot(l0_le, fx, fy);
-                    const float d0_ee_at_le = dot(l0_ee, gx, gy), d0_le_at_le = dot(l0_le, gx, gy);
-                    const float d1_at_ee = dot(label1, fx, fy), d1_at_le = dot(label1, gx, gy);
-                    const float w = smoothnessCoeff[mode][k][(size_t)ey * width + ex];
                     const size_t i = (size_t)y * region.width + x;
-                    const float th = params.th_smooth;
-                    cost00[k][i] = std::min(std::fabs(d0_ee_at_ee - d0_le_at_ee) + std::fabs(d0_ee_at_le - d0_le_at_le), th) * w * params.lambda;
-                    cost01[k][i] = std::min(std::fabs(d0_ee_at_ee - d1_at_ee) + std::fabs(d0_ee_at_le - d1_at_le), th) * w * params.lambda;
-                    cost10[k][i] = std::min(std::fabs(d1_at_ee - d0_le_at_ee) + std::fabs(d1_at_le - d0_le_at_le), th) * w * params.lambda;
+                    smoothnessTermsExpansionAt(labeling0, label1, region.x + x, region.y + y, k, cost00[k][i], cost01[k][i], cost10[k][i], mode);
                 }
         }
     }
 
     // The three terms of computeSmoothnessTermsExpansion for one pixel `ee` = (ex, ey) and one forward neighbour k
-    // (same arithmetic; used by the expansion move to build its graph without the intermediate cost arrays).
+    // (the one place this arithmetic lives: the array form above calls it; the expansion move builds its graph from it directly).
+    // dot = channelDot / channelSum order of the reference.
     void smoothnessTermsExpansionAt(const LabelMap& labeling0, const Plane& label1, int ex, int ey, int k, float& c00, float& c01, float& c10,
                                     int mode = 0) const
     {
