@@ -125,6 +125,7 @@ const MarchEntry* find_march(int R, int wide = 1)
     return best;
 }
 
+constexpr long long kRawPatchCapFloats = 1ll << 30;   // 4 GB of raw-cost patches per batch and view (image-based energy on the march kernel)
 constexpr int kRansacMaxSam = 500;   // RansacProposer default MAX_SAM, LES/Proposer.h:265
 
 struct ViewData {
@@ -178,6 +179,13 @@ struct les_hip_batch {
     const MarchEntry* mentry = nullptr;  // the geometry the table was cut for
     int nmgroups = 0;
     bool march_ok = false;
+    // image-based energy on the march kernel: the calls' filterRects with the offsets of their raw-cost patches, and one patch
+    // buffer per view (allocated on the view's first run; two host threads may drive the two views of one batch)
+    les::RawCall* d_rawcalls = nullptr;
+    long long* d_raw_off = nullptr;
+    long long raw_floats = 0;
+    int raw_chunks = 1;
+    mutable float* d_raw[2] = {nullptr, nullptr};
     std::vector<les_hip_rect> targets;
     int device = 0;
     // cell geometry for the proposers / WTA
@@ -202,6 +210,10 @@ struct les_hip_scratch {
     float* d_tile = nullptr; float* h_tile = nullptr; size_t tile_cap = 0;        // floats
     float4* d_plane = nullptr; float4* h_plane = nullptr;
     struct Entry { les_hip_rect f, t; int want_march; const void* march; int njobs, ngroups; les::Job* d_jobs; unsigned long long stamp; };
+    // image-based energy on the march kernel: raw-cost patch of the call's filterRect and its one-entry call table
+    float* d_raw = nullptr; size_t raw_cap = 0;
+    les::RawCall* d_rawcall = nullptr; long long* d_raw_off = nullptr;
+    les_hip_rect raw_f = {-1, -1, -1, -1};
     std::vector<Entry> cache;
     unsigned long long clock = 0;
 };
@@ -383,11 +395,27 @@ int ensure_planes(les_hip_ctx* c, size_t n)
     return LES_HIP_OK;
 }
 
+// The raw-cost patches of an image-based context (null for a cost-volume context): call table, patch offsets, patch buffer
+struct RawPatches { const les::RawCall* calls; const long long* off; float* raw; int n, chunks; };
+
+les::View strip_view(const les_hip_ctx* c, int mode)
+{
+    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, c->v[mode].ipk10, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
+    if (c->naive) { view.feat_self = c->v[mode].feat; view.feat_other = c->v[1 - mode].feat; }
+    return view;
+}
+
 int launch_march(les_hip_ctx* c, const MarchEntry* m, int mode, const les::Job* d_mjobs, int ngroups, const float4* d_planes, float* d_out, int check,
-                 hipStream_t stream)
+                 hipStream_t stream, const RawPatches* rp = nullptr)
 {
     if (ngroups <= 0) return LES_HIP_OK;
-    hipLaunchKernelGGL(m->fn, dim3(ngroups), dim3(m->NT), 0, stream, c->geom, c->v[mode].mv, d_mjobs, d_planes, d_out, ngroups, check);
+    les::MarchView mv = c->v[mode].mv;
+    if (c->naive) {
+        if (!rp || !rp->raw || !c->v[1 - mode].feat) return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
+        hipLaunchKernelGGL(les::les_naive_raw_kernel, dim3(rp->n, rp->chunks), dim3(256), 0, stream, c->geom, strip_view(c, mode), rp->calls, d_planes, rp->raw);
+        mv.vol = rp->raw; mv.raw_off = rp->off;
+    }
+    hipLaunchKernelGGL(m->fn, dim3(ngroups), dim3(m->NT), 0, stream, c->geom, mv, d_mjobs, d_planes, d_out, ngroups, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -397,8 +425,7 @@ int launch_strips(les_hip_ctx* c, int mode, const les::Job* d_jobs, int njobs, c
     if (njobs <= 0) return LES_HIP_OK;
     if (mode < 0 || mode > 1 || !c->v[mode].stats || (c->naive ? !c->v[1 - mode].feat : !c->v[mode].vol))
         return fail(LES_HIP_ERR_ARG, "view %d was not supplied at creation", mode);
-    les::View view{c->v[mode].vol, c->v[mode].stats, c->v[mode].ipk, c->v[mode].ipk10, nullptr, nullptr, mode ? -1.0f : 1.0f, c->th_color, c->th_grad};
-    if (c->naive) { view.feat_self = c->v[mode].feat; view.feat_other = c->v[1 - mode].feat; }
+    const les::View view = strip_view(c, mode);
     hipLaunchKernelGGL(c->strip->fn, dim3(njobs), dim3(c->strip->NT), 0, stream, c->geom, view, d_jobs, d_planes, d_out, njobs, check);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
@@ -414,12 +441,13 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     const size_t P = (size_t)c->p.H * c->p.W;
     const int W = c->p.W, H = c->p.H;
     v.march_ok = false;
-    const float th = c->p.th_col;
+    // image-based energy: the raw cost min(|dcolor|, th_color) + min(|dgrad|, th_grad) lies in [0, th_color + th_grad] by construction
+    const float th = c->naive ? c->th_color + c->th_grad : c->p.th_col;
     if (!(th > 0.0f) || !(th < INFINITY)) return LES_HIP_OK;
     // cost range
     const int nb = 2048;
-    std::vector<float> hmin(nb); std::vector<int> hbad(nb);
-    {
+    std::vector<float> hmin(nb, 0.0f); std::vector<int> hbad(nb, 0);
+    if (!c->naive) {
         // one allocation for both partial arrays, released on every path (a failing call must not leak device memory)
         struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } part;
         HIPCHECK(hipMalloc(&part.p, nb * (sizeof(float) + sizeof(int))));
@@ -465,6 +493,7 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     mv.kapS = (float)((double)(1 << les::kMarchSH) * up / 255.0 * scale);
     mv.upS = (float)(up * scale);
     mv.qscale = 1.0 / (255.0 * scale);
+    mv.raw_off = nullptr;
     v.mv = mv;
     v.march_ok = true;
     return LES_HIP_OK;
@@ -501,7 +530,7 @@ int build_view(les_hip_ctx* c, int m, const uint8_t* im, const float* vol)
     hipLaunchKernelGGL(les::les_stats_hsum_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), v.ipk, d_hs, H, W, c->R);
     hipLaunchKernelGGL(les::les_stats_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.stats, H, W, c->R, c->p.eps);
     HIPCHECK(hipGetLastError());
-    if (c->march && v.vol) {
+    if (c->march && (v.vol || c->naive)) {
         int rc = build_march_view(c, m, d_hs);
         if (rc) { (void)hipFree(d_img); (void)hipFree(d_hs); return rc; }
     }
@@ -558,7 +587,7 @@ static int create_common(les_hip_ctx** out, const les_hip_params* params, const 
     c->p = p;
     c->R = p.windR / 2;
     c->strip = strip;
-    c->march = naive ? nullptr : find_march(p.windR / 2);
+    c->march = find_march(p.windR / 2);
 #if !defined(LES_SIM)
     {
         int v = 0;
@@ -699,6 +728,31 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
             b->nmgroups = (int)(mjobs.size() / b->mentry->NJ);
             b->march_ok = true;
         }
+        if (b->march_ok && c->naive) {
+            // raw-cost patches: one per call, the size of its filterRect.  Batches whose patches would not fit the cap stay on the strip kernel.
+            std::vector<les::RawCall> calls((size_t)n);
+            std::vector<long long> offs((size_t)n);
+            long long tot = 0, amax = 1;
+            for (int i = 0; i < n; i++) {
+                const bool live = trs[i].w > 0 && trs[i].h > 0;
+                const long long a = live ? (long long)frs[i].w * frs[i].h : 0;
+                calls[i] = les::RawCall{frs[i].x, frs[i].y, live ? frs[i].w : 0, live ? frs[i].h : 0, tot};
+                offs[i] = tot;
+                tot += a; amax = std::max(amax, a);
+            }
+            if (tot > kRawPatchCapFloats) b->march_ok = false;
+            else {
+                b->raw_floats = tot;
+                b->raw_chunks = (int)std::min<long long>(1024, std::max<long long>(1, (amax + 4095) / 4096));
+                if (hipMalloc((void**)&b->d_rawcalls, (size_t)n * sizeof(les::RawCall)) != hipSuccess ||
+                    hipMemcpy(b->d_rawcalls, calls.data(), (size_t)n * sizeof(les::RawCall), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMalloc((void**)&b->d_raw_off, (size_t)n * sizeof(long long)) != hipSuccess ||
+                    hipMemcpy(b->d_raw_off, offs.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess) {
+                    les_hip_batch_destroy(b);
+                    return fail(LES_HIP_ERR_DEVICE, "upload of the raw-cost call table failed");
+                }
+            }
+        }
     }
     if (!jobs.empty()) {
         if (hipMalloc((void**)&b->d_jobs, jobs.size() * sizeof(les::Job)) != hipSuccess) { les_hip_batch_destroy(b); return fail(LES_HIP_ERR_DEVICE, "hipMalloc(jobs) failed"); }
@@ -715,6 +769,9 @@ void les_hip_batch_destroy(les_hip_batch* b)
     if (!b) return;
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_mjobs) (void)hipFree(b->d_mjobs);
+    if (b->d_rawcalls) (void)hipFree(b->d_rawcalls);
+    if (b->d_raw_off) (void)hipFree(b->d_raw_off);
+    for (int m = 0; m < 2; m++) if (b->d_raw[m]) (void)hipFree(b->d_raw[m]);
     if (b->d_units) (void)hipFree(b->d_units);
     if (b->d_targets) (void)hipFree(b->d_targets);
     if (b->d_graph_off) (void)hipFree(b->d_graph_off);
@@ -939,8 +996,15 @@ int les_hip_batch_run(les_hip_ctx* c, const les_hip_batch* b, int mode, const le
         HIPCHECK(hipMemcpyAsync(c->d_planes, planes, (size_t)b->n * sizeof(float4), hipMemcpyHostToDevice, cur_stream(c)));
         d_planes = c->d_planes;
     }
-    if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok)
-        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, cur_stream(c));
+    if (b->march_ok && mode >= 0 && mode <= 1 && c->march && c->v[mode].march_ok) {
+        if (!c->naive) return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, cur_stream(c));
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!b->d_raw[mode]) HIPCHECK(hipMalloc((void**)&b->d_raw[mode], (size_t)std::max<long long>(b->raw_floats, 1) * sizeof(float)));
+        }
+        const RawPatches rp{b->d_rawcalls, b->d_raw_off, b->d_raw[mode], b->n, b->raw_chunks};
+        return launch_march(c, b->mentry, mode, b->d_mjobs, b->nmgroups, d_planes, out_dev, check, cur_stream(c), &rp);
+    }
     return launch_strips(c, mode, b->d_jobs, b->njobs, d_planes, out_dev, check, cur_stream(c));
 }
 
@@ -992,6 +1056,9 @@ void les_hip_scratch_destroy(les_hip_scratch* s)
     for (auto& e : s->cache) if (e.d_jobs) (void)hipFree(e.d_jobs);
     if (s->d_tile) (void)hipFree(s->d_tile);
     if (s->h_tile) (void)hipHostFree(s->h_tile);
+    if (s->d_raw) (void)hipFree(s->d_raw);
+    if (s->d_rawcall) (void)hipFree(s->d_rawcall);
+    if (s->d_raw_off) (void)hipFree(s->d_raw_off);
     if (s->d_plane) (void)hipFree(s->d_plane);
     if (s->h_plane) (void)hipHostFree(s->h_plane);
     delete s;
@@ -1058,7 +1125,34 @@ int les_hip_unary_one_scratch(les_hip_ctx* c, les_hip_scratch* s, int mode, cons
     }
     *s->h_plane = make_float4(plane->a, plane->b, plane->c, plane->v);
     HIPCHECK(hipMemcpyAsync(s->d_plane, s->h_plane, sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    if (e->march) rc = launch_march(c, static_cast<const MarchEntry*>(e->march), mode, e->d_jobs, e->ngroups, s->d_plane, s->d_tile, check, s->stream);
+    if (e->march && c->naive) {
+        // raw-cost patch of this filterRect (the one-entry call table is rewritten when the rect changes; everything is ordered on the scratch's stream)
+        const size_t rneed = (size_t)fr->w * fr->h;
+        if (rneed > s->raw_cap || !s->d_rawcall) {
+            HIPCHECK(hipStreamSynchronize(s->stream));
+            if (s->d_raw) HIPCHECK(hipFree(s->d_raw));
+            s->d_raw = nullptr; s->raw_cap = 0;
+            const size_t cap = std::max(rneed, (size_t)256 * 256);
+            HIPCHECK(hipMalloc((void**)&s->d_raw, cap * sizeof(float)));
+            s->raw_cap = cap;
+            if (!s->d_rawcall) {
+                HIPCHECK(hipMalloc((void**)&s->d_rawcall, sizeof(les::RawCall)));
+                HIPCHECK(hipMalloc((void**)&s->d_raw_off, sizeof(long long)));
+                const long long zero = 0;
+                HIPCHECK(hipMemcpy(s->d_raw_off, &zero, sizeof zero, hipMemcpyHostToDevice));
+            }
+            s->raw_f = les_hip_rect{-1, -1, -1, -1};
+        }
+        if (memcmp(&s->raw_f, fr, sizeof *fr)) {
+            const les::RawCall call{fr->x, fr->y, fr->w, fr->h, 0};
+            HIPCHECK(hipStreamSynchronize(s->stream));
+            HIPCHECK(hipMemcpy(s->d_rawcall, &call, sizeof call, hipMemcpyHostToDevice));
+            s->raw_f = *fr;
+        }
+        const RawPatches rp{s->d_rawcall, s->d_raw_off, s->d_raw, 1, (int)std::min<size_t>(1024, (rneed + 4095) / 4096)};
+        rc = launch_march(c, static_cast<const MarchEntry*>(e->march), mode, e->d_jobs, e->ngroups, s->d_plane, s->d_tile, check, s->stream, &rp);
+    }
+    else if (e->march) rc = launch_march(c, static_cast<const MarchEntry*>(e->march), mode, e->d_jobs, e->ngroups, s->d_plane, s->d_tile, check, s->stream);
     else rc = launch_strips(c, mode, e->d_jobs, e->njobs, s->d_plane, s->d_tile, check, s->stream);
     if (rc) return rc;
     HIPCHECK(hipMemcpyAsync(s->h_tile, s->d_tile, need * sizeof(float), hipMemcpyDeviceToHost, s->stream));

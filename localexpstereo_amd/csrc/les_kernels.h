@@ -687,6 +687,32 @@ __global__ void les_naive_features_kernel(const uint8_t* __restrict__ img, float
     feat[(size_t)y * W + x] = f;
 }
 
+// Raw image-based matching cost of whole calls (LES/StereoEnergy.h:686-719, the loop that fills the cost patch before the
+// guided filter): call i evaluates its plane on every pixel of its filterRect and stores the patch compactly at raw + off.
+// The march kernel (les_march.h, role A KIND 3) then reads that patch like one slice of a cost volume, so the image-based
+// energy runs on the same fixed-point filter as the volume-based one.  Every value lies in [0, th_color + th_grad] (a
+// comparison with a NaN operand selects the threshold), which is the range the march kernel's fixed point is scaled for.
+struct RawCall {
+    int fx, fy, fw, fh;        // filterRect
+    long long off;             // float offset of its patch
+};
+__global__ void les_naive_raw_kernel(Geom g, View view, const RawCall* __restrict__ calls, const float4* __restrict__ planes,
+                                     float* __restrict__ raw)
+{
+    const RawCall rc = calls[blockIdx.x];
+    const float4 plane = planes[blockIdx.x];
+    const long long area = (long long)rc.fw * rc.fh;
+    const long long per = (area + gridDim.y - 1) / gridDim.y;
+    const long long p0 = per * blockIdx.y, p1 = p0 + per < area ? p0 + per : area;
+    for (long long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const int yy = (int)(p / rc.fw), xx = (int)(p - (long long)yy * rc.fw);
+        const int gx = rc.fx + xx, gy = rc.fy + yy;
+        const NaivePrep np = naive_prepare(g, view.sign, plane.x, plane.y, plane.z, gx, gy);
+        const uint32_t px = (uint32_t)gy * (uint32_t)g.W + (uint32_t)gx;
+        raw[rc.off + p] = naive_finish(view, np, view.feat_self[px], view.feat_other[np.ia], view.feat_other[np.ib]);
+    }
+}
+
 // One dword per lane streaming copy: the calibration pattern for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (the strip
 // kernel reads and writes dwords; MI355X_MICROARCH.md asks for a calibration on a known byte count in the same access width).
 __global__ void les_calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n)

@@ -53,6 +53,10 @@ struct MarchView {
     float kapS;                   // 2^SH * u_p / 255 * scale        (u_p = (th_col - vmin) / (2^PB - 1))
     float upS;                    // u_p * scale
     double qscale;                // 1 / (255 * scale)
+    // image-based energy (les_hip_create_naive): vol is the raw-cost scratch les_naive_raw_kernel has just filled, raw_off[i] the
+    // float offset of call i's filterRect patch in it (row stride = filterRect width), vmin = 0, th_col -> th_color + th_grad.
+    // Null for a cost-volume context.
+    const long long* raw_off;
 };
 
 template <int R, int WGC, int NJ, int BY>
@@ -327,6 +331,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         //   KIND 0  fronto-parallel plane, one volume tap  (integer disparity, clamped or invalid label)
         //   KIND 1  fronto-parallel plane, two taps
         //   KIND 2  general plane: taps / weight / mode per lane and row
+        //   KIND 3  image-based energy: one tap into the call's raw-cost patch (any plane; no truncation, no invalid mode)
         // For fronto-parallel planes everything but the clip test is per-job, the row bases are scalars and the loads need no
         // address arithmetic.
         auto march_a = [&](auto kind_tag) __attribute__((always_inline)) {
@@ -341,19 +346,28 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // valid address and flagged off, so the issue needs no branch.
         int nx_rowpx = 0;
         float nx_dbase = 0.0f;
+        int nx_rowraw = 0;               // KIND 3: float offset of the row in the call's patch
+        const int fw = job.cx1 - job.cx0;
+        const float* rawbase = nullptr;
+        if constexpr (KIND == 3) rawbase = view.vol + view.raw_off[job.plane_idx] - job.cx0;
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy = job.ty0 - 2 * R + t;
             const int sy = min(max(gy, job.cy0), cy1m);
             nx_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
-            nx_dbase = plane.y * (float)sy + plane.z;                   // b*y + c, LES/CostVolumeEnergy.h:73
+            if constexpr (KIND == 3) nx_rowraw = (sy - job.cy0) * fw;
+            else nx_dbase = plane.y * (float)sy + plane.z;              // b*y + c, LES/CostVolumeEnergy.h:73
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;
             const uint32_t rowpx = (uint32_t)readlane_i32(nx_rowpx, i);
             const uint32_t ro = rowpx & 0x7fffffffu;
             if (LES_MARCH_EXP & 64) { rowbits = 0x7f; v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
-            if constexpr (KIND < 2) {
+            if constexpr (KIND == 3) {
+                rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
+                const float* r0 = rawbase + (size_t)(uint32_t)readlane_i32(nx_rowraw, i);
+                v0[i] = ld_sbase(r0, sx4);
+            } else if constexpr (KIND < 2) {
                 rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
                 const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
                 v0[i] = ld_sbase(r0, sx4);
@@ -387,7 +401,9 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             constexpr int i = decltype(itag)::value;
                             constexpr int SLOT = BASE + i;       // ring slot of p-row k*BY + i; it holds the row that leaves the window (2R+1 rows ago)
                             int pi;
-                            if constexpr (KIND < 2) {
+                            if constexpr (KIND == 3) {
+                                pi = (col_in && ((rowbits >> i) & 1u)) ? (int)fmaf(v0[i], view.sp, pbias) : 0;
+                            } else if constexpr (KIND < 2) {
                                 // LES/CostVolumeEnergy.h:78-96 with per-job taps: clamped / interpolated / invalid, then min(C, th_col)
                                 // (one tap: the weight of the second is zero and the volume is finite, so f0 v0 + 0 v1 = v0)
                                 float C = v0[i];
@@ -423,10 +439,11 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
                         const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
+                        constexpr bool kPair = KIND != 2;
 #ifndef LES_MARCH_PREFIX_PAIR
 #define LES_MARCH_PREFIX_PAIR 1
 #endif
-                        if (LES_MARCH_PREFIX_PAIR && KIND < 2 && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
+                        if (LES_MARCH_PREFIX_PAIR && kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
                             if (da) { wave_sync(); march_prefix_tile<BY, PCOLS>(s_T1[k & 1][slot], ci0, lane); }
                             if (db) march_prefix_tile<BY, PCOLS>(TB, ci0, lane);
@@ -438,13 +455,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         }
         LES_TICK_END(0);
         };
-        if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
+        if (view.raw_off) march_a(std::integral_constant<int, 3>{});
+        else if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
         else if (fronto) march_a(std::integral_constant<int, 1>{});
         else march_a(std::integral_constant<int, 2>{});
     } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
         // ================================================= role C =================================================
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
-        const bool general_plane = !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2)
+        const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2)
         // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
         // normalisation factors, the row part into the row's 1/count_y (0 * finite = 0, and v_cvt_rpi(+-0) = 0)
         const float kap_x = s1_col ? view.kapS * (float)s_rtab[nx] : 0.0f;

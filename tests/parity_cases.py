@@ -97,6 +97,12 @@ def case_naive(lib, windR=20, pm=True):
         ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
         got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes, mode=mode, check=True)
         worst = max(worst, compare_maps(got, ref, tight=NAIVE_TIGHT))
+        # which kernel served the lock-step: the march kernel (raw-cost patches + role A's one-tap path) where the radius has an
+        # instantiation and LES_HIP_KERNEL does not force the strip kernel; both must meet the same bound
+        bt = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+        want = 1 if (windR // 2 in (7, 10) and os.environ.get("LES_HIP_KERNEL", "") != "strip") else 0
+        assert bt.kernel_kind(mode) == want, (windR, bt.kernel_kind(mode))
+        bt.destroy()
     pr.close()
     return worst
 

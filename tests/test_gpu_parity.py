@@ -537,6 +537,14 @@ def test_gpu_naive_energy(oracle_mod):
     print("naive energy max abs err", worst)
     worst = pc.case_naive(None, windR=8)
     print("naive energy (windR 8) max abs err", worst)
+    worst = pc.case_naive(None, windR=14)            # radius 7: the other march-kernel instantiation
+    print("naive energy (windR 14) max abs err", worst)
+    os.environ["LES_HIP_KERNEL"] = "strip"           # the fp64 strip kernel of the same energy stays covered
+    try:
+        worst = pc.case_naive(None)
+    finally:
+        del os.environ["LES_HIP_KERNEL"]
+    print("naive energy (strip kernel) max abs err", worst)
 
 
 def test_gpu_quality_on_cones_crop_naive_energy():

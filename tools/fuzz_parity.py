@@ -180,6 +180,9 @@ def one_case(rng, lib, stats):
             ref = on.unary_batch(frs, trs, pl, mode=mode, check=True)
             got = en.unary_batch(frs, trs, pl, mode=mode, check=True)
             pc.compare_maps(got, ref, tight=False)
+        bt = api.Batch(en, frs, trs)
+        stats["naive_march"] = stats.get("naive_march", 0) + (1 if bt.kernel_kind(0) == 1 else 0)
+        bt.destroy()
         en.close()
         stats["naive"] = stats.get("naive", 0) + 1
 
@@ -203,7 +206,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
-          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut), {stats.get('naive', 0)} image-based energies, {stats.get('march', 0)} configurations on the march kernel, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut), {stats.get('naive', 0)} image-based energies ({stats.get('naive_march', 0)} of them on the march kernel), {stats.get('march', 0)} configurations on the march kernel, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
