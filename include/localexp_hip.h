@@ -64,7 +64,9 @@ int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_
  * colour + x-gradient difference between this view and the other view warped by the plane (StereoEnergy.h:702-742), then
  * the same guided-filter aggregation and validity rule.  params->D and the volume fields are ignored, th_col is
  * Parameters::th_col (10 for MiddV2), alpha / th_grad are Parameters::alpha / th_grad.  Both images are required.
- * Every other entry point (unary_one / unary_batch / batch_* / wta) works on the returned context unchanged. */
+ * Every other entry point (unary_one / unary_batch / batch_* / wta) works on the returned context unchanged.
+ * A prepared batch of such a context owns one raw-cost patch buffer per view (the sum of its filterRect areas in floats,
+ * allocated on the view's first les_hip_batch_run): runs of the same batch and view must be stream-ordered. */
 int les_hip_create_naive(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
                          float alpha, float th_grad);
 void les_hip_destroy(les_hip_ctx* ctx);                 /* replaces: ~CostVolumeEnergy (:50-52)          */

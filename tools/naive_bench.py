@@ -61,7 +61,8 @@ def child(args):
         p[:, 0] = rng.uniform(-0.05, 0.05, len(s))
         p[:, 2] = rng.uniform(0, 200, len(s))
         pls.append(torch.from_numpy(p).to(dev))
-    evals = int(sum((filt[s][:, 2].astype(np.int64) * filt[s][:, 3]).sum() for s in sets))
+    f4 = filt.view(np.int32).reshape(-1, 4)
+    evals = int(sum((f4[s][:, 2].astype(np.int64) * f4[s][:, 3]).sum() for s in sets))
 
     def cells():
         for b, p in zip(batches, pls):
