@@ -121,14 +121,18 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     graph.reset_for_load(w, h);
     // large regions: the node load and the segment read-out are split over the same number of threads as the first max-flow phase
     auto rows_parallel = [&](auto&& body) {
-        if (bands <= 1) { body(0, h); return; }
-        BandPool::mine().run(bands, [&](int b) { body((int)((long long)h * b / bands), (int)((long long)h * (b + 1) / bands)); });
+        if (bands <= 1) { body(0, 0, h); return; }
+        BandPool::mine().run(bands, [&](int b) { body(b, (int)((long long)h * b / bands), (int)((long long)h * (b + 1) / bands)); });
     };
-    rows_parallel([&](int y0, int y1) {
+    static const bool prepush = [] { const char* e = getenv("LES_GC_PREPUSH"); return !e || atoi(e) != 0; }();
+    std::vector<double> routed((size_t)std::max(1, bands), 0.0);
+    rows_parallel([&](int b, int y0, int y1) {
+        if (prepush) { routed[(size_t)b] = graph.load_rows_prepushed(payload, y0, y1); return; }
         for (int y = y0; y < y1; y++)
             for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
     });
     graph.set_base_flow(base_flow);
+    for (double f : routed) graph.add_base_flow(f);                         // (in band order: the sum does not depend on the threads' timing)
     const bool budgeted = (long long)w * h >= pushRelabelMinNodes();
     static const double band_ops = [] { const char* e = getenv("LES_GC_BK_BAND_OPS_PER_NODE"); return e ? atof(e) : -1.0; }();
     const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0, band_ops);
@@ -137,22 +141,21 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
         static thread_local GridPushRelabel pr_tls;
         GridPushRelabel& pr = pr_tls;
         pr.reset_for_load(w, h);
-        rows_parallel([&](int y0, int y1) {
+        rows_parallel([&](int, int y0, int y1) {
             float rc8[8], tr;
             for (int y = y0; y < y1; y++)
                 for (int x = 0; x < w; x++) { graph.residual(x, y, rc8, &tr); pr.load_residual(x, y, rc8, tr); }
         });
         pr.set_base_flow(flow);
         const double total = pr.maxflow();
-        rows_parallel([&](int y0, int y1) {
+        rows_parallel([&](int, int y0, int y1) {
             for (int y = y0; y < y1; y++)
                 for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = pr.what_segment(x, y) == GridPushRelabel::SOURCE ? 255 : 0;
         });
         return total;
     }
-    rows_parallel([&](int y0, int y1) {
-        for (int y = y0; y < y1; y++)
-            for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = graph.what_segment(x, y) == GridMaxFlow::SOURCE ? 255 : 0;
+    rows_parallel([&](int, int y0, int y1) {
+        for (int y = y0; y < y1; y++) graph.segment_row(y, mask + (size_t)y * w);
     });
     return flow;
 }

@@ -40,6 +40,7 @@ public:
         for (int k = 0; k < 8; k++) off_[k] = o[k];
         flow_ = 0;
         main_ = Ctx();
+        have_sign_ = false; lazy_ = false;
     }
     int id(int x, int y) const { return (y + 1) * pw_ + (x + 1); }
 
@@ -67,8 +68,12 @@ public:
         const size_t n = (size_t)(w + 2) * (h + 2);
         if (nodes_.size() < n) nodes_.resize(n);
         const Node blank;
-        for (int x = 0; x < pw_; x++) { nodes_[x] = blank; nodes_[(size_t)(h + 1) * pw_ + x] = blank; }
-        for (int y = 1; y <= h; y++) { nodes_[(size_t)y * pw_] = blank; nodes_[(size_t)y * pw_ + w + 1] = blank; }
+        // the byte maps (see load_node): every interior entry is written by load_node, the ring is "sink side, nothing to do"
+        if (sign_.size() < n) { sign_.resize(n); dirty_.resize(n); }
+        auto ring = [&](size_t i) { nodes_[i] = blank; sign_[i] = 0; dirty_[i] = 0; };
+        for (int x = 0; x < pw_; x++) { ring((size_t)x); ring((size_t)(h + 1) * pw_ + x); }
+        for (int y = 1; y <= h; y++) { ring((size_t)y * pw_); ring((size_t)y * pw_ + w + 1); }
+        have_sign_ = true; lazy_ = false;
         const int o[8] = {+1, -1, +pw_, -pw_, pw_ - 1, -pw_ + 1, pw_ + 1, -pw_ - 1};
         for (int k = 0; k < 8; k++) off_[k] = o[k];
         flow_ = 0;
@@ -80,8 +85,113 @@ public:
     {
         Node& n = nodes_[id(x, y)];
         n.rc[E] = p5[1]; n.rc[W] = 0; n.rc[S] = p5[2]; n.rc[N] = 0; n.rc[SW] = p5[3]; n.rc[NE] = 0; n.rc[SE] = p5[4]; n.rc[NW] = 0;
-        n.tr = p5[0]; n.next_active = NOT_QUEUED; n.ts = 0; n.dist = 0; n.parent = P_NONE; n.is_sink = 0;
+        const float tr = p5[0];
+        const bool src = tr > 0, snk = tr < 0;
+        n.tr = tr; n.next_active = NOT_QUEUED; n.ts = 0;
+        // the initial trees (what init_trees did in a pass of its own): terminal-connected nodes are roots at distance 1
+        n.dist = (src || snk) ? 1 : 0; n.parent = (src || snk) ? P_TERMINAL : P_NONE; n.is_sink = snk ? 1 : 0;
+        // Byte maps next to the 64-byte nodes.  Most moves of the later iterations are easy: nearly every node prefers its current label
+        // (tr < 0: a root of the sink tree) and so do its eight neighbours.  Such a node has nothing to do when it is taken from the
+        // active queue -- no free neighbour to claim, no source-tree neighbour to meet, equal distances so no re-parenting -- and unless
+        // an augmentation orphans it, it is on the sink side at the end.  sign_ lets init_trees leave those nodes out of the queue
+        // (the queue order of the others and every comparison of time stamps is unchanged: the clock ticks per node taken from the
+        // queue, and the events of two different ticks stay on different ticks); dirty_ lets the read-out skip them.
+        const size_t i = (size_t)id(x, y);
+        sign_[i] = src ? 2 : snk ? 0 : 1;
+        dirty_[i] = snk ? 0 : 1;
     }
+    // mask row for the caller: 255 = SOURCE segment (LES/FastGCStereo.h:557: the proposal is taken), 0 = SINK
+    void segment_row(int y, uint8_t* out) const
+    {
+        const size_t r = (size_t)(y + 1) * pw_ + 1;
+        if (lazy_) { for (int x = 0; x < w_; x++) out[x] = seg_[r + x] ? 0 : 255; return; }
+        if (!have_sign_) { for (int x = 0; x < w_; x++) out[x] = what_segment(x, y) == SOURCE ? 255 : 0; return; }
+        const uint8_t* d = &dirty_[r];
+        for (int x = 0; x < w_; x++) {
+            if (!d[x]) { out[x] = 0; continue; }
+            const Node& n = nodes_[r + x];
+            out[x] = (n.parent != P_NONE && n.is_sink) ? 0 : 255;
+        }
+    }
+    // Local pre-push for a graph loaded with load_node: rows [y0, y1), to be called before maxflow (once per row band, the bands
+    // may run on different threads; a band pushes only inside itself).  Returns the flow routed (add it with add_base_flow).
+    //
+    // Why: the expansion-move construction (LES/FastGCStereo.h:485-551) writes every pairwise term as +c at one endpoint, -c at
+    // the other and an arc between them that can carry c.  On the moves of an almost converged labelling 44 % of the nodes of a
+    // coarse cell come out with source excess -- and one sweep in which every such node pushes along its four forward arcs into
+    // neighbours with sink capacity cancels 99.5 % of it (a 387 x 387 cell: 28 896 units of flow, 36 left on 0.2 % of the nodes).
+    // The search trees then start from those few nodes instead of from every second one.  Any feasible flow may be routed first:
+    // every s-t cut loses the same amount, so the minimum cuts -- and the one the segment rule picks -- are unchanged.
+    //
+    // The sweep leaves the former excess nodes with tr == 0 ("free").  Growing the sink tree over them is what would cost the
+    // time now, so this mode does without: only source roots are queued (a search from the source side alone finds every
+    // augmenting path; sink roots stay roots, orphans are adopted as usual), and the segments are read off the residual graph
+    // afterwards by classify(): SINK = the nodes that can still reach a node with sink capacity, which is the same rule.
+    double prepush_rows(int y0, int y1)
+    {
+        lazy_ = true;
+        double routed = 0;
+        for (int y = y0; y < y1; y++) routed += prepush_row(y, y + 1 >= y1);
+        return routed;
+    }
+    // load_node for the rows [y0, y1) of a w x h payload (5 floats per node, row-major) with the pre-push of a row done as soon as
+    // the row below it is in place, while both are still in the cache
+    double load_rows_prepushed(const float* payload, int y0, int y1)
+    {
+        lazy_ = true;
+        double routed = 0;
+        for (int y = y0; y < y1; y++) {
+            const float* p = payload + 5 * (size_t)y * w_;
+            for (int x = 0; x < w_; x++) load_node(x, y, p + 5 * x);
+            if (y > y0) routed += prepush_row(y - 1, false);
+        }
+        if (y1 > y0) routed += prepush_row(y1 - 1, true);
+        return routed;
+    }
+    void add_base_flow(double f) { flow_ += f; }
+
+private:
+    double prepush_row(int y, bool last)
+    {
+        double routed = 0;
+        {
+            const size_t r = (size_t)(y + 1) * pw_ + 1;
+            for (int x = 0; x < w_; x++) {
+                Node& n = nodes_[r + x];
+                float e = n.tr;
+                if (e > 0) {
+                    static constexpr int kForward[4] = {E, S, SW, SE};      // the arcs that have capacity at load time
+                    for (int q = 0; q < 4 && e > 0; q++) {
+                        const int k = kForward[q];
+                        if (k != E && last) break;
+                        const float c = n.rc[k];
+                        if (!(c > 0)) continue;
+                        Node& m = nodes_[r + x + off_[k]];
+                        const float d = m.tr;
+                        if (!(d < 0)) continue;
+                        float f = e < c ? e : c;
+                        if (-d < f) f = -d;
+                        n.rc[k] = c - f; m.rc[k ^ 1] += f;
+                        e -= f; m.tr = d + f;
+                        routed += (double)f;
+                    }
+                    n.tr = e;
+                }
+            }
+            // row y is final now (rows above have pushed into it, it has pushed east and down): the initial trees and the maps
+            for (int x = 0; x < w_; x++) {
+                Node& n = nodes_[r + x];
+                const bool src = n.tr > 0, snk = n.tr < 0;
+                n.dist = (src || snk) ? 1 : 0; n.parent = (src || snk) ? P_TERMINAL : P_NONE; n.is_sink = snk ? 1 : 0;
+                sign_[r + x] = src ? 2 : snk ? 0 : 1;
+                dirty_[r + x] = snk ? 1 : 0;             // lazy mode: dirty_ is the map of the nodes with sink capacity (kept by augment)
+            }
+        }
+        return routed;
+    }
+
+public:
+
     void store_node(int x, int y, float* p5) const
     {
         const Node& n = nodes_[id(x, y)];
@@ -108,6 +218,7 @@ public:
             main_.budget = budget;
             init_trees(main_, 0, h_);
             exhausted_ = !search(main_);
+            if (lazy_ && !exhausted_) classify(1);
             return flow_ + main_.flow;
         }
         std::vector<int> row0(bands + 1);
@@ -138,11 +249,12 @@ public:
                 const int y = row0[b] + dy;
                 for (int x = 0; x < w_; x++) {
                     const int i = id(x, y);
-                    if (nodes_[i].parent != P_NONE) set_active(main_, i);
+                    if (nodes_[i].parent != P_NONE) set_active(main_, i);      // (lazy mode: set_active keeps the source-tree nodes only)
                 }
             }
         main_.budget = budget;
         exhausted_ = !search(main_);
+        if (lazy_ && !exhausted_) classify(bands);
         return flow_ + main_.flow;
     }
     // after maxflow(..., ops_per_node): true = the budget ran out; the return value is then the flow routed so far and residual(x, y)
@@ -157,6 +269,7 @@ public:
 
     termtype what_segment(int x, int y) const
     {
+        if (lazy_) return seg_[(size_t)id(x, y)] ? SINK : SOURCE;
         const Node& n = nodes_[id(x, y)];
         return (n.parent != P_NONE && n.is_sink) ? SINK : SOURCE;
     }
@@ -192,8 +305,82 @@ private:
     int off_[8];
     double flow_;                                  // flow routed by the t-links while the graph was built
     bool exhausted_ = false;
+    bool have_sign_ = false;                       // the graph was loaded with load_node: sign_ / dirty_ are valid
     std::vector<Node> nodes_;
+    std::vector<uint8_t> sign_;                    // per node at load time: 0 tr < 0, 1 tr == 0 (free), 2 tr > 0; read-only during the searches
+    bool lazy_ = false;                            // prepush_rows was used: sink trees are not grown, classify() reads the segments
+    std::vector<uint8_t> seg_;                     // lazy mode, after maxflow: 1 = the node can reach the sink in the residual graph
+    std::vector<int> bfs_;
+    std::vector<std::vector<int>> bandq_;          // per band: queue, nodes whose propagation crosses the band border
+    std::vector<uint8_t> dirty_;                   // 1: the node was not a sink root at load time or has been freed since (may be SOURCE at the end)
     Ctx main_;
+
+    // lazy mode: residual reachability of the sink.  Start: the nodes with sink capacity left; then every node with a residual arc
+    // into the set joins it: one raster pass that pulls, then a queue for what the raster order missed.  bands > 1: every row band
+    // does that inside itself on its own thread (it reads the neighbouring bands' bytes, which only ever change from 0 to 1, and
+    // never writes them); what would cross a band border is finished by one thread afterwards.  The result is the least fixed
+    // point whatever the interleaving.
+    static uint8_t ldb(const uint8_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+    static void stb(uint8_t* p) { __atomic_store_n(p, (uint8_t)1, __ATOMIC_RELAXED); }
+    void classify_rows(int y0, int y1, std::vector<int>& q, std::vector<int>* spill)
+    {
+        uint8_t* seg = seg_.data();
+        q.clear();
+        for (int y = y0; y < y1; y++) {
+            const size_t r = (size_t)(y + 1) * pw_ + 1;
+            const bool edge = spill && (y == y0 || y + 1 == y1);
+            for (int x = 0; x < w_; x++) {
+                const size_t i = r + x;
+                if (ldb(seg + i)) continue;
+                const Node& nd = nodes_[i];
+                for (int k = 0; k < 8; k++)
+                    if (nd.rc[k] > 0 && ldb(seg + i + off_[k])) {
+                        stb(seg + i);
+                        // the nodes later in raster order pull from this one themselves; only an undecided earlier neighbour needs the
+                        // queue (and, in a band, the rows next to another band: its thread may have passed already)
+                        if (edge || !(ldb(seg + i - 1) & ldb(seg + i - pw_ - 1) & ldb(seg + i - pw_) & ldb(seg + i - pw_ + 1))) q.push_back((int)i);
+                        break;
+                    }
+            }
+        }
+        const int lo = (y0 + 1) * pw_, hi = (y1 + 1) * pw_;          // node indices of the band's rows
+        for (size_t head = 0; head < q.size(); head++) {
+            const int u = q[head];
+            bool spilled = false;
+            for (int k = 0; k < 8; k++) {
+                const int v = u + off_[k];
+                if (ldb(seg + v) || !(nodes_[v].rc[k ^ 1] > 0)) continue;      // residual arc v -> u
+                if (spill && (v < lo || v >= hi)) { if (!spilled) { spill->push_back(u); spilled = true; } continue; }
+                stb(seg + v);
+                q.push_back(v);
+            }
+        }
+    }
+    void classify(int bands)
+    {
+        const size_t n = (size_t)pw_ * (h_ + 2);
+        if (seg_.size() < n) seg_.resize(n);
+        std::copy(dirty_.begin(), dirty_.begin() + n, seg_.begin());
+        if (bands <= 1) { classify_rows(0, h_, bfs_, nullptr); return; }
+        if ((int)bandq_.size() < 2 * bands) bandq_.resize((size_t)2 * bands);
+        BandPool::mine().run(bands, [&](int b) {
+            bandq_[2 * b + 1].clear();
+            classify_rows((int)((long long)h_ * b / bands), (int)((long long)h_ * (b + 1) / bands), bandq_[2 * b], &bandq_[2 * b + 1]);
+        });
+        // across the borders: the spilled nodes once more, now without a fence
+        bfs_.clear();
+        for (int b = 0; b < bands; b++) bfs_.insert(bfs_.end(), bandq_[2 * b + 1].begin(), bandq_[2 * b + 1].end());
+        uint8_t* seg = seg_.data();
+        for (size_t head = 0; head < bfs_.size(); head++) {
+            const int u = bfs_[head];
+            for (int k = 0; k < 8; k++) {
+                const int v = u + off_[k];
+                if (seg[v] || !(nodes_[v].rc[k ^ 1] > 0)) continue;
+                seg[v] = 1;
+                bfs_.push_back(v);
+            }
+        }
+    }
 
     void markPadding()
     {
@@ -206,6 +393,7 @@ private:
     void set_active(Ctx& c, int i)
     {
         if (nodes_[i].next_active != NOT_QUEUED) return;
+        if (lazy_ && nodes_[i].is_sink) return;                 // lazy mode: the search runs from the source side only (see prepush_rows)
         nodes_[i].next_active = i;
         if (c.queue_last[1] != NONE_NODE) nodes_[c.queue_last[1]].next_active = i;
         else c.queue_first[1] = i;
@@ -229,6 +417,22 @@ private:
     }
     void init_trees(Ctx& c, int y0, int y1)
     {
+        if (have_sign_) {
+            // the trees were set up by load_node; queue the source roots and the sink roots with a neighbour that is not a sink root
+            std::vector<uint8_t> f((size_t)pw_);
+            for (int y = y0; y < y1; y++) {
+                const size_t r = (size_t)(y + 1) * pw_;
+                const uint8_t *a = &sign_[r - pw_], *b = &sign_[r], *d = &sign_[r + pw_];
+                if (lazy_) {
+                    for (int x = 1; x <= w_; x++) if (b[x] == 2) set_active(c, (int)(r + x));
+                    continue;
+                }
+                for (int x = 1; x <= w_; x++) f[x] = (uint8_t)(a[x - 1] | a[x] | a[x + 1] | b[x - 1] | b[x + 1] | d[x - 1] | d[x] | d[x + 1]);
+                for (int x = 1; x <= w_; x++)
+                    if (b[x] == 2 || (b[x] == 0 && f[x])) set_active(c, (int)(r + x));
+            }
+            return;
+        }
         for (int y = y0; y < y1; y++)
             for (int x = 0; x < w_; x++) {
                 const int i = id(x, y);
@@ -340,7 +544,7 @@ private:
             const int p = nodes_[i].parent;
             if (p == P_TERMINAL) {
                 nodes_[i].tr += bottleneck;
-                if (!(nodes_[i].tr < 0)) make_orphan(c, i);
+                if (!(nodes_[i].tr < 0)) { make_orphan(c, i); if (lazy_) dirty_[i] = 0; }
                 break;
             }
             const int m = i + off_[p];
@@ -404,6 +608,7 @@ private:
             }
         }
         ni.parent = P_NONE;
+        if (have_sign_ && !lazy_) dirty_[i] = 1;
     }
 };
 

@@ -287,6 +287,14 @@ class PMRunner:
                                 if dump:
                                     with open(os.path.join(dump, f"cutlog_view{m}.txt"), "a") as f:
                                         f.write(f"{iteration} {li} {kind} {it} {sh.n} {t2 - t1:.6f}\n")
+                                every = int(os.environ.get("LES_DUMP_EVERY", "0")) if dump else 0   # tooling: a sample of ordinary lock-steps (first two cells of every N-th one that was cut on the host)
+                                if every and not on_dev:
+                                    self._dump_count = getattr(self, "_dump_count", 0) + 1
+                                    if self._dump_count % every == 0:
+                                        k2 = min(2, sh.n)
+                                        nn = int(sh.graph_off[k2 - 1] + int(sh.regions[k2 - 1]["w"]) * int(sh.regions[k2 - 1]["h"]))
+                                        np.savez_compressed(os.path.join(dump, f"sample_view{m}_it{iteration}_layer{li}_{self._dump_count}.npz"), regions=sh.regions[:k2],
+                                                            offsets=sh.graph_off[:k2], payload=sh.payload_host.numpy()[: nn * 5].copy(), seconds=t2 - t1, cells=sh.n)
                                 if dump and li == len(self.shards) - 1 and iteration >= 1 and t2 - t1 > getattr(self, "_dump_worst", 0.012):
                                     self._dump_worst = t2 - t1
                                     nn = int(sh.graph_off[-1] + int(sh.regions[-1]["w"]) * int(sh.regions[-1]["h"]))

@@ -136,7 +136,7 @@ static int grid_vs_generic()
 static int push_relabel_vs_bk()
 {
     RNG rng(4711);
-    int fail = 0, trials = 0, hybrids = 0, exhausted_none = 0;
+    int fail = 0, trials = 0, hybrids = 0, exhausted_none = 0, prepushed = 0;
     const int shapes[][2] = {{1, 1}, {2, 1}, {1, 7}, {9, 1}, {2, 2}, {5, 3}, {16, 12}, {33, 27}, {64, 48}, {97, 61}, {120, 90}};
     for (const auto& sh : shapes)
         for (int variant = 0; variant < 6; variant++, trials++) {
@@ -167,6 +167,28 @@ static int push_relabel_vs_bk()
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) diff += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
             if (fb != fp || diff) { printf("FAIL push-relabel vs BK %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", w, h, variant, fp, fb, diff); fail = 1; }
+            // the path the drivers take (expansionMovePrebuilt): local pre-push while loading, search from the source side only, segments by
+            // residual reachability of the sink -- one band, and row bands loaded / pre-pushed / classified separately
+            for (int nb : {1, 3, 5}) {
+                if (nb > 1 && h < 8 * nb) continue;
+                GridMaxFlow lz;
+                lz.reset_for_load(w, h);
+                double routed = 0;
+                for (int b2 = 0; b2 < nb; b2++) routed += lz.load_rows_prepushed(pay.data(), (int)((long long)h * b2 / nb), (int)((long long)h * (b2 + 1) / nb));
+                lz.add_base_flow(routed);
+                const double fl = lz.maxflow(nb);
+                int dl = 0;
+                std::vector<uint8_t> row((size_t)w);
+                for (int y = 0; y < h; y++) {
+                    lz.segment_row(y, row.data());
+                    for (int x = 0; x < w; x++) {
+                        dl += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (lz.what_segment(x, y) == GridMaxFlow::SOURCE);
+                        dl += (row[x] != 0) != (bk.what_segment(x, y) == GridMaxFlow::SOURCE);
+                    }
+                }
+                prepushed++;
+                if (fl != fb || dl) { printf("FAIL pre-push path (%d bands) %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", nb, w, h, variant, fl, fb, dl); fail = 1; }
+            }
             // the hybrid of expansionMovePrebuilt: BK until a (here: tiny) work budget runs out, push-relabel on the residual graph
             for (double budget : {0.25, 1.5, 4.0}) {
                 GridMaxFlow part;
@@ -205,7 +227,7 @@ static int push_relabel_vs_bk()
         for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) diff += (mask[(size_t)y * w + x] != 0) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
         if (fb != fp || diff) { printf("FAIL push-relabel vs expansionMovePrebuilt: flow %.1f vs %.1f, %d differences\n", fp, fb, diff); fail = 1; }
     }
-    printf("push-relabel vs Boykov-Kolmogorov: %d random grids %s; %d of them also cut as BK-with-a-budget + push-relabel on the residual graph\n", trials, fail ? "FAILED" : "identical", hybrids);
+    printf("push-relabel vs Boykov-Kolmogorov: %d random grids %s; %d of them also cut as BK-with-a-budget + push-relabel on the residual graph, %d runs of the pre-push path\n", trials, fail ? "FAILED" : "identical", hybrids, prepushed);
     return fail;
 }
 
