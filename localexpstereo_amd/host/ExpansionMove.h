@@ -97,6 +97,10 @@ inline double expansionMove(const StereoEnergy& E, const LabelMap& currentLabeli
 // finishes on the residual graph.  Both return the canonical cut; budget and threshold are functions of the region size only, so every
 // rank and every host cuts a given cell the same way.  LES_GC_PUSH_RELABEL_MIN_NODES overrides the threshold (0: never switch),
 // LES_GC_BK_OPS_PER_NODE the budget (A/B measurements).
+// The budget: since the graphs are pre-pushed while they are loaded (GridMaxFlow::load_rows_prepushed: the search starts from the 0.2 .. 1 %
+// of the nodes that still have source excess) an ordinary move needs 0.05 .. 1.6 operations per node, the moves on which the trees are
+// rebuilt over and over 5 .. 70 (sampled lock-steps of a two-view run, tools/cut_replay.py / DESIGN 6.3); 3 separates the two and costs a
+// hard 129 x 129 cell about a millisecond before push-relabel takes over.  (It was 12 when every node started in the queue.)
 inline long long pushRelabelMinNodes()
 {
     static const long long v = [] {
@@ -109,7 +113,7 @@ inline long long pushRelabelMinNodes()
 }
 inline double bkOpsPerNode()
 {
-    static const double v = [] { const char* e = getenv("LES_GC_BK_OPS_PER_NODE"); return e ? atof(e) : 12.0; }();
+    static const double v = [] { const char* e = getenv("LES_GC_BK_OPS_PER_NODE"); return e ? atof(e) : 3.0; }();
     return v;
 }
 

@@ -136,7 +136,8 @@ public:
     }
     // load_node for the rows [y0, y1) of a w x h payload (5 floats per node, row-major) with the pre-push of a row done as soon as
     // the row below it is in place, while both are still in the cache
-    double load_rows_prepushed(const float* payload, int y0, int y1)
+    // sources (optional): += the number of nodes of these rows that still have source excess afterwards
+    double load_rows_prepushed(const float* payload, int y0, int y1, long long* sources = nullptr)
     {
         lazy_ = true;
         double routed = 0;
@@ -146,6 +147,14 @@ public:
             if (y > y0) routed += prepush_row(y - 1, false);
         }
         if (y1 > y0) routed += prepush_row(y1 - 1, true);
+        if (sources) {
+            long long n = 0;
+            for (int y = y0; y < y1; y++) {
+                const uint8_t* sg = &sign_[(size_t)(y + 1) * pw_ + 1];
+                for (int x = 0; x < w_; x++) n += sg[x] == 2;
+            }
+            *sources += n;
+        }
         return routed;
     }
     void add_base_flow(double f) { flow_ += f; }

@@ -1,6 +1,9 @@
 // les_gc.cpp -- C ABI (include/localexp_host.h) over the host graph-cut fusion (ExpansionMove.h / MaxFlow.h).
 #include "../../include/localexp_host.h"
 
+#include <chrono>
+#include <thread>
+#include <functional>
 #include <omp.h>
 
 #include <cstdarg>
@@ -156,12 +159,20 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
     }
     nthreads = defaultThreads(nthreads, n);
     tuneBandSpin(n, nthreads, [&](int i) { return Rect(0, 0, regions[i].w, regions[i].h); });
+    // tooling (LES_GC_TRACE=file): wall-clock of every call as seen from inside, one line per call
+    static FILE* trace = [] { const char* p = getenv("LES_GC_TRACE"); return p ? fopen(p, "a") : (FILE*)nullptr; }();
+    const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int i = 0; i < n; i++) {
         const Rect region(0, 0, regions[i].w, regions[i].h);
         if (region.width <= 0 || region.height <= 0) continue;
         const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, masks + offsets[i], bandsFor(region, n));
         if (flows) flows[i] = flow;
+    }
+    if (trace) {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(trace, "%zx %d %d %d %.6f\n", std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffff, n, n > 0 ? regions[0].w : 0, nthreads, dt);
+        fflush(trace);
     }
     return 0;
 }

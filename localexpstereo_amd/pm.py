@@ -288,10 +288,10 @@ class PMRunner:
                                     with open(os.path.join(dump, f"cutlog_view{m}.txt"), "a") as f:
                                         f.write(f"{iteration} {li} {kind} {it} {sh.n} {t2 - t1:.6f}\n")
                                 every = int(os.environ.get("LES_DUMP_EVERY", "0")) if dump else 0   # tooling: a sample of ordinary lock-steps (first two cells of every N-th one that was cut on the host)
-                                if every and not on_dev:
+                                if every and not on_dev and os.environ.get("LES_DUMP_VIEW", str(m)) == str(m):
                                     self._dump_count = getattr(self, "_dump_count", 0) + 1
                                     if self._dump_count % every == 0:
-                                        k2 = min(2, sh.n)
+                                        k2 = sh.n if os.environ.get("LES_DUMP_FULL") else min(2, sh.n)
                                         nn = int(sh.graph_off[k2 - 1] + int(sh.regions[k2 - 1]["w"]) * int(sh.regions[k2 - 1]["h"]))
                                         np.savez_compressed(os.path.join(dump, f"sample_view{m}_it{iteration}_layer{li}_{self._dump_count}.npz"), regions=sh.regions[:k2],
                                                             offsets=sh.graph_off[:k2], payload=sh.payload_host.numpy()[: nn * 5].copy(), seconds=t2 - t1, cells=sh.n)

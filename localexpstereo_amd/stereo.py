@@ -5,6 +5,7 @@ What runs where: proposals, unary costs, winner-take-all updates, post-processin
 (liblocalexp_hip.so); graph cuts of the main iterations -> host cores (liblocalexp_host.so); file formats and the
 Evaluator -> numpy (io.py).  One process per GPU: pass rank/world to shard the cells of every disjoint set.
 """
+import os
 import time
 
 import numpy as np
@@ -31,6 +32,11 @@ class FastGCStereo:
         # slow ones (7-8 s of the 10 s of cuts) and then sit on the critical path of every lock-step, so it is not the default.
         self.concurrent_views = world == 1 and int(np.asarray(imL).shape[0]) * int(np.asarray(imL).shape[1]) >= 500_000
         self.joint_views = False
+        if os.environ.get("LES_VIEWS"):                 # tooling: "joint" | "concurrent" | "serial" | "concurrent-swapped"
+            v = os.environ["LES_VIEWS"]
+            self.joint_views = v == "joint"
+            self.concurrent_views = v.startswith("concurrent")
+            self._swap_view_threads = v == "concurrent-swapped"
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
         self.device_cuts = None                  # None: cut the cells that fit a workgroup's LDS on the GPU when there is one (pm.PMRunner.begin_gc)
 
@@ -152,7 +158,7 @@ class FastGCStereo:
                                 one_view(m, it, per_view)
                         except BaseException as ex:          # re-raised in the caller's thread below
                             errors.append(ex)
-                    ths = [threading.Thread(target=guarded, args=(m,)) for m in viewModes]
+                    ths = [threading.Thread(target=guarded, args=(m,)) for m in (reversed(viewModes) if getattr(self, "_swap_view_threads", False) else viewModes)]
                     for th in ths:
                         th.start()
                     for th in ths:

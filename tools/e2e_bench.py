@@ -38,14 +38,26 @@ def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0
     volL = ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
     t_scene = time.perf_counter() - t0
     data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    def cpu_stat():
+        # cgroup CPU accounting: a process that keeps more threads busy than its quota grants is stopped until the next period
+        try:
+            return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat")) if k in ("usage_usec", "nr_throttled", "throttled_usec")}
+        except Exception:
+            return {}
+    c0 = cpu_stat()
     t1 = time.perf_counter()
     st, lab, raw = stereo.MidV3(data, volL, None, iterations=iterations, pmIterations=pm_iterations, doDual=bool(dual),
                                 smooth_weight=smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=host_threads)
     t_total = time.perf_counter() - t1
+    c1 = cpu_stat()
+    cpu = {k: c1[k] - c0[k] for k in c0 if k in c1}
+    if "usage_usec" in cpu:
+        cpu = {"cpu_seconds": round(cpu["usage_usec"] * 1e-6, 2), "mean_cpus_busy": round(cpu["usage_usec"] * 1e-6 / t_total, 2),
+               "periods_throttled": cpu.get("nr_throttled"), "seconds_throttled": round(cpu.get("throttled_usec", 0) * 1e-6, 3)}
     rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
     return dict(shape=[W, H, D], iterations=iterations, pm_iterations=pm_iterations, dual=bool(dual), host_cores=os.cpu_count(),
                 seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
-                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, log=rows)
+                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, cgroup_cpu=cpu, host_threads=host_threads, log=rows)
 
 
 def main():
