@@ -138,7 +138,9 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     graph.set_base_flow(base_flow);
     for (double f : routed) graph.add_base_flow(f);                         // (in band order: the sum does not depend on the threads' timing)
     const bool budgeted = (long long)w * h >= pushRelabelMinNodes();
-    static const double band_ops = [] { const char* e = getenv("LES_GC_BK_BAND_OPS_PER_NODE"); return e ? atof(e) : -1.0; }();
+    // (the band searches of the coarsest layer's cells run in parallel while the push-relabel that would take over does not: they get four
+    // times the allowance -- two-view run at the Adirondack shape: 6.2 s with 12 per band node, 6.5 with 3 or 40, 6.8 with 200)
+    static const double band_ops = [] { const char* e = getenv("LES_GC_BK_BAND_OPS_PER_NODE"); return e ? atof(e) : 4.0 * bkOpsPerNode(); }();
     const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0, band_ops);
     if (graph.exhausted()) {
         // a hard move: push-relabel continues from the feasible flow found so far

@@ -1,7 +1,11 @@
 // les_gc.cpp -- C ABI (include/localexp_host.h) over the host graph-cut fusion (ExpansionMove.h / MaxFlow.h).
 #include "../../include/localexp_host.h"
 
+#include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include <thread>
 #include <functional>
 #include <omp.h>
@@ -162,12 +166,38 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
     // tooling (LES_GC_TRACE=file): wall-clock of every call as seen from inside, one line per call
     static FILE* trace = [] { const char* p = getenv("LES_GC_TRACE"); return p ? fopen(p, "a") : (FILE*)nullptr; }();
     const auto t0 = std::chrono::steady_clock::now();
+    // Longest cell first.  A lock-step lasts as long as its slowest cell, and one hard cell (10 .. 50 x the median) that the
+    // dynamic schedule hands out last adds its whole length to the lock-step.  The drivers call with the same payload buffer for the same
+    // cells of a disjoint set, proposal after proposal, and a cell that was hard is usually hard again: the time each cell took is
+    // remembered under the address of its payload and the next call starts the cells in decreasing order of it.  (Only the order in
+    // which independent cells are started changes, never a result.)
+    static std::mutex hist_mu;
+    static std::unordered_map<const float*, float> hist;
+    std::vector<int> order((size_t)n);
+    std::vector<float> cost((size_t)n, 0.0f);
+    {
+        std::lock_guard<std::mutex> lk(hist_mu);
+        for (int i = 0; i < n; i++) {
+            order[(size_t)i] = i;
+            auto it = hist.find(payload + 5 * offsets[i]);
+            cost[(size_t)i] = it != hist.end() ? it->second : 1e-9f * (float)regions[i].w * (float)regions[i].h;
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int i = 0; i < n; i++) {
+    for (int q = 0; q < n; q++) {
+        const int i = order[(size_t)q];
         const Rect region(0, 0, regions[i].w, regions[i].h);
         if (region.width <= 0 || region.height <= 0) continue;
+        const auto c0 = std::chrono::steady_clock::now();
         const double flow = expansionMovePrebuilt(payload + 5 * offsets[i], 0.0, region, masks + offsets[i], bandsFor(region, n));
+        cost[(size_t)i] = std::chrono::duration<float>(std::chrono::steady_clock::now() - c0).count();
         if (flows) flows[i] = flow;
+    }
+    {
+        std::lock_guard<std::mutex> lk(hist_mu);
+        if (hist.size() > (1u << 20)) hist.clear();                 // (buffers come and go with the runs of a long-lived process)
+        for (int i = 0; i < n; i++) hist[payload + 5 * offsets[i]] = cost[(size_t)i];
     }
     if (trace) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
