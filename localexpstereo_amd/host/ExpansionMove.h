@@ -153,7 +153,7 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
                 for (int x = 0; x < w; x++) { graph.residual(x, y, rc8, &tr); pr.load_residual(x, y, rc8, tr); }
         });
         pr.set_base_flow(flow);
-        const double total = pr.maxflow();
+        const double total = pr.maxflow(bands);                 // (the coarsest layer's cells: the same row bands as the search)
         rows_parallel([&](int, int y0, int y1) {
             for (int y = y0; y < y1; y++)
                 for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = pr.what_segment(x, y) == GridPushRelabel::SOURCE ? 255 : 0;

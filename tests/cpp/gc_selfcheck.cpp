@@ -136,7 +136,7 @@ static int grid_vs_generic()
 static int push_relabel_vs_bk()
 {
     RNG rng(4711);
-    int fail = 0, trials = 0, hybrids = 0, exhausted_none = 0, prepushed = 0;
+    int fail = 0, trials = 0, hybrids = 0, exhausted_none = 0, prepushed = 0, banded_pr = 0;
     const int shapes[][2] = {{1, 1}, {2, 1}, {1, 7}, {9, 1}, {2, 2}, {5, 3}, {16, 12}, {33, 27}, {64, 48}, {97, 61}, {120, 90}};
     for (const auto& sh : shapes)
         for (int variant = 0; variant < 6; variant++, trials++) {
@@ -167,6 +167,20 @@ static int push_relabel_vs_bk()
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) diff += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
             if (fb != fp || diff) { printf("FAIL push-relabel vs BK %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", w, h, variant, fp, fb, diff); fail = 1; }
+            // push-relabel with the band-parallel first phase
+            for (int nb : {2, 4, 7}) {
+                if (h < 8 * nb) continue;
+                GridPushRelabel pb;
+                pb.reset_for_load(w, h);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) pb.load_node(x, y, &pay[5 * ((size_t)y * w + x)]);
+                const double fpb = pb.maxflow(nb);
+                int db = 0;
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) db += (bk.what_segment(x, y) == GridMaxFlow::SOURCE) != (pb.what_segment(x, y) == GridPushRelabel::SOURCE);
+                banded_pr++;
+                if (fpb != fb || db) { printf("FAIL banded push-relabel (%d bands) %dx%d variant %d: flow %.1f vs %.1f, %d segment differences\n", nb, w, h, variant, fpb, fb, db); fail = 1; }
+            }
             // the path the drivers take (expansionMovePrebuilt): local pre-push while loading, search from the source side only, segments by
             // residual reachability of the sink -- one band, and row bands loaded / pre-pushed / classified separately
             for (int nb : {1, 3, 5}) {
@@ -227,7 +241,7 @@ static int push_relabel_vs_bk()
         for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) diff += (mask[(size_t)y * w + x] != 0) != (pr.what_segment(x, y) == GridPushRelabel::SOURCE);
         if (fb != fp || diff) { printf("FAIL push-relabel vs expansionMovePrebuilt: flow %.1f vs %.1f, %d differences\n", fp, fb, diff); fail = 1; }
     }
-    printf("push-relabel vs Boykov-Kolmogorov: %d random grids %s; %d of them also cut as BK-with-a-budget + push-relabel on the residual graph, %d runs of the pre-push path\n", trials, fail ? "FAILED" : "identical", hybrids, prepushed);
+    printf("push-relabel vs Boykov-Kolmogorov: %d random grids %s; %d of them also cut as BK-with-a-budget + push-relabel on the residual graph, %d runs of the pre-push path, %d of push-relabel with a band-parallel first phase\n", trials, fail ? "FAILED" : "identical", hybrids, prepushed, banded_pr);
     return fail;
 }
 

@@ -180,7 +180,7 @@ def test_sim_proposers(cones):
 
 
 def test_sim_pm_iteration(sim_lib, oracle_mod):
-    pr = pc.synth_pair(sim_lib, 56, 76, 10)
+    pr = pc.synth_pair(sim_lib, 48, 64, 10)
     try:
         steps, worst = pc.case_pm_iteration(pr, layers_units=(10, 30), plane_exact=True)
         assert steps > 100 and worst <= pc.TIGHT
