@@ -9,6 +9,10 @@
 // A pixel takes the proposal iff it ends on the SOURCE side (:555-559).
 #pragma once
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 #include "BandPool.h"
@@ -117,8 +121,36 @@ inline double bkOpsPerNode()
     return v;
 }
 
+// tooling (LES_GC_PROFILE=1): where the time of the prebuilt cuts goes, summed over all threads, printed when the process ends
+struct CutProfile {
+    std::atomic<long long> ns[5], cells[3], nodes[3];          // phases: load + pre-push, search, hand-over, push-relabel, read-out; classes: small, large, large handed over
+    static CutProfile& get() { static CutProfile p; return p; }
+    static bool on() { static const bool v = [] { const char* e = getenv("LES_GC_PROFILE"); return e && atoi(e) != 0; }(); return v; }
+    CutProfile()
+    {
+        for (auto& x : ns) x = 0;
+        for (auto& x : cells) x = 0;
+        for (auto& x : nodes) x = 0;
+        if (on()) atexit([] {
+            CutProfile& p = get();
+            fprintf(stderr, "host cuts (all threads): load+prepush %.3f s, search %.3f s, hand-over %.3f s, push-relabel %.3f s, read-out %.3f s | cells: %lld searched only (%lld nodes), %lld large searched only (%lld), %lld handed to push-relabel (%lld)\n",
+                    p.ns[0] * 1e-9, p.ns[1] * 1e-9, p.ns[2] * 1e-9, p.ns[3] * 1e-9, p.ns[4] * 1e-9, (long long)p.cells[0], (long long)p.nodes[0], (long long)p.cells[1], (long long)p.nodes[1],
+                    (long long)p.cells[2], (long long)p.nodes[2]);
+        });
+    }
+};
+
 inline double expansionMovePrebuilt(const float* payload, double base_flow, const Rect& region, uint8_t* mask, int bands = 1)
 {
+    const bool prof = CutProfile::on();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](int phase, std::chrono::steady_clock::time_point& t) {
+        if (!prof) return;
+        const auto t1 = now();
+        CutProfile::get().ns[phase] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t).count();
+        t = t1;
+    };
+    auto tp = prof ? now() : std::chrono::steady_clock::time_point();
     static thread_local GridMaxFlow graph_tls;
     GridMaxFlow& graph = graph_tls;                 // (a reference: the helper threads below must use THIS thread's solver, not their own)
     const int w = region.width, h = region.height;
@@ -135,6 +167,7 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
         for (int y = y0; y < y1; y++)
             for (int x = 0; x < w; x++) graph.load_node(x, y, payload + 5 * ((size_t)y * w + x));
     });
+    lap(0, tp);
     graph.set_base_flow(base_flow);
     for (double f : routed) graph.add_base_flow(f);                         // (in band order: the sum does not depend on the threads' timing)
     const bool budgeted = (long long)w * h >= pushRelabelMinNodes();
@@ -142,6 +175,8 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
     // times the allowance -- two-view run at the Adirondack shape: 6.2 s with 12 per band node, 6.5 with 3 or 40, 6.8 with 200)
     static const double band_ops = [] { const char* e = getenv("LES_GC_BK_BAND_OPS_PER_NODE"); return e ? atof(e) : 4.0 * bkOpsPerNode(); }();
     const double flow = graph.maxflow(bands, budgeted ? bkOpsPerNode() : 0.0, band_ops);
+    lap(1, tp);
+    if (prof) { const int cls = graph.exhausted() ? 2 : budgeted ? 1 : 0; CutProfile::get().cells[cls]++; CutProfile::get().nodes[cls] += (long long)w * h; }
     if (graph.exhausted()) {
         // a hard move: push-relabel continues from the feasible flow found so far
         static thread_local GridPushRelabel pr_tls;
@@ -153,16 +188,20 @@ inline double expansionMovePrebuilt(const float* payload, double base_flow, cons
                 for (int x = 0; x < w; x++) { graph.residual(x, y, rc8, &tr); pr.load_residual(x, y, rc8, tr); }
         });
         pr.set_base_flow(flow);
+        lap(2, tp);
         const double total = pr.maxflow(bands);                 // (the coarsest layer's cells: the same row bands as the search)
+        lap(3, tp);
         rows_parallel([&](int, int y0, int y1) {
             for (int y = y0; y < y1; y++)
                 for (int x = 0; x < w; x++) mask[(size_t)y * w + x] = pr.what_segment(x, y) == GridPushRelabel::SOURCE ? 255 : 0;
         });
+        lap(4, tp);
         return total;
     }
     rows_parallel([&](int, int y0, int y1) {
         for (int y = y0; y < y1; y++) graph.segment_row(y, mask + (size_t)y * w);
     });
+    lap(4, tp);
     return flow;
 }
 // Row bands of the parallel first max-flow phase: only for large regions (the coarsest layer: 4-6 cells of ~400 x 400 nodes per
