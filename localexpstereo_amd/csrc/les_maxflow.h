@@ -72,7 +72,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     float* sentA = ex + NP;                                // what a node pushed along the first / second direction of the pass
     float* sentB = sentA + NP;
     uint16_t* hgt = reinterpret_cast<uint16_t*>(sentB + NP);
-    int* flag = reinterpret_cast<int*>(hgt + NP);          // [0] any active, [1] relabel sweep changed something
+    int* flag = reinterpret_cast<int*>(hgt + NP);          // [0] any active, [1..3] relabel sweep changed something (rotating)
 
     const GraphCellMf c = cells[blockIdx.x];
     const int W = c.w, H = c.h, N = W * H;
@@ -122,10 +122,15 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             d[j] = (v < N && ex[v] < 0.0f) ? 1 : BIG;
             if (v < N) dist[v] = d[j];
         }
+        if (tid < 3) flag[1 + tid] = 0;
         __syncthreads();
-        for (;;) {
-            if (tid == 0) flag[1] = 0;
-            __syncthreads();
+        // Chaotic relaxation: a node takes min(own, neighbour + 1) over the LIVE distances (another lane may have lowered a neighbour
+        // in this very sweep: the values only fall and the fixed point -- the breadth-first distances -- is the same whatever the order),
+        // so an update can travel several hops per sweep, and a sweep costs one barrier: "did anything change" rotates through three
+        // flags (the one for sweep s + 1 is cleared during sweep s, two barriers after its last reader).
+        for (int s = 0;; s++) {
+            const int cur = 1 + s % 3, nxt = 1 + (s + 1) % 3;
+            if (tid == 0) flag[nxt] = 0;
             dbg_sweeps++;
             bool changed = false;
 #pragma unroll
@@ -143,18 +148,11 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
                     const int dw = dist[w] + 1;
                     best = (rk[k] > 0.0f && dw < best) ? dw : best;
                 }
-                if (best < d[j]) { d[j] = best; changed = true; }
+                if (best < d[j]) { d[j] = best; dist[v] = best; changed = true; }
             }
-            __syncthreads();                                                 // every lane has read the old distances
-#pragma unroll
-            for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
-                if (v < N) dist[v] = d[j];
-            }
-            if (changed) flag[1] = 1;
+            if (changed) flag[cur] = 1;
             __syncthreads();
-            if (!flag[1]) break;
-            __syncthreads();
+            if (!flag[cur]) break;
         }
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
