@@ -169,17 +169,24 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
     // Longest cell first.  A lock-step lasts as long as its slowest cell, and one hard cell (10 .. 50 x the median) that the
     // dynamic schedule hands out last adds its whole length to the lock-step.  The drivers call with the same payload buffer for the same
     // cells of a disjoint set, proposal after proposal, and a cell that was hard is usually hard again: the time each cell took is
-    // remembered under the address of its payload and the next call starts the cells in decreasing order of it.  (Only the order in
+    // remembered under (staging buffer, cell rect) and the next call starts the cells in decreasing order of it.  (Only the order in
     // which independent cells are started changes, never a result.)
     static std::mutex hist_mu;
-    static std::unordered_map<const float*, float> hist;
+    static std::unordered_map<unsigned long long, float> hist;
+    // (the drivers stage every lock-step of a view in one buffer: the cell is identified by buffer, position and size)
+    auto key = [&](int i) {
+        unsigned long long k = (unsigned long long)(uintptr_t)payload;
+        for (unsigned long long v : {(unsigned long long)(unsigned)regions[i].x, (unsigned long long)(unsigned)regions[i].y, (unsigned long long)(unsigned)regions[i].w, (unsigned long long)(unsigned)regions[i].h})
+            k = (k ^ v) * 0x9E3779B97F4A7C15ull + (k >> 29);
+        return k;
+    };
     std::vector<int> order((size_t)n);
     std::vector<float> cost((size_t)n, 0.0f);
     {
         std::lock_guard<std::mutex> lk(hist_mu);
         for (int i = 0; i < n; i++) {
             order[(size_t)i] = i;
-            auto it = hist.find(payload + 5 * offsets[i]);
+            auto it = hist.find(key(i));
             cost[(size_t)i] = it != hist.end() ? it->second : 1e-9f * (float)regions[i].w * (float)regions[i].h;
         }
     }
@@ -197,7 +204,7 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
     {
         std::lock_guard<std::mutex> lk(hist_mu);
         if (hist.size() > (1u << 20)) hist.clear();                 // (buffers come and go with the runs of a long-lived process)
-        for (int i = 0; i < n; i++) hist[payload + 5 * offsets[i]] = cost[(size_t)i];
+        for (int i = 0; i < n; i++) hist[key(i)] = cost[(size_t)i];
     }
     if (trace) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
