@@ -308,10 +308,12 @@ def main():
                 rec = {}
                 for dual in (0, 1):
                     r = e2e_bench.run(dual=dual, quiet=True)
-                    rec["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
+                    rec["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "seconds_reference_clock", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
                 from localexpstereo_amd.gc import cpu_budget
                 rec["host_cpus"] = cpu_budget()
-                rec["note"] = "synthetic pair at the Adirondack-H shape (the data set is not in the container); MidV3 defaults: layers 14/43/129, 2 PatchMatch + 5 graph-cut iterations"
+                rec["note"] = ("synthetic pair at the Adirondack-H shape (the data set is not in the container); MidV3 defaults: layers 14/43/129, 2 PatchMatch + 5 graph-cut iterations; "
+                               "seconds_optimiser counts from the top of run() (layers, job tables, host energy context, label initialisation included), seconds_reference_clock from where the "
+                               "reference starts its timer (after initCurrentFast, LES/FastGCStereo.h:141); both exclude the evaluator")
                 result["e2e"] = rec
             except Exception as ex:
                 result["e2e"] = {"error": repr(ex)}

@@ -106,6 +106,10 @@ class FastGCStereo:
             else:
                 runners[m].init_from_labels(labeling)          # warm start from a given labelling (LES/FastGCStereo.h:116-130)
             self._evaluate(0, m, runners[m], None, t0)
+        # the reference starts its clock HERE -- START_TIMER after initCurrentFast and the first evaluation (LES/FastGCStereo.h:135-141),
+        # with the layers (addLayer, LES/main.cpp:395-397) and the energy built before run() -- `seconds` below keeps counting from the top
+        # of this function; `seconds_reference_clock` is the same run on the reference's clock
+        self.init_seconds = time.perf_counter() - t0 - self.eval_seconds
         for it in range(pmInit):
             for m in viewModes:
                 runners[m].iteration(it)
@@ -191,7 +195,8 @@ class FastGCStereo:
                 self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
             # (the rows of the log belong to the ranks of the left view's group)
         lab = final[0].cpu().numpy().copy() if 0 in final else None
-        self.seconds = time.perf_counter() - t0 - self.eval_seconds          # the reference's clock: evaluation excluded
+        self.seconds = time.perf_counter() - t0 - self.eval_seconds          # evaluation excluded (as in the reference), set-up and initialisation included (unlike it)
+        self.seconds_reference_clock = self.seconds - self.init_seconds
         for r in runners.values():
             r.close()
         if g is not None:
