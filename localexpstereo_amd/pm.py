@@ -24,28 +24,29 @@ def layer_geometry(W, H, windR, unit):
     split_w, split_h = frac_w >= minsize, frac_h >= minsize
     wb, hb = W // unit + int(split_w), H // unit + int(split_h)
 
+    # (vectorised over the cells: the per-cell Python loop was 30 ms of a run's set-up at the Adirondack shape)
     def clip(x0, y0, x1, y1):
-        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, W), min(y1, H)
-        return (x0, y0, x1 - x0, y1 - y0) if x1 > x0 and y1 > y0 else (0, 0, 0, 0)
+        x0, y0, x1, y1 = np.maximum(x0, 0), np.maximum(y0, 0), np.minimum(x1, W), np.minimum(y1, H)
+        ok = (x1 > x0) & (y1 > y0)
+        z = np.zeros_like(x0)
+        return np.where(ok, x0, z), np.where(ok, y0, z), np.where(ok, x1 - x0, z), np.where(ok, y1 - y0, z)
 
-    units, shared, filt = [], [], []
-    for i in range(hb):
-        for j in range(wb):
-            ux1 = (j + 1) * unit + (frac_w if (not split_w and j == wb - 1) else 0)
-            uy1 = (i + 1) * unit + (frac_h if (not split_h and i == hb - 1) else 0)
-            units.append(clip(j * unit, i * unit, ux1, uy1))
-            ex = frac_w if (not split_w and j == wb - 2) else 0
-            ey = frac_h if (not split_h and i == hb - 2) else 0
-            s = clip((j - 1) * unit, (i - 1) * unit, (j + 2) * unit, (i + 2) * unit)
-            shared.append((s[0], s[1], s[2] + ex, s[3] + ey))
-            f = clip((j - 1) * unit - windR, (i - 1) * unit - windR, (j + 2) * unit + windR, (i + 2) * unit + windR)
-            filt.append(clip(f[0], f[1], f[0] + f[2] + ex, f[1] + f[3] + ey))
-    sets = [[] for _ in range(16)]
-    for i in range(hb):
-        for j in range(wb):
-            sets[(i % 4) * 4 + (j % 4)].append(i * wb + j)
+    i, j = np.meshgrid(np.arange(hb, dtype=np.int64), np.arange(wb, dtype=np.int64), indexing="ij")
+    i, j = i.reshape(-1), j.reshape(-1)
+    ux1 = (j + 1) * unit + np.where((not split_w) & (j == wb - 1), frac_w, 0)
+    uy1 = (i + 1) * unit + np.where((not split_h) & (i == hb - 1), frac_h, 0)
+    units = np.stack(clip(j * unit, i * unit, ux1, uy1), axis=1)
+    ex = np.where((not split_w) & (j == wb - 2), frac_w, 0)
+    ey = np.where((not split_h) & (i == hb - 2), frac_h, 0)
+    sx, sy, sw, sh = clip((j - 1) * unit, (i - 1) * unit, (j + 2) * unit, (i + 2) * unit)
+    shared = np.stack([sx, sy, sw + ex, sh + ey], axis=1)
+    fx, fy, fw, fh = clip((j - 1) * unit - windR, (i - 1) * unit - windR, (j + 2) * unit + windR, (i + 2) * unit + windR)
+    filt = np.stack(clip(fx, fy, fx + fw + ex, fy + fh + ey), axis=1)
+    phase = (i % 4) * 4 + (j % 4)
+    cell = i * wb + j
+    sets = [cell[phase == s] for s in range(16)]
     to = lambda a: np.array(a, np.int32).reshape(-1, 4).view(api.RECT_DT).reshape(-1)
-    return to(units), to(shared), to(filt), [np.array(s, np.int64) for s in sets if s]
+    return to(units), to(shared), to(filt), [np.asarray(s, np.int64) for s in sets if len(s)]
 
 
 def seeds_for(n, seed):
