@@ -28,6 +28,9 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # before any OpenMP runtime starts (as tools/e2e_bench.py does): the e2e sub-record's two cut teams
+                                                         # sleep between lock-steps instead of spinning against each other
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
