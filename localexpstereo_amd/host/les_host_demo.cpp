@@ -266,6 +266,55 @@ static int cmd_full(int argc, char** argv)
     return fail;
 }
 
+// The C++ driver on a scene written by tools/dump_scene.py (the synthetic Adirondack-shape pair of tools/e2e_bench.py, left volume as the device
+// ingest leaves it): the same data, parameters and layers as the Python driver's end-to-end run, one view.
+static int cmd_scene(int argc, char** argv)
+{
+    if (argc < 3) { printf("usage: les_host_demo scene <dir> [iters pm]\n"); return 2; }
+    const std::string dir = argv[2];
+    const int iters = argc > 3 ? atoi(argv[3]) : 5, pm = argc > 4 ? atoi(argv[4]) : 2;
+    int W = 0, H = 0, D = 0;
+    {
+        FILE* f = fopen((dir + "/meta.txt").c_str(), "r");
+        if (!f || fscanf(f, "%d %d %d", &W, &H, &D) != 3) { printf("FAIL: %s/meta.txt\n", dir.c_str()); return 1; }
+        fclose(f);
+    }
+    auto slurp = [&](const char* name, void* dst, size_t bytes) {
+        FILE* f = fopen((dir + "/" + name).c_str(), "rb");
+        const bool ok = f && fread(dst, 1, bytes, f) == bytes;
+        if (f) fclose(f);
+        if (!ok) printf("FAIL: %s/%s\n", dir.c_str(), name);
+        return ok;
+    };
+    std::vector<uint8_t> imL((size_t)W * H * 3), imR((size_t)W * H * 3);
+    std::vector<float> vol((size_t)W * H * D), gt((size_t)W * H);
+    if (!slurp("imL.bgr", imL.data(), imL.size()) || !slurp("imR.bgr", imR.data(), imR.size()) || !slurp("volL.f32", vol.data(), vol.size() * 4) ||
+        !slurp("gt.f32", gt.data(), gt.size() * 4)) return 1;
+    Parameters param(0.5f, 20, "GF", 1e-4f);                          // MidV3: smooth_weight 0.5, filterRadious 20 (LES/main.cpp:330-420)
+    param.th_col = 0.5f;                                               // mc_threshold
+    const float maxdisp = (float)D - 1;
+    const auto t1 = std::chrono::steady_clock::now();
+    auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
+    st->setSeed(1);
+    st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(imL.data(), imR.data(), W, H, vol.data(), vol.data(), D, param, maxdisp));
+    const double t_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    st->addLayer(std::max(2, int(W * 0.01)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});   // LES/main.cpp:391-397
+    st->addLayer(std::max(4, int(W * 0.03)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    st->addLayer(std::max(8, int(W * 0.09)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    double sec = 0;
+    if (!st->runDevice(pm, {0}, &sec, iters)) { printf("FAIL: runDevice\n"); return 1; }
+    const std::vector<float> disp = st->computeDisparities(0);
+    size_t badn = 0;
+    for (size_t i = 0; i < disp.size(); i++) badn += std::fabs(disp[i] - gt[i]) > 1.0f;
+    const double bad = 100.0 * (double)badn / (double)disp.size(), e = st->totalEnergy(0);
+    printf("scene %dx%dx%d  pm %d + gc %d: optimiser %.3f s  (context + upload %.3f s)  E=%.1f  bad1.0=%.2f%%\n", W, H, D, pm, iters, sec, t_ctx, e, bad);
+    printf("scene graph-cut lock-steps: %ld   GPU propose+unary+graphs+device cuts %.3f s   host cuts %.3f s   H2D labels %.3f s   cells cut on the GPU %ld\n",
+           st->gcLockSteps, st->gcSeconds[0], st->gcSeconds[1], st->gcSeconds[2], st->gcCellsCutOnDevice);
+    const int fail = bad > 25.0 ? 1 : 0;
+    printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
+    return fail;
+}
+
 // Two ranks of the sharded device driver on ONE GPU (two host threads, two contexts), the per-set tile exchange going through
 // les_hip_exchange_pack / _unpack and a loop-back transport in host memory instead of RCCL: the result of every rank must equal the
 // single-rank run bit for bit.  (On a multi-GPU node the same driver runs with one process per GPU and PMStereo::ncclComm.)
@@ -352,6 +401,7 @@ int main(int argc, char** argv)
             return 3;
         }
     }
+    if (argc >= 2 && !strcmp(argv[1], "scene")) return cmd_scene(argc, argv);
     if (argc >= 2 && !strcmp(argv[1], "full")) {
         try {
             return cmd_full(argc, argv);
