@@ -145,6 +145,67 @@ KERNEL_CVT(k_cvt_f32_f64, A_CVT_F32_F64, float, double)
 KERNEL_CVT(k_mad_u64_u32, A_MAD_U64_U32, unsigned long long, unsigned)
 KERNEL_CVT(k_mad_i64_i32, A_MAD_I64_I32, long long, int)
 
+
+// ---- round 4: candidates for the instruction diet of the march kernel
+#define A_MUL_I24_SDWA(r) "v_mul_i32_i24_sdwa " #r ", sext(" #r "), %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+#define A_ADD_U32_SDWA(r) "v_add_u32_sdwa " #r ", sext(" #r "), %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+#define A_MAD_I24(r) "v_mad_i32_i24 " #r ", " #r ", %8, %9\n"
+#define A_MUL_I24(r) "v_mul_i32_i24 " #r ", " #r ", %8\n"
+#define A_ADD3_U32(r) "v_add3_u32 " #r ", " #r ", %8, %9\n"
+#define A_PERM_B32(r) "v_perm_b32 " #r ", " #r ", %8, %9\n"
+#define A_CVT_F32_UBYTE1(r) "v_cvt_f32_ubyte1 " #r ", " #r "\n"
+#define A_RNDNE_F32(r) "v_rndne_f32 " #r ", " #r "\n"
+#define A_FLOOR_F32(r) "v_floor_f32 " #r ", " #r "\n"
+#define A_FRACT_F32(r) "v_fract_f32 " #r ", " #r "\n"
+#define A_MUL_HI_I32(r) "v_mul_hi_i32 " #r ", " #r ", %8\n"
+#define A_MUL_HI_U24(r) "v_mul_hi_u32_u24 " #r ", " #r ", %8\n"
+#define A_BFE_U32(r) "v_bfe_u32 " #r ", " #r ", 8, 8\n"
+#define A_LSHRREV(r) "v_lshrrev_b32 " #r ", 8, " #r "\n"
+#define A_MAX_F32(r) "v_max_f32 " #r ", " #r ", %8\n"
+#define A_MED3_F32(r) "v_med3_f32 " #r ", " #r ", %8, %9\n"
+#define A_MIN_I32(r) "v_min_i32 " #r ", " #r ", %8\n"
+#define A_AND_OR(r) "v_and_or_b32 " #r ", " #r ", %8, %9\n"
+#define A_XAD(r) "v_xad_u32 " #r ", " #r ", %8, %9\n"
+#define A_LSHL_OR(r) "v_lshl_or_b32 " #r ", " #r ", 3, %8\n"
+#define A_ADD_CO(r) "v_add_co_u32 " #r ", vcc, " #r ", %8\n"
+#define A_ADDC_CO(r) "v_addc_co_u32 " #r ", vcc, " #r ", %8, vcc\n"
+#define A_DOT4_I8(r) "v_dot4_i32_i8 " #r ", " #r ", %8, %9\n"
+#define A_DOT2_I16(r) "v_dot2_i32_i16 " #r ", " #r ", %8, %9\n"
+#define A_PK_ADD_U16(r) "v_pk_add_u16 " #r ", " #r ", %8\n"
+#define A_PK_MAD_I16(r) "v_pk_mad_i16 " #r ", " #r ", %8, %9\n"
+#define A_CVT_F32_I32_SDWA(r) "v_cvt_f32_i32_sdwa " #r ", sext(" #r ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+#define A_CVT_FLR(r) "v_cvt_flr_i32_f32 " #r ", " #r "\n"
+#define A_LDEXP(r) "v_ldexp_f32 " #r ", " #r ", 3\n"
+KERNEL32(k_mul_i24_sdwa, A_MUL_I24_SDWA)
+KERNEL32(k_add_u32_sdwa, A_ADD_U32_SDWA)
+KERNEL32(k_mad_i24, A_MAD_I24)
+KERNEL32(k_mul_i24, A_MUL_I24)
+KERNEL32(k_add3_u32, A_ADD3_U32)
+KERNEL32(k_perm_b32, A_PERM_B32)
+KERNEL32(k_cvt_f32_ubyte1, A_CVT_F32_UBYTE1)
+KERNEL32(k_rndne_f32, A_RNDNE_F32)
+KERNEL32(k_floor_f32, A_FLOOR_F32)
+KERNEL32(k_fract_f32, A_FRACT_F32)
+KERNEL32(k_mul_hi_i32, A_MUL_HI_I32)
+KERNEL32(k_mul_hi_u24, A_MUL_HI_U24)
+KERNEL32(k_bfe_u32, A_BFE_U32)
+KERNEL32(k_lshrrev, A_LSHRREV)
+KERNEL32(k_max_f32, A_MAX_F32)
+KERNEL32(k_med3_f32, A_MED3_F32)
+KERNEL32(k_min_i32, A_MIN_I32)
+KERNEL32(k_and_or, A_AND_OR)
+KERNEL32(k_xad, A_XAD)
+KERNEL32(k_lshl_or, A_LSHL_OR)
+KERNEL32(k_add_co, A_ADD_CO)
+KERNEL32(k_addc_co, A_ADDC_CO)
+KERNEL32(k_dot4_i8, A_DOT4_I8)
+KERNEL32(k_dot2_i16, A_DOT2_I16)
+KERNEL32(k_pk_add_u16, A_PK_ADD_U16)
+KERNEL32(k_pk_mad_i16, A_PK_MAD_I16)
+KERNEL32(k_cvt_f32_i32_sdwa, A_CVT_F32_I32_SDWA)
+KERNEL32(k_cvt_flr, A_CVT_FLR)
+KERNEL32(k_ldexp, A_LDEXP)
+
 // ---- LDS: 32 reads (or writes) per iteration, conflict-free lane-linear addresses
 #define KERNEL_LDS(NAME, BODY, BYTES)                                                               \
     __global__ void __launch_bounds__(256) NAME(unsigned long long* out, float seed)                \
@@ -224,6 +285,12 @@ int main(int argc, char** argv)
         {"v_lshl_add_u64", k_lshl_add_u64, 64}, {"v_mov_b64", k_mov_b64, 64},
         {"v_cvt_f64_f32", k_cvt_f64_f32, 64}, {"v_cvt_f64_i32", k_cvt_f64_i32, 64}, {"v_cvt_f32_f64", k_cvt_f32_f64, 64},
         {"v_mad_u64_u32", k_mad_u64_u32, 64}, {"v_mad_i64_i32", k_mad_i64_i32, 64},
+        {"v_mul_i32_i24_sdwa (sext byte)", k_mul_i24_sdwa, 64}, {"v_add_u32_sdwa (sext byte)", k_add_u32_sdwa, 64}, {"v_mad_i32_i24", k_mad_i24, 64}, {"v_mul_i32_i24", k_mul_i24, 64},
+        {"v_add3_u32", k_add3_u32, 64}, {"v_perm_b32", k_perm_b32, 64}, {"v_cvt_f32_ubyte1", k_cvt_f32_ubyte1, 64}, {"v_rndne_f32", k_rndne_f32, 64}, {"v_floor_f32", k_floor_f32, 64},
+        {"v_fract_f32", k_fract_f32, 64}, {"v_mul_hi_i32", k_mul_hi_i32, 64}, {"v_mul_hi_u32_u24", k_mul_hi_u24, 64}, {"v_bfe_u32", k_bfe_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
+        {"v_max_f32", k_max_f32, 64}, {"v_med3_f32", k_med3_f32, 64}, {"v_min_i32", k_min_i32, 64}, {"v_and_or_b32", k_and_or, 64}, {"v_xad_u32", k_xad, 64}, {"v_lshl_or_b32", k_lshl_or, 64},
+        {"v_add_co_u32", k_add_co, 64}, {"v_addc_co_u32", k_addc_co, 64}, {"v_dot4_i32_i8", k_dot4_i8, 64}, {"v_dot2_i32_i16", k_dot2_i16, 64}, {"v_pk_add_u16", k_pk_add_u16, 64},
+        {"v_pk_mad_i16", k_pk_mad_i16, 64}, {"v_cvt_f32_i32_sdwa (sext byte)", k_cvt_f32_i32_sdwa, 64}, {"v_cvt_flr_i32_f32", k_cvt_flr, 64}, {"v_ldexp_f32", k_ldexp, 64},
         {"ds_read_b32", k_lds_r32, 32}, {"ds_read_b64", k_lds_r64, 32}, {"ds_read_b128", k_lds_r128, 32},
         {"ds_write_b32", k_lds_w32, 32}, {"ds_write_b64", k_lds_w64, 32}, {"ds_write_b128", k_lds_w128, 32},
         {"mix 16 ds_read_b64 + 16 v_add_f64", k_mix_f64_lds, 32},
