@@ -114,7 +114,6 @@ const MarchEntry kMarch[] = {
     LES_MARCH_ENTRY(7, 256, 1, 5),
     LES_MARCH_ENTRY(7, 128, 2, 5),
 };
-static_assert((2 * 10 + 1) * (2 * 10 + 1) * (1ll << les::kMarchPB) < (1ll << 31), "stage-1 box sums must fit int32");
 // wide != 0: the entry with the widest jobs, else the one with the narrowest
 const MarchEntry* find_march(int R, int wide = 1)
 {
@@ -137,7 +136,7 @@ struct ViewData {
     float4* feat = nullptr;              // NaiveStereoEnergy feature image (image-based matching cost)
     // march kernel (les_march.h): guide as signed bytes, statistics in its format, cost range of the volume
     uint32_t* ipk8 = nullptr;
-    float4* mstats = nullptr;
+    float* mstats = nullptr;
     bool march_ok = false;               // volume finite, range condition met, tables built
     les::MarchView mv = {};
 };
@@ -473,7 +472,7 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
         unsigned* d_dmax = static_cast<unsigned*>(dm.p);
         HIPCHECK(hipMemsetAsync(d_dmax, 0, sizeof(unsigned), cur_stream(c)));
         HIPCHECK(hipMalloc((void**)&v.ipk8, P * sizeof(uint32_t)));
-        HIPCHECK(hipMalloc((void**)&v.mstats, P * 3 * sizeof(float4)));
+        HIPCHECK(hipMalloc((void**)&v.mstats, P * les::kMarchStatWords * sizeof(float)));
         hipLaunchKernelGGL(les::les_march_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, cur_stream(c), d_hs, v.ipk, v.ipk8, v.mstats, d_dmax, H, W, c->R, c->p.eps);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, cur_stream(c)));
@@ -485,14 +484,20 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     const int K = 2 * c->R + 1;
     const double Ba = 0.5 * range * std::sqrt((double)dmax), Bb = range + 1.5 * Ba;
     const double scale = 1073741824.0 / ((double)K * Bb * 1.25);    // horizontal box sums of the quantised a, b stay below 2^30
-    const double up = range / (double)((1 << les::kMarchPB) - 1);
+    // centred fixed-point cost (les_march.h): count = rint(p sp) + c0, c0 an integer, so that [vmin, th] maps onto [-2^(PB-1), 2^(PB-1) - 1]
+    const int PB = les::march_pb(c->R);
+    const float spf = (float)((double)((1 << PB) - 1) / range);
+    const double c0 = std::rint(-(double)vmin * (double)spf) - (double)(1 << (PB - 1));
+    const double up = 1.0 / (double)spf;
     les::MarchView mv;
     mv.vol = v.vol; mv.ipk8 = v.ipk8; mv.mstats = v.mstats;
-    mv.vmin = vmin;
-    mv.sp = (float)((double)((1 << les::kMarchPB) - 1) / range);
+    mv.sp = spf;
+    mv.pmagic = (float)(12582912.0 + c0);                           // 1.5 * 2^23 + c0: an integer below 2^24, exact
+    mv.poff = (float)(-c0 * up);
     mv.kapS = (float)((double)(1 << les::kMarchSH) * up / 255.0 * scale);
     mv.upS = (float)(up * scale);
-    mv.qscale = 1.0 / (255.0 * scale);
+    mv.qscale = (float)((double)(1 << les::kMarchS2) / (255.0 * scale));
+    mv.kmu = (float)(1.0 / ((double)(1ll << les::kMarchMB) * 255.0));
     mv.raw_off = nullptr;
     v.mv = mv;
     v.march_ok = true;

@@ -5,30 +5,34 @@
 //     q     = guided filter of p with the colour guide, radius R, eps           LES/GuidedFilter.h:142-266, 301-326
 //     q    -> 1e6 where the label is invalid                                    LES/CostVolumeEnergy.h:176-183
 //
-// but is organised around what the MI355X micro-benchmarks say is cheap (tools/ubench/valu_rates.hip, mix_issue.hip): 32-bit
-// integer / fp32 adds issue in 2 cycles per wave, every fp64 operation, conversion, DPP move or 64-bit integer MAD in 4 on a pipe
-// the waves of a SIMD share, an LDS ds_write_b128 costs ~13 CU cycles and a ds_read_b128 4, a wave issues at most one
-// instruction per ~4 cycles, a taken branch costs ~26, and the arbiter prefers the oldest wave.  All four box-filter passes are
-// therefore EXACT INTEGER sums, computed by three wave-specialised roles (A, C, D below; the prefix passes B1 / B2 run on the
-// waves of role A) that work on consecutive row blocks at the same time:
+// but is organised around what the MI355X micro-benchmarks say is cheap (tools/ubench/valu_rates.hip, profiles/round4_valu_rates_w3.log):
+// only fp32 add / mul / fma, 32-bit integer add / sub, logic, shifts and moves issue at ~2.9 cycles per wave-instruction with the
+// three waves a SIMD holds here; EVERY other VALU instruction -- fp64, conversions, min / max, selects, 24- and 32-bit integer
+// multiplies, three-operand integer adds, DPP, bit-field extracts -- takes ~4.2, an SDWA byte operand is free on top of that, an
+// LDS ds_write_b128 costs ~13.7 CU cycles and a ds_read_b128 4.1, a wave issues at most one instruction per ~4 cycles, a taken
+// branch costs ~26, and the arbiter prefers the oldest wave.  So the kernel minimises instruction COUNT: all four box-filter passes
+// are EXACT 32-BIT INTEGER sums (round 4: no 64-bit or fp64 accumulation anywhere in the loops), computed by three wave-specialised
+// roles (A, C, D below; the prefix passes B1 / B2 run on the waves of role A) that work on consecutive row blocks at the same time:
 //
 //   A  (lane = image column of a job, marching down the rows; NJ jobs per workgroup)
-//        p -> 22-bit fixed point  pi = round((p - vmin) * sp)      (p lives in [vmin, th_col]; vmin = min of the volume)
-//        vertical 2R+1 running sums over a register ring of (pi, packed guide):  Sp = sum pi   (int32, exact)
-//                                                                                Sc = sum Iq_c * pi (int64, exact; Iq = u8 - 128)
-//        -> LDS T1[row][col] = {Sp, (Sc + 2^8) >> 9}                 (the only rounding of stage 1: 2^-31 of full scale)
-//   B1 (lane = (row, 8-column segment)) in-place prefix sums along x, modulo 2^32 (the 21-column differences are exact)
-//   C  (lane = column)  box sums s, t_c = P(x+R) - P(x-R-1);  N cov_c = t_c - hi32(M_c * s)  (M_c = mean_c in 2^-23 u8 units:
+//        p -> centred fixed point  pi = rint(p * sp) + c0  in [-2^(PB-1), 2^(PB-1)]   (PB = 20: one v_fma_f32 onto 1.5 * 2^23 + c0, the
+//        integer is the low mantissa of the result; p lives in [vmin, th_col], vmin = min of the volume)
+//        vertical 2R+1 running sums over a register ring of (-pi, packed guide):  Sp = sum pi            (|Sp| < 2^24)
+//                                                                                Sc = sum Iq_c * pi     (Iq = u8 - 128; |Sc| < 2^30.4:
+//        v_mul_i32_i24 with the guide byte as an SDWA operand, v_add3_u32; int32, exact)
+//        -> LDS T1[row][col] = {Sp, (Sc + 2^4) >> 5}                 (the only rounding of stage 1: 2^-26 of full scale)
+//   B1 (lane = (row, 8-column segment)) in-place prefix sums along x, modulo 2^32 (the 2R+1-column differences are exact)
+//   C  (lane = column)  box sums s, t_c = P(x+R) - P(x-R-1);  N cov_c = t_c - hi32(M_c * 8 s)  (M_c = mean_c in 2^-24 u8 units:
 //        one v_mad_i64_i32, the cancellation is exact);  a = inv * cov,  b = mean_p - a . mean   in fp32 (as les_strip_kernel);
 //        a, b -> int32 with a scale derived from a rigorous bound on |a|, |b|  -> LDS T2
 //   B2 prefix sums of T2
-//   D  (lane = column)  horizontal box = prefix difference (int32), vertical running sums over an int32 register ring,
-//        accumulated in fp64 (integers < 2^53: exact),  q = (Sb * 255 + sum_c Sa_c * Iq_c) * rn / (255 scale) + vmin.
+//   D  (lane = column)  horizontal box = prefix difference (int32, < 2^30), vertical running sums over an int32 register ring in
+//        64-bit integers (one v_mad_i64_i32 each), rounded once to 2^4:  q = (Sb * 255 + sum_c Sa_c * Iq_c) * 2^4 / (255 scale N) + p(0)  in fp32.
 //
-// Error budget against the double-precision reference (tools/fixedpoint_probe.py, DESIGN.md "Numerics"): the fixed-point
-// cost (6e-8 of the range), the 2^-31 rounding of the stage-1 vertical sums, M_c (2^-31), the fp32 3x3 algebra (shared with
-// les_strip_kernel) and the stage-2 quantisation (resolution ~1e-6 of |a|max before a 441-pixel average): measured 6e-8 ..
-// 4e-7 absolute on costs in [0, 0.5] for eps = 1e-4.
+// Error budget against the double-precision reference (tools/fixedpoint_probe.py, DESIGN.md "Numerics"): the fixed-point cost
+// (2.4e-7 of the range per pixel, unbiased, before a 441-pixel average), the 2^-26 rounding of the stage-1 vertical sums, M_c
+// (2^-25 u8), the fp32 3x3 algebra (shared with les_strip_kernel), the stage-2 quantisation (resolution ~1e-6 of |a|max before a
+// 441-pixel average), the 2^4 rounding of the stage-2 window sums (2^-30 of their full scale) and the fp32 combination.
 //
 // The kernel is only launched when the host has established its preconditions (les_hip.hip: march_usable): a finite volume,
 // th_col - vmin <= 8 |th_col|, and every target at least 2R away from clip borders that are not image borders (so that every
@@ -37,22 +41,55 @@
 
 #include "les_kernels.h"
 
+// Measurement switches (role masks, role order, ablations, cache policies, per-role clocks) live in les_march_lab.h and exist only
+// in -DLES_MARCH_LAB builds; here every hook is a no-op.
+#if defined(LES_MARCH_LAB)
+#include "les_march_lab.h"
+#else
+#define LES_MARCH_ROLE_ORDER 5
+#define LES_STATS_POLICY ""
+#define LES_LAB_ROLE_ON(bit) true
+#define LES_LAB_ABLATE(bit) false
+#endif
+#ifndef LES_TICK_BEGIN
+#define LES_TICK_BEGIN() ((void)0)
+#define LES_TICK_MARK() ((void)0)
+#define LES_TICK_BARRIER() __syncthreads()
+#define LES_TICK_END(role_) ((void)0)
+#endif
+
 namespace les {
 
-constexpr int kMarchPB = 22;      // bits of the fixed-point cost
-constexpr int kMarchSH = 9;       // right shift of the vertical sums of Iq * pi before the horizontal pass (M_c has 23 fraction bits: SH + 23 = 32)
+constexpr int kMarchSH = 5;       // right shift of the vertical sums of Iq * pi before the horizontal pass
+constexpr int kMarchMB = 24;      // fraction bits of M_c (centred guide mean in u8 units): |M_c| <= 2^31
+constexpr int kMarchSL = 3;       // left shift of the window sum s before the product with M_c:  SH + MB + SL = 32
+constexpr int kMarchS2 = 4;       // right shift of the stage-2 horizontal box sums before the vertical pass
+constexpr int kMarchMagicBits = 0x4B400000;     // float bits of 1.5 * 2^23: fma(p, sp, 1.5 * 2^23 + c0) has the integer rint(p sp) + c0 in its low mantissa
+static_assert(kMarchSH + kMarchMB + kMarchSL == 32, "N cov = t - hi32(M * (s << SL)) needs the scales to meet at 2^32");
+// Bits of the centred fixed-point cost for radius R: the stage-1 window sum s << SL and the vertical sums of Iq * pi must fit int32
+// ((2R+1)^2 2^(PB-1) 2^SL < 2^31 and (2R+1) 2^7 2^(PB-1) < 2^31).
+__host__ __device__ constexpr int march_pb(int R) { return (2 * R + 1) * (2 * R + 1) < 512 ? 20 : 19; }
+// words per pixel of the guide statistics: 9 = {inv00 inv01 inv02 inv11} {inv12 inv22 M0 M1} {M2} (36 bytes: two 16-byte loads and one
+// 4-byte load per pixel and hypothesis; the float means are derived from M_c), 12 = the round-3 record with mu_c stored as well
+#ifndef LES_MARCH_STAT_WORDS
+#define LES_MARCH_STAT_WORDS 9
+#endif
+constexpr int kMarchStatWords = LES_MARCH_STAT_WORDS;
+static_assert(kMarchStatWords == 9 || kMarchStatWords == 12, "statistics record of 36 or 48 bytes");
 
 struct MarchView {
     const float* vol;             // [D][H][W]
     const uint32_t* ipk8;         // [H*W] guide pixel as three signed bytes u8 - 128 (byte 3 = 0)
-    const float4* mstats;         // [H*W][3]: {inv00, inv01, inv02, inv11} {inv12, inv22, mu0, mu1} {mu2, M0, M1, M2}
+    const float* mstats;          // [H*W][kMarchStatWords]: {inv00, inv01, inv02, inv11} {inv12, inv22, M0, M1} {M2 [, mu0, mu1, mu2]}
                                   //   inv = (Sigma + eps U)^-1 of the guide in [0,1] units (LES/GuidedFilter.h:87-101),
-                                  //   mu_c = mean_I_c - 128/255 (fp32), M_c = rint((255 mean_I_c - 128) 2^23) (int32 bits)
-    float vmin;                   // lower end of the cost range (min of the volume, <= th_col)
-    float sp;                     // (2^PB - 1) / (th_col - vmin)
-    float kapS;                   // 2^SH * u_p / 255 * scale        (u_p = (th_col - vmin) / (2^PB - 1))
+                                  //   M_c = rint((255 mean_I_c - 128) 2^MB) (int32 bits), mu_c = mean_I_c - 128/255 = M_c 2^-MB / 255
+    float sp;                     // counts per cost unit: (2^PB - 1) / (th_col - vmin)
+    float pmagic;                 // 1.5 * 2^23 + c0,  c0 = rint(-vmin sp) - 2^(PB-1)  (an integer: exact in fp32)
+    float poff;                   // the cost that count 0 stands for: -c0 / sp
+    float kapS;                   // 2^SH * u_p / 255 * scale        (u_p = 1 / sp, scale = stage-2 counts per unit of a, b)
     float upS;                    // u_p * scale
-    double qscale;                // 1 / (255 * scale)
+    float qscale;                 // 2^S2 / (255 * scale)
+    float kmu;                    // 2^-MB / 255
     // image-based energy (les_hip_create_naive): vol is the raw-cost scratch les_naive_raw_kernel has just filled, raw_off[i] the
     // float offset of call i's filterRect patch in it (row stride = filterRect width), vmin = 0, th_col -> th_color + th_grad.
     // Null for a cost-volume context.
@@ -62,27 +99,28 @@ struct MarchView {
 template <int R, int WGC, int NJ, int BY>
 struct MarchCfg {
     static constexpr int KS = 2 * R + 1;
+    static constexpr int RS = 3 * BY;                      // ring length: three blocks (the tick loop is unrolled by 3, so ring slots and stage-2 buffers are compile-time); >= KS
     static constexpr int TW = WGC - 4 * R;                 // output columns per job
     static constexpr int HWV = WGC / 64;                   // waves per role and job slot
     static constexpr int NW = 3 * HWV * NJ;                // waves per workgroup: roles A, C, D
     static constexpr int NT = 64 * NW;
     static constexpr int SEGL = 8;                         // columns per prefix segment
-#ifndef LES_MARCH_PADW
-#define LES_MARCH_PADW 16
-#endif
     // Physical columns: a leading zero element (P(-1)) + one pad element per PADW columns; with PADW = 16 the row length is rounded
     // up to 4 mod 8 elements.  The prefix pass reads, per 16 lanes, the 8 segments (stride 8 columns = 32 banks, shifted by one
     // element = 4 banks per pad) of two rows (shifted by +-16 banks when the row length is 4 mod 8): all 64 banks once.  The
     // consumers' 16 consecutive columns then straddle one pad (one bank collision per 16 lanes) instead of two.
-    static constexpr int PADW = LES_MARCH_PADW;
+    static constexpr int PADW = 16;
     static constexpr int PCOLS0 = 1 + WGC + WGC / PADW;
-    static constexpr int PCOLS = PADW == 16 ? PCOLS0 + ((4 - PCOLS0 % 8) + 8) % 8 : PCOLS0;      // 4 or 12 mod 16: the second row lands 16 banks off either way
-    static_assert(KS % BY == 0, "the block height must divide the ring length (compile-time ring slots)");
-    static_assert(KS / BY == 3, "three blocks per ring: the ring slots and the stage-2 buffer of a block are compile-time constants in a loop unrolled by 3");
+    static constexpr int PCOLS = PCOLS0 + ((4 - PCOLS0 % 8) + 8) % 8;      // 4 or 12 mod 16: the second row lands 16 banks off either way
+    static_assert(RS >= KS, "the ring must hold a whole window (the row that leaves it is the one written KS rows ago)");
+    static_assert(RS - KS < BY, "a ring longer than the window by a block or more wastes registers: pick the smallest block height");
     static_assert(WGC % 64 == 0, "a job slot is a whole number of waves");
     static_assert(BY * (64 / SEGL) <= 64, "one wave prefixes its own tile");
     static_assert(TW > 0, "job too narrow for this radius");
     static_assert(2 * R + 1 < 64, "a window crosses at most one wave boundary");
+    static_assert((long long)KS * KS * (1ll << (march_pb(R) - 1 + kMarchSL)) < (1ll << 31), "stage-1 window sums (shifted for the product with M) must fit int32");
+    static_assert((long long)KS * 128 * (1ll << (march_pb(R) - 1)) < (1ll << 31), "vertical sums of Iq * pi must fit int32");
+    static_assert((long long)KS * (1ll << (30 - kMarchS2)) < (1ll << 31), "the stage-2 window sums, rounded to 2^S2, must fit int32");
     __host__ __device__ static constexpr int pcol(int ci) { return 1 + ci + ci / PADW; }
 };
 
@@ -123,7 +161,7 @@ __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int
     const int row = 2 * (lane >> 4) + (lane & 1), seg = (lane & 15) >> 1;
     const bool act = row < BY;
     const int c0 = ci0 + seg * SEGL;                                           // first column of the segment; a segment never contains a pad
-    int4* p = &T[act ? row : 0][1 + c0 + c0 / LES_MARCH_PADW];                // (the lanes of the unused 8th row read row 0 and write nothing)
+    int4* p = &T[act ? row : 0][1 + c0 + c0 / 16];                // (the lanes of the unused 8th row read row 0 and write nothing)
     int4 v[SEGL];
 #pragma unroll
     for (int j = 0; j < SEGL; j++) v[j] = p[j];
@@ -144,7 +182,7 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
     const int row = 2 * (lane >> 4) + (lane & 1), seg = (lane & 15) >> 1;
     const bool act = row < BY;
     const int c0 = ci0 + seg * SEGL;
-    const int pc = 1 + c0 + c0 / LES_MARCH_PADW;
+    const int pc = 1 + c0 + c0 / 16;
     int4* pa = &TA[act ? row : 0][pc];
     int4* pb = &TB[act ? row : 0][pc];
     int4 va[SEGL], vb[SEGL];
@@ -167,21 +205,6 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
     }
 }
 
-// -DLES_PHASE_TIMING: lane 0 of every wave accumulates the cycles it computes per tick and the cycles it waits at the tick
-// barrier: les_dbg[2 role] += compute, les_dbg[2 role + 1] += wait, les_dbg[6 + role] += ticks, les_dbg[9 + role] += the part of
-// `compute` before LES_TICK_MARK (the row loop; the rest is the prefix pass of the tile)            (tools/phase_probe.py)
-#if defined(LES_PHASE_TIMING) && !defined(LES_SIM)
-#define LES_TICK_BEGIN() unsigned long long tk_c_ = 0, tk_w_ = 0, tk_n_ = 0, tk_r_ = 0, tk_m_ = 0, tk_t_ = clock64()
-#define LES_TICK_MARK() (tk_m_ = clock64())
-#define LES_TICK_BARRIER() do { const unsigned long long a_ = clock64(); __syncthreads(); const unsigned long long b_ = clock64(); tk_c_ += a_ - tk_t_; tk_r_ += (tk_m_ > tk_t_ ? tk_m_ : a_) - tk_t_; tk_w_ += b_ - a_; tk_t_ = b_; tk_n_++; } while (0)
-#define LES_TICK_END(role_) do { if (lane == 0) { atomicAdd(&les_dbg[2 * (role_)], tk_c_); atomicAdd(&les_dbg[2 * (role_) + 1], tk_w_); atomicAdd(&les_dbg[6 + (role_)], tk_n_); atomicAdd(&les_dbg[9 + (role_)], tk_r_); } } while (0)
-#else
-#define LES_TICK_BEGIN() ((void)0)
-#define LES_TICK_MARK() ((void)0)
-#define LES_TICK_BARRIER() __syncthreads()
-#define LES_TICK_END(role_) ((void)0)
-#endif
-
 // wave-uniform base + unsigned 32-bit per-lane byte offset: compiles to the `saddr` form of global_load / global_store, i.e. no
 // 64-bit address arithmetic on the VALU.  (The empty asm pins the offset as a 32-bit value in the block of the access; otherwise its
 // zero-extension is hoisted out of the loops and instruction selection falls back to a 64-bit VGPR address + v_lshl_add_u64.)
@@ -190,63 +213,103 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
 #else
 #define LES_PIN_U32(x) asm volatile("" : "+v"(x))
 #endif
+// (`byte_off` is pinned IN PLACE: the caller passes a mutable per-role copy, so no v_mov precedes the access)
 template <class T>
-__device__ __forceinline__ T ld_sbase(const T* base, uint32_t byte_off)
+__device__ __forceinline__ T ld_sbase(const T* base, uint32_t& byte_off)
 {
     LES_PIN_U32(byte_off);
-#if defined(LES_VOL_NT) && !defined(LES_SIM)
-    return __builtin_nontemporal_load((const T*)((const char*)base + byte_off));      // measurement switch: streaming loads of volume / guide rows
+#if defined(LES_MARCH_LAB) && defined(LES_VOL_NT) && !defined(LES_SIM)
+    return __builtin_nontemporal_load((const T*)((const char*)base + byte_off));
 #else
     return *(const T*)((const char*)base + byte_off);
 #endif
 }
 template <class T>
-__device__ __forceinline__ void st_sbase(T* base, uint32_t byte_off, T v) { LES_PIN_U32(byte_off); *(T*)((char*)base + byte_off) = v; }
+__device__ __forceinline__ void st_sbase(T* base, uint32_t& byte_off, T v) { LES_PIN_U32(byte_off); *(T*)((char*)base + byte_off) = v; }
 
-// The statistics rows of role C are loop-carried 16-byte register tuples that are reloaded in place, one row at a time, while
-// the rest of the block is still being consumed.  Written as plain C++ loads, the register allocator lands every reload in a
-// fresh tuple and copies it to the loop-carried one right away, i.e. waits for the load it has just issued.  The loads are
-// therefore issued as inline assembly with the destination TIED to the variable, and the vmcnt bookkeeping for them is done
-// by hand (this role issues no other vector-memory instruction): march_stats_wait3/6<n>(rows...) waits until at most n of this
-// wave's loads are outstanding and, by naming the rows as read-write operands, keeps their uses behind the wait.
+// The statistics rows of role C are loop-carried register tuples that are reloaded in place, one row at a time, while the rest of
+// the block is still being consumed.  Written as plain C++ loads, the register allocator lands every reload in a fresh tuple and
+// copies it to the loop-carried one right away, i.e. waits for the load it has just issued.  The loads are therefore issued as
+// inline assembly with the destination TIED to the variable, and the vmcnt bookkeeping for them is done by hand (this role issues
+// no other vector-memory instruction): march_stats_wait<n>(rows...) waits until at most n of this wave's loads are outstanding and,
+// by naming the rows as read-write operands, keeps their uses behind the wait.  A row is three loads: 16 + 16 + 4 bytes (16 + 16 +
+// 16 with the 48-byte record).
 #if defined(LES_SIM)
 typedef float4 mstat4;
-#define LES_STATS_LOAD(dst, base, off, IMM) ((dst) = *(const float4*)((const char*)(base) + (off) + (IMM)))
-template <int N>
-__device__ inline void march_stats_wait3(float4 (&r)[3]) { (void)r; }
-template <int N>
-__device__ inline void march_stats_wait6(float4 (&r)[3], float4 (&q)[3]) { (void)r; (void)q; }
 #else
 typedef float mstat4 __attribute__((ext_vector_type(4)));
-#ifndef LES_STATS_POLICY
-#define LES_STATS_POLICY ""        // cache-policy bits of the statistics loads (measurement switch: " nt", " sc0", " sc1", " sc0 sc1")
 #endif
-#define LES_STATS_LOAD(dst, base, off, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM LES_STATS_POLICY : "+v"(dst) : "v"(off), "s"(base))
-template <int N>
-__device__ __forceinline__ void march_stats_wait3(mstat4 (&r)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : "n"(N)); }
-template <int N>
-__device__ __forceinline__ void march_stats_wait6(mstat4 (&r)[3], mstat4 (&q)[3])
+#if LES_MARCH_STAT_WORDS == 9
+typedef float mstat_tail;                       // {M2}
+#else
+typedef mstat4 mstat_tail;                      // {M2, mu0, mu1, mu2}
+#endif
+struct MarchStatRow { mstat4 a, b; mstat_tail c; };
+#if defined(LES_SIM)
+__device__ inline void march_stats_load(MarchStatRow& r, const float* base, uint32_t off)
 {
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : "n"(N));
+    const char* q = (const char*)base + off;                        // 36-byte records: not 16-byte aligned
+    memcpy(&r.a, q, 16); memcpy(&r.b, q + 16, 16); memcpy(&r.c, q + 32, sizeof r.c);
+}
+template <int N>
+__device__ inline void march_stats_wait(MarchStatRow& r) { (void)r; }
+template <int N>
+__device__ inline void march_stats_wait(MarchStatRow& r, MarchStatRow& q) { (void)r; (void)q; }
+#else
+__device__ __forceinline__ void march_stats_load(MarchStatRow& r, const float* base, uint32_t off)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" LES_STATS_POLICY : "+v"(r.a) : "v"(off), "s"(base));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" LES_STATS_POLICY : "+v"(r.b) : "v"(off), "s"(base));
+#if LES_MARCH_STAT_WORDS == 9
+    asm volatile("global_load_dword %0, %1, %2 offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(off), "s"(base));
+#else
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(off), "s"(base));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void march_stats_wait(MarchStatRow& r) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a), "+v"(r.b), "+v"(r.c) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void march_stats_wait(MarchStatRow& r, MarchStatRow& q)
+{
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(q.a), "+v"(q.b), "+v"(q.c) : "n"(N));
 }
 #endif
-
-// measurement switches (ablations: the output is meaningless, the time shows what a resource costs): 1 role C issues no statistics
-// loads, 2 role C reads no LDS, 16 role D reads no LDS, 64 role A loads nothing, 128 role D loads / stores nothing
-#ifndef LES_MARCH_EXP
-#define LES_MARCH_EXP 0
+__device__ __forceinline__ int march_stat_m2(const MarchStatRow& r)
+{
+#if LES_MARCH_STAT_WORDS == 9
+    return __float_as_int(r.c);
+#else
+    return __float_as_int(r.c.x);
 #endif
+}
+
+// LES/StereoEnergy.h:560-610 for a whole target rectangle at once: true when the plane is certainly a valid label at every pixel of
+// [x0, x1] x [y0, y1] (the five disparities ds, ds +- 5a +- 5b lie inside [mind, maxd] by a margin far above the rounding of the
+// reference's float expression).  Role D then skips the per-pixel test; anything not proven runs the exact per-pixel code.
+__device__ __forceinline__ bool march_label_surely_valid(const Geom& g, float4 pl, int x0, int x1, int y0, int y1)
+{
+    const float ax0 = pl.x * (float)x0, ax1 = pl.x * (float)x1, by0 = pl.y * (float)y0, by1 = pl.y * (float)y1;
+    const float spread = 5.0f * (fabsf(pl.x) + fabsf(pl.y));
+    const float lo = (fminf(ax0, ax1) + fminf(by0, by1)) + pl.z - spread;
+    const float hi = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + pl.z + spread;
+    const float mag = fmaxf(fabsf(ax0), fabsf(ax1)) + fmaxf(fabsf(by0), fabsf(by1)) + fabsf(pl.z) + spread;
+    const float margin = 1e-5f * mag + 1e-30f;
+    // (a non-finite coefficient makes lo / hi / mag non-finite or NaN and fails the comparisons; 0 * v must be 0 for the reference's ds)
+    return (0.0f * pl.w == 0.0f) && mag < 1e30f && (lo - margin >= g.mind) && (hi + margin <= g.maxd);
+}
+
 template <int R, int WGC, int NJ, int BY>
 __global__ void __launch_bounds__(3 * WGC * NJ)
 les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
                  float* __restrict__ out, int ngroups, int check)
 {
     using Cfg = MarchCfg<R, WGC, NJ, BY>;
-    constexpr int KS = Cfg::KS, NT = Cfg::NT, HWV = Cfg::HWV, NW = Cfg::NW, PCOLS = Cfg::PCOLS;
+    constexpr int KS = Cfg::KS, RS = Cfg::RS, NT = Cfg::NT, HWV = Cfg::HWV, PCOLS = Cfg::PCOLS;
+    constexpr int UN = 3;                     // blocks per ring = ticks per unrolled loop iteration = stage-2 buffers
 
     __shared__ int4 s_T1[2][NJ][BY][PCOLS];  // stage 1: vertical sums, then (in place) their prefix sums along x; double buffered over blocks
     __shared__ int4 s_T2[3][NJ][BY][PCOLS];  // stage 2: quantised (a_0, a_1, a_2, b), then their prefix sums; three blocks in flight (written, prefixed, consumed)
-    __shared__ double s_rtab[KS + 1];        // 1/n, n = 0..2R+1
+    __shared__ float s_rtab[KS + 1];         // 1/n, n = 0..2R+1 (0 for n = 0)
 
     // XCD-aware group order (cf. les_strip_kernel): consecutive groups (same strip, consecutive planes) share an XCD's L2
     int grp;
@@ -259,9 +322,6 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = readfirstlane_i32(tid >> 6);
-#ifndef LES_MARCH_ROLE_ORDER
-#define LES_MARCH_ROLE_ORDER 5
-#endif
     // Which role gets the oldest waves of a job slot.  The SIMD arbiter strictly prefers older waves (tools/ubench/mix_issue.hip),
     // so the youngest role only fills the issue slots the other two leave.  Measured on the headline workload (ms per pass, roles
     // listed oldest first): A D C 2.53 | D A C 2.58 | A C D 3.00 | C A D 3.20 | C D A 3.29 | D C A 3.40 -- the two roles that are
@@ -279,7 +339,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const float4 plane = planes[job.plane_idx];
     const int cy1m = max(job.cy1 - 1, job.cy0);
 
-    if (tid <= KS) s_rtab[tid] = tid > 0 ? 1.0 / (double)tid : 0.0;
+    if (tid <= KS) s_rtab[tid] = tid > 0 ? (float)(1.0 / (double)tid) : 0.0f;
     // element 0 of every row is P(-1) = 0 and stays untouched; every other element is written before it is read (a block is
     // written for all its columns before the next role reads it), the pads are never read
     for (int k = tid; k < 3 * NJ * BY; k += NT) {
@@ -292,7 +352,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int gx = job.tx0 - 2 * R + ci;                                  // image column of this lane (p, stage-1 and output column alike)
     const bool col_in = gx >= job.cx0 && gx < job.cx1 && job.th > 0;
     const int sx = min(max(gx, job.cx0), max(job.cx1 - 1, job.cx0));      // clamped: addresses stay inside the image
-    const uint32_t sx4 = (uint32_t)sx * 4u;                               // its byte offset in a row of floats / packed pixels
+    uint32_t sx4 = (uint32_t)sx * 4u;                                     // its byte offset in a row of floats / packed pixels (mutable: pinned in place by ld_sbase)
     const int nx = window_count(gx, R, job.cx0, job.cx1);                 // the same count serves stage 1 and stage 2 (same column)
     // physical columns of P(x+R), P(x-R-1) and, when the window crosses a wave boundary, of the left neighbour's tile total
     const int cP = min(ci + R, WGC - 1), cM = ci - R - 1;
@@ -302,11 +362,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int pcX = cross ? Cfg::pcol((cP >> 6) * 64 - 1) : 0;           // element 0 is the constant zero
     const int pcS = Cfg::pcol(ci);
 
-    // measurement switch (tools/role_time.sh): bit 0 / 1 / 2 = compile role A / C / D in; the waves of the other roles exit at once
-#ifndef LES_MARCH_ROLE_MASK
-#define LES_MARCH_ROLE_MASK 7
-#endif
-    if (role == 0 && (LES_MARCH_ROLE_MASK & 1)) {
+    if (role == 0 && LES_LAB_ROLE_ON(1)) {
         // ================================================= role A =================================================
         const uint32_t HWu = (uint32_t)g.H * (uint32_t)g.W;
         const float g_ax = plane.x * (float)sx;                           // a * x, LES/CostVolumeEnergy.h:76
@@ -314,19 +370,24 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const bool fronto = plane.x == 0.0f && plane.y == 0.0f;
         GatherPrep gpc = gather_prepare(g, 0.0f, plane.z, 0u, HWu, true);
         if (gpc.f1 == 0.0f) gpc.i1 = gpc.i0;                              // weight 0 on a finite volume: the second tap is never needed
-        int ringP[KS];                   // fixed-point cost of the last 2R+1 p-rows of this column
-        uint32_t ringG[KS];              // their guide pixels
+        int ringN[RS];                   // MINUS the fixed-point cost of the last RS p-rows of this column (the sign the row leaves the sums with)
+        uint32_t ringG[RS];              // their guide pixels
 #pragma unroll
-        for (int k = 0; k < KS; k++) { ringP[k] = 0; ringG[k] = 0u; }
+        for (int k = 0; k < RS; k++) { ringN[k] = 0; ringG[k] = 0u; }
         int Sp = 0;
-        long long Sc[3] = {1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1), 1ll << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
+        int Sc[3] = {1 << (kMarchSH - 1), 1 << (kMarchSH - 1), 1 << (kMarchSH - 1)};   // rounding bias of the >> SH folded in
         const uint32_t i0s = (uint32_t)readfirstlane_i32((int)gpc.i0), i1s = (uint32_t)readfirstlane_i32((int)gpc.i1);
         const float f1s = __int_as_float(readfirstlane_i32(__float_as_int(gpc.f1)));
         const int modes = readfirstlane_i32(gpc.mode);
-        const float pbias = fmaf(-view.vmin, view.sp, 0.5f);             // pi = trunc(p * sp + (0.5 - vmin * sp))
         const float f0s = 1.0f - f1s;
-        const bool inv_job = modes == 2;
-        // The march itself exists in three specialisations, selected once per job (a wave-uniform test per row costs the wave a
+        // fronto-parallel plane with an invalid label (LES/CostVolumeEnergy.h:80-88: C = 1e6 at every pixel, so p = th_col): the
+        // count is a per-job constant -- multiply the loaded cost by 0 and put the count of th_col into the addend
+        const bool inv_job = modes == 2 && !view.raw_off;
+        // Columns outside the clip contribute count 0: their factor is 0 and their addend the bare 1.5 * 2^23 (per-lane constants, so
+        // the column half of the clip test costs nothing per row; the row half is one v_and with a scalar mask)
+        const float spj = !col_in ? 0.0f : (inv_job ? 0.0f : view.sp);
+        const float pmj = !col_in ? __int_as_float(kMarchMagicBits) : (inv_job ? fmaf(g.th_col, view.sp, view.pmagic) : view.pmagic);
+        // The march itself exists in four specialisations, selected once per job (a wave-uniform test per row costs the wave a
         // taken branch and splits the row code into blocks the scheduler cannot interleave):
         //   KIND 0  fronto-parallel plane, one volume tap  (integer disparity, clamped or invalid label)
         //   KIND 1  fronto-parallel plane, two taps
@@ -362,7 +423,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             constexpr int i = decltype(itag)::value;
             const uint32_t rowpx = (uint32_t)readlane_i32(nx_rowpx, i);
             const uint32_t ro = rowpx & 0x7fffffffu;
-            if (LES_MARCH_EXP & 64) { rowbits = 0x7f; v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
+            if (LES_LAB_ABLATE(64)) { rowbits = 0x7f; v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
             if constexpr (KIND == 3) {
                 rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
                 const float* r0 = rawbase + (size_t)(uint32_t)readlane_i32(nx_rowraw, i);
@@ -386,9 +447,8 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         prep(0);
         static_for<BY>([&](auto itag) { issue_row(itag); });
         LES_TICK_BEGIN();
-        // three ticks per loop iteration: the ring slot of a block's first row, (k * BY) mod KS, is then a compile-time constant
+        // three ticks per loop iteration: the ring slot of a block's first row, (k * BY) mod RS, is then a compile-time constant
         // and the rings stay in fixed registers (a branch per block on the slot base made the allocator spill half of them)
-        constexpr int UN = KS / BY;
         for (int k0 = 0; k0 < nticks; k0 += UN) {
             static_for<UN>([&](auto utag) {
                 constexpr int BASE = decltype(utag)::value * BY;
@@ -399,36 +459,33 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         prep(k + 1);
                         static_for<BY>([&](auto itag) {
                             constexpr int i = decltype(itag)::value;
-                            constexpr int SLOT = BASE + i;       // ring slot of p-row k*BY + i; it holds the row that leaves the window (2R+1 rows ago)
+                            constexpr int SLOT = BASE + i;                   // ring slot of p-row k*BY + i
+                            constexpr int OLD = (SLOT + RS - KS) % RS;       // slot of the row that leaves the window (2R+1 rows ago); == SLOT when RS == KS
                             int pi;
                             if constexpr (KIND == 3) {
-                                pi = (col_in && ((rowbits >> i) & 1u)) ? (int)fmaf(v0[i], view.sp, pbias) : 0;
+                                pi = (__float_as_int(fmaf(v0[i], spj, pmj)) - kMarchMagicBits) & -(int)((rowbits >> i) & 1u);
                             } else if constexpr (KIND < 2) {
                                 // LES/CostVolumeEnergy.h:78-96 with per-job taps: clamped / interpolated / invalid, then min(C, th_col)
                                 // (one tap: the weight of the second is zero and the volume is finite, so f0 v0 + 0 v1 = v0)
                                 float C = v0[i];
                                 if constexpr (KIND == 1) C = f0s * v0[i] + f1s * v1[i];
-                                C = inv_job ? LES_COST_INVALID : C;
-                                const float p = (g.th_col < C) ? g.th_col : C;
-                                pi = (col_in && ((rowbits >> i) & 1u)) ? (int)fmaf(p, view.sp, pbias) : 0;
+                                const float p = min_f32_finite(C, g.th_col);
+                                pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & -(int)((rowbits >> i) & 1u);
                             } else {
                                 const float p = gather_finish(g, gp[i], v0[i], v1[i]);
-                                pi = gp[i].mode == 3 ? 0 : (int)fmaf(p, view.sp, pbias);
+                                pi = __float_as_int(fmaf(p, view.sp, view.pmagic)) - kMarchMagicBits;
+                                pi = gp[i].mode == 3 ? 0 : pi;
                             }
                             const uint32_t gi = gw[i];
-                            const int po = ringP[SLOT];
-                            const uint32_t go = ringG[SLOT];
-                            ringP[SLOT] = pi;
+                            const int no = ringN[OLD];
+                            const uint32_t go = ringG[OLD];
+                            ringN[SLOT] = -pi;
                             ringG[SLOT] = gi;
-                            Sp += pi - po;
-                            const int npo = -po;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                const int qi = ((int)(gi << (24 - 8 * c))) >> 24, qo = ((int)(go << (24 - 8 * c))) >> 24;
-                                Sc[c] += (long long)qi * (long long)pi;
-                                Sc[c] += (long long)qo * (long long)npo;
-                            }
-                            T[i][pcS] = int4{Sp, (int)(Sc[0] >> kMarchSH), (int)(Sc[1] >> kMarchSH), (int)(Sc[2] >> kMarchSH)};
+                            Sp = Sp + pi + no;
+                            Sc[0] = Sc[0] + mul24_sbyte<0>(gi, pi) + mul24_sbyte<0>(go, no);
+                            Sc[1] = Sc[1] + mul24_sbyte<1>(gi, pi) + mul24_sbyte<1>(go, no);
+                            Sc[2] = Sc[2] + mul24_sbyte<2>(gi, pi) + mul24_sbyte<2>(go, no);
+                            T[i][pcS] = int4{Sp, Sc[0] >> kMarchSH, Sc[1] >> kMarchSH, Sc[2] >> kMarchSH};
                             issue_row(itag);                     // the same row of block k + 1
                         });
                         LES_TICK_MARK();
@@ -440,10 +497,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
                         const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
                         constexpr bool kPair = KIND != 2;
-#ifndef LES_MARCH_PREFIX_PAIR
-#define LES_MARCH_PREFIX_PAIR 1
-#endif
-                        if (LES_MARCH_PREFIX_PAIR && kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
+                        if (kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
                             if (da) { wave_sync(); march_prefix_tile<BY, PCOLS>(s_T1[k & 1][slot], ci0, lane); }
                             if (db) march_prefix_tile<BY, PCOLS>(TB, ci0, lane);
@@ -459,25 +513,32 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         else if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
         else if (fronto) march_a(std::integral_constant<int, 1>{});
         else march_a(std::integral_constant<int, 2>{});
-    } else if (role == 1 && (LES_MARCH_ROLE_MASK & 2)) {
+    } else if (role == 1 && LES_LAB_ROLE_ON(2)) {
         // ================================================= role C =================================================
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
         const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2)
         // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
         // normalisation factors, the row part into the row's 1/count_y (0 * finite = 0, and v_cvt_rpi(+-0) = 0)
-        const float kap_x = s1_col ? view.kapS * (float)s_rtab[nx] : 0.0f;
-        const float up_x = s1_col ? view.upS * (float)s_rtab[nx] : 0.0f;
-        const uint32_t sx48 = (uint32_t)sx * 48u;
-        mstat4 st[BY][3];
+        const float kap_x = s1_col ? view.kapS * s_rtab[nx] : 0.0f;
+        const float up_x = s1_col ? view.upS * s_rtab[nx] : 0.0f;
+        const uint32_t sxS = (uint32_t)sx * (uint32_t)(4 * kMarchStatWords);
+        MarchStatRow st[BY];
 #pragma unroll
-        for (int i = 0; i < BY; i++) st[i][0] = st[i][1] = st[i][2] = mstat4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < BY; i++) {
+            st[i].a = st[i].b = mstat4{0.0f, 0.0f, 0.0f, 0.0f};
+#if LES_MARCH_STAT_WORDS == 9
+            st[i].c = 0.0f;
+#else
+            st[i].c = mstat4{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
+        }
         float rny[BY];                                                    // 1 / count_y of the rows of the block in flight, 0 for rows outside the clip or before the march is primed (wave-uniform: scalar registers)
         int nx_srow = 0;
         float nx_rny = 0.0f;
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy1 = job.ty0 - 3 * R + t;                          // centre of the vertical window that ends at p-row t
-            nx_rny = (float)s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
+            nx_rny = s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
             nx_srow = (int)(((uint32_t)min(max(gy1, job.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot) ? 0x80000000u : 0u));
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {      // rolling prefetch, see role A
@@ -485,11 +546,9 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             const uint32_t srow = (uint32_t)readlane_i32(nx_srow, i);
             const float r = readlane_f32(nx_rny, i);
             rny[i] = (srow >> 31) ? r : 0.0f;
-            const float4* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * 3;          // scalar row base + the lane's column
-            mstat4 &d0 = st[i][0], &d1 = st[i][1], &d2 = st[i][2];                    // (named here: operands of an asm statement alone do not capture)
-            const uint32_t off = sx48;
-            if (LES_MARCH_EXP & 1) return;
-            LES_STATS_LOAD(d0, sp, off, 0); LES_STATS_LOAD(d1, sp, off, 16); LES_STATS_LOAD(d2, sp, off, 32);
+            const float* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * kMarchStatWords;          // scalar row base + the lane's column
+            if (LES_LAB_ABLATE(1)) return;
+            march_stats_load(st[i], sp, sxS);
         };
         prep(0);
         static_for<BY>([&](auto itag) { issue_row(itag); });
@@ -510,7 +569,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
 #pragma unroll
                     for (int j = 0; j < GC; j++)
                         if (S * GC + j < BY) {
-                            if (LES_MARCH_EXP & 2) { pp[S & 1][j] = int4{lane, k, 2, 3}; pm[S & 1][j] = int4{3, 2, k, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
+                            if (LES_LAB_ABLATE(2)) { pp[S & 1][j] = int4{lane, k, 2, 3}; pm[S & 1][j] = int4{3, 2, k, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
                             else { pp[S & 1][j] = T1[S * GC + j][pcP]; pm[S & 1][j] = T1[S * GC + j][pcM]; px[S & 1][j] = T1[S * GC + j][pcX]; }
                         }
                 };
@@ -524,30 +583,32 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     // loads are in flight in issue order: the BY rows of the previous tick (or of the initial issue), then the rows
                     // of this tick's earlier stages.  Younger than the last row of this stage: 3 loads for each of the other BY - N rows.
                     static_assert(GC == 2, "vmcnt bookkeeping below is written for stages of two rows");
-                    {
-                        mstat4 (&ra)[3] = st[LO];
-                        mstat4 (&rb)[3] = st[LO + N - 1];
-                        if constexpr (N == 2) march_stats_wait6<3 * (BY - 2)>(ra, rb);
-                        else march_stats_wait3<3 * (BY - 1)>(ra);
-                    }
+                    if constexpr (N == 2) march_stats_wait<3 * (BY - 2)>(st[LO], st[LO + 1]);
+                    else march_stats_wait<3 * (BY - 1)>(st[LO]);
                     static_for<N>([&](auto jtag) {
                         constexpr int j = decltype(jtag)::value;
                         constexpr int i = LO + j;
                         const int s = pp[CB][j].x - pm[CB][j].x + px[CB][j].x;                         // sum of pi over the window (exact)
                         const int t0c = pp[CB][j].y - pm[CB][j].y + px[CB][j].y, t1c = pp[CB][j].z - pm[CB][j].z + px[CB][j].z, t2c = pp[CB][j].w - pm[CB][j].w + px[CB][j].w;
-                        const mstat4 q0 = st[i][0], q1 = st[i][1], q2 = st[i][2];
-                        const int M0 = __float_as_int(q2.y), M1 = __float_as_int(q2.z), M2 = __float_as_int(q2.w);
-                        // N cov_c in units of 2^SH (u8 * pi): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
-                        const float d0 = (float)(t0c - (int)(((long long)M0 * (long long)s + (1ll << 31)) >> 32));
-                        const float d1 = (float)(t1c - (int)(((long long)M1 * (long long)s + (1ll << 31)) >> 32));
-                        const float d2 = (float)(t2c - (int)(((long long)M2 * (long long)s + (1ll << 31)) >> 32));
+                        const mstat4 q0 = st[i].a, q1 = st[i].b;
+                        const int M0 = __float_as_int(q1.z), M1 = __float_as_int(q1.w), M2 = march_stat_m2(st[i]);
+                        // N cov_c in units of 2^SH (u8 * count): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
+                        const long long s8 = (long long)(s << kMarchSL);
+                        const float d0 = (float)(t0c - (int)(((long long)M0 * s8 + (1ll << 31)) >> 32));
+                        const float d1 = (float)(t1c - (int)(((long long)M1 * s8 + (1ll << 31)) >> 32));
+                        const float d2 = (float)(t2c - (int)(((long long)M2 * s8 + (1ll << 31)) >> 32));
                         // LES/GuidedFilter.h:204-221 with the scale of the integer stage 2 folded into the normalisation
                         const float ka = kap_x * rny[i];
                         const float a0 = fmaf(q0.z, d2, fmaf(q0.y, d1, q0.x * d0)) * ka;     // inv00 inv01 inv02
                         const float a1 = fmaf(q1.x, d2, fmaf(q0.w, d1, q0.y * d0)) * ka;     // inv01 inv11 inv12
                         const float a2 = fmaf(q1.y, d2, fmaf(q1.x, d1, q0.z * d0)) * ka;     // inv02 inv12 inv22
                         const float mp = (float)s * (up_x * rny[i]);
-                        const float bb = fmaf(-a2, q2.x, fmaf(-a1, q1.w, fmaf(-a0, q1.z, mp)));
+#if LES_MARCH_STAT_WORDS == 9
+                        // b = mean_p - a . mu with mu_c = M_c 2^-MB / 255 (the float of M_c carries the mean to 2^-24 relative, as a stored float would)
+                        const float bb = fmaf(-view.kmu, fmaf(a2, (float)M2, fmaf(a1, (float)M1, a0 * (float)M0)), mp);
+#else
+                        const float bb = fmaf(-a2, st[i].c.w, fmaf(-a1, st[i].c.z, fmaf(-a0, st[i].c.y, mp)));
+#endif
                         int4 o;
                         o.x = cvt_rpi_i32(a0);
                         o.y = cvt_rpi_i32(a1);
@@ -567,19 +628,22 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             LES_TICK_BARRIER();
         }
         LES_TICK_END(1);
-    } else if (role == 2 && (LES_MARCH_ROLE_MASK & 4)) {
+    } else if (role == 2 && LES_LAB_ROLE_ON(4)) {
         // ================================================= role D =================================================
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
-        const uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;           // byte offset of the lane's output column in a row of the output tile
+        uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;                 // byte offset of the lane's output column in a row of the output tile
         // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
         // ds +- 5a +- 5b must all lie in [MIN, MAX]  <=>  min of the five >= MIN and max <= MAX (a NaN only arises next to an
         // infinity, which fails the range test; an all-NaN set fails the comparison itself)
         const float vl_xa = (float)gx * plane.x, vl_c = 1.0f * plane.z, vl_zv = 0.0f * plane.w, vl_a5 = plane.x * 5, vl_b5 = plane.y * 5;
-        const double c_lane = view.qscale * s_rtab[nx];                    // 1 / (255 scale count_x)
-        int ring2[4][KS];                // horizontal box sums of (a_0, a_1, a_2, b) of the last 2R+1 stage-1 rows
+        const float c_lane = view.qscale * s_rtab[nx];                     // 2^S2 / (255 scale count_x)
+        int ring2[4][RS];                // rounded horizontal box sums of (a_0, a_1, a_2, b) of the last RS stage-1 rows
 #pragma unroll
-        for (int k = 0; k < KS; k++) ring2[0][k] = ring2[1][k] = ring2[2][k] = ring2[3][k] = 0;
-        double S2[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < RS; k++) ring2[0][k] = ring2[1][k] = ring2[2][k] = ring2[3][k] = 0;
+        // their sums over the last 2R+1 rows: exact 64-bit integers (< 2^34.4), one v_mad_i64_i32 per row and quantity (acc64_add_i32); rounded once, to 2^-S2, when a row is
+        // written -- rounding every horizontal sum instead (int32 accumulators) triples the error of the full-size linearity property
+        // (tools/fixedpoint_probe.py --full: 6.6e-7 against 3.0e-7; the test bound is 5e-7)
+        long long S2[4] = {1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1)};
         uint32_t gq[BY];
         float rny2[BY];                                                   // 1 / count_y of the block's output rows
         uint32_t okbits = 0;
@@ -588,7 +652,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy2 = job.ty0 - 4 * R + t;
-            nx_rny = (float)s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
+            nx_rny = s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
             nx_grow = (int)(((uint32_t)min(max(gy2, job.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < Ttot) ? 0x80000000u : 0u));
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
@@ -597,14 +661,13 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             rny2[i] = readlane_f32(nx_rny, i);
             okbits = (okbits & ~(1u << i)) | ((grow >> 31) << i);
             const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
-            if (LES_MARCH_EXP & 128) { gq[i] = (uint32_t)lane; return; }
+            if (LES_LAB_ABLATE(128)) { gq[i] = (uint32_t)lane; return; }
             gq[i] = ld_sbase(rg, sx4);
         };
         // two specialisations (label check on / off), selected once per job -- see role A
         auto march_d = [&](auto check_tag) __attribute__((always_inline)) {
         constexpr bool CHECK = decltype(check_tag)::value != 0;
         LES_TICK_BEGIN();
-        constexpr int UN = KS / BY;
         for (int k0 = 0; k0 < nticks; k0 += UN) {
             static_for<UN>([&](auto utag) {
                 constexpr int U = decltype(utag)::value;
@@ -621,7 +684,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
 #pragma unroll
                             for (int j = 0; j < GD; j++)
                                 if (S * GD + j < BY) {
-                                    if (LES_MARCH_EXP & 16) { pp[S & 1][j] = int4{lane, b, 2, 3}; pm[S & 1][j] = int4{3, 2, b, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
+                                    if (LES_LAB_ABLATE(16)) { pp[S & 1][j] = int4{lane, b, 2, 3}; pm[S & 1][j] = int4{3, 2, b, lane}; px[S & 1][j] = int4{0, 0, 0, 0}; }
                                     else { pp[S & 1][j] = T2[S * GD + j][pcP]; pm[S & 1][j] = T2[S * GD + j][pcM]; px[S & 1][j] = T2[S * GD + j][pcX]; }
                                 }
                         };
@@ -635,21 +698,20 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             static_for<N>([&](auto jtag) {
                                 constexpr int j = decltype(jtag)::value;
                                 constexpr int i = LO + j;
-                                constexpr int SLOT = BASE + i;
+                                constexpr int SLOT = BASE + i, OLD = (SLOT + RS - KS) % RS;
+                                // horizontal box sums (exact, |h| < 2^30 by the stage-2 scale)
                                 const int h0 = pp[CB][j].x - pm[CB][j].x + px[CB][j].x, h1 = pp[CB][j].y - pm[CB][j].y + px[CB][j].y;
                                 const int h2 = pp[CB][j].z - pm[CB][j].z + px[CB][j].z, h3 = pp[CB][j].w - pm[CB][j].w + px[CB][j].w;
-                                S2[0] += (double)(h0 - ring2[0][SLOT]); ring2[0][SLOT] = h0;
-                                S2[1] += (double)(h1 - ring2[1][SLOT]); ring2[1][SLOT] = h1;
-                                S2[2] += (double)(h2 - ring2[2][SLOT]); ring2[2][SLOT] = h2;
-                                S2[3] += (double)(h3 - ring2[3][SLOT]); ring2[3][SLOT] = h3;
+                                const int o0 = ring2[0][OLD], o1 = ring2[1][OLD], o2 = ring2[2][OLD], o3 = ring2[3][OLD];
+                                ring2[0][SLOT] = h0; ring2[1][SLOT] = h1; ring2[2][SLOT] = h2; ring2[3][SLOT] = h3;
+                                acc64_add_i32(S2[0], h0 - o0); acc64_add_i32(S2[1], h1 - o1); acc64_add_i32(S2[2], h2 - o2); acc64_add_i32(S2[3], h3 - o3);
                                 if (out_col && ((okbits >> i) & 1u)) {
                                     const int t = b * BY + i;
                                     const uint32_t gi = gq[i];
-                                    const double i0 = (double)(((int)(gi << 24)) >> 24), i1 = (double)(((int)(gi << 16)) >> 24), i2 = (double)(((int)(gi << 8)) >> 24);
-                                    // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide, in integers < 2^53
-                                    const double acc = fma(S2[2], i2, fma(S2[1], i1, fma(S2[0], i0, S2[3] * 255.0)));
-                                    // the 1/count_y factor and the offset are applied in fp32 (relative error 1e-7 of q - vmin)
-                                    float q = fmaf((float)(acc * c_lane), rny2[i], view.vmin);
+                                    // LES/GuidedFilter.h:243: (b + a . I) / N on the centred guide (fp32: each window sum carries 2^-24 relative)
+                                    const float f0 = (float)(int)(S2[0] >> kMarchS2), f1 = (float)(int)(S2[1] >> kMarchS2), f2 = (float)(int)(S2[2] >> kMarchS2), f3 = (float)(int)(S2[3] >> kMarchS2);
+                                    const float acc = fmaf(f2, cvt_f32_sbyte<2>(gi), fmaf(f1, cvt_f32_sbyte<1>(gi), fmaf(f0, cvt_f32_sbyte<0>(gi), f3 * 255.0f)));
+                                    float q = fmaf(acc * c_lane, rny2[i], view.poff);
                                     if constexpr (CHECK) {
                                         const int gy2 = job.ty0 + t - 4 * R;
                                         const float ds = ((vl_xa + (float)gy2 * plane.y) + vl_c) + vl_zv;
@@ -658,14 +720,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                         const float mn = fmin3(fmin3(ds, d1, d2), d3, d4), mx = fmax3(fmax3(ds, d1, d2), d3, d4);
                                         if (!(mn >= g.mind && mx <= g.maxd)) q = LES_COST_INVALID;
                                     }
-                                    if (!((LES_MARCH_EXP & 128) && q != 12345.0f))
+                                    if (!(LES_LAB_ABLATE(128) && q != 12345.0f))
                                     st_sbase(out + (job.out_off + (long long)(t - 4 * R) * job.out_stride), oc4, q);
                                 }
                             });
                             LES_MARCH_SCHED_FENCE();
                         });
                     }
-                    if (k >= 2 && k <= nblk + 1) {                // guide rows of the block this role handles at the next tick (7 dwords per
+                    if (k >= 2 && k <= nblk + 1) {                // guide rows of the block this role handles at the next tick (BY dwords per
                         prep(k - 2);                              // lane; this role is never the last to arrive at the barrier, and it has no
                         static_for<BY>([&](auto itag) { issue_row(itag); });   // registers to spare for a rolling issue)
                     }
@@ -675,7 +737,10 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         }
         LES_TICK_END(2);
         };
-        if (check) march_d(std::integral_constant<int, 1>{});
+        // The per-pixel label test is only compiled in where it can matter: not for a plane that is provably valid on the whole target
+        // strip (every fronto-parallel plane with c inside the range, and the optimiser's proposals away from the disparity limits).
+        const bool surely_valid = march_label_surely_valid(g, plane, job.tx0, job.tx0 + max(job.tw, 1) - 1, job.ty0, job.ty0 + max(job.th, 1) - 1);
+        if (check && !surely_valid) march_d(std::integral_constant<int, 1>{});
         else march_d(std::integral_constant<int, 0>{});
     }
 }
@@ -686,7 +751,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
 // guide as signed bytes + statistics in the march format (from the same fp64 horizontal sums as les_stats_finish_kernel);
 // *inv_diag_max (float bits, positive) collects max over pixels of the diagonal of the inverse covariance
 __global__ void les_march_stats_kernel(const double* __restrict__ hs, const uint32_t* __restrict__ ipk, uint32_t* __restrict__ ipk8,
-                                       float4* __restrict__ mstats, unsigned* __restrict__ inv_diag_max, int H, int W, int R, double eps)
+                                       float* __restrict__ mstats, unsigned* __restrict__ inv_diag_max, int H, int W, int R, double eps)
 {
     int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y;
     if (x >= W) return;
@@ -707,11 +772,18 @@ __global__ void les_march_stats_kernel(const double* __restrict__ hs, const uint
     double det = irr * rr + irg * rg + irb * rb;
     irr /= det; irg /= det; irb /= det; igg /= det; igb /= det; ibb /= det;
     size_t px = (size_t)y * W + x;
-    const double c0 = m0 * 255.0 - 128.0, c1 = m1 * 255.0 - 128.0, c2 = m2 * 255.0 - 128.0;    // centred means in u8 units
-    const int M0 = (int)rint(c0 * 8388608.0), M1 = (int)rint(c1 * 8388608.0), M2 = (int)rint(c2 * 8388608.0);
-    mstats[px * 3 + 0] = make_float4((float)irr, (float)irg, (float)irb, (float)igg);
-    mstats[px * 3 + 1] = make_float4((float)igb, (float)ibb, (float)(c0 / 255.0), (float)(c1 / 255.0));
-    mstats[px * 3 + 2] = make_float4((float)(c2 / 255.0), __int_as_float(M0), __int_as_float(M1), __int_as_float(M2));
+    // centred means in u8 units, [-128, 127], as integers with MB fraction bits (|M| <= 2^31: the clamp only guards the rounding of a
+    // mean of exactly 255)
+    const double fs = (double)(1ll << kMarchMB);
+    const double c0 = m0 * 255.0 - 128.0, c1 = m1 * 255.0 - 128.0, c2 = m2 * 255.0 - 128.0;
+    const int M0 = (int)fmin(fmax(rint(c0 * fs), -2147483648.0), 2147483647.0);
+    const int M1 = (int)fmin(fmax(rint(c1 * fs), -2147483648.0), 2147483647.0);
+    const int M2 = (int)fmin(fmax(rint(c2 * fs), -2147483648.0), 2147483647.0);
+    float* o = mstats + px * kMarchStatWords;
+    o[0] = (float)irr; o[1] = (float)irg; o[2] = (float)irb; o[3] = (float)igg;
+    o[4] = (float)igb; o[5] = (float)ibb; o[6] = __int_as_float(M0); o[7] = __int_as_float(M1);
+    o[8] = __int_as_float(M2);
+    if (kMarchStatWords == 12) { o[9] = (float)(c0 / 255.0); o[10] = (float)(c1 / 255.0); o[11] = (float)(c2 / 255.0); }
     const uint32_t v = ipk[px];
     const uint32_t b0 = ((v & 0xffu) - 128u) & 0xffu, b1 = (((v >> 8) & 0xffu) - 128u) & 0xffu, b2 = (((v >> 16) & 0xffu) - 128u) & 0xffu;
     ipk8[px] = b0 | (b1 << 8) | (b2 << 16);

@@ -66,6 +66,14 @@ __device__ inline float fmin3(float a, float b, float c) { return fminf(fminf(a,
 __device__ inline float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 // value of `v` in lane `l` of this wave (every lane of the wave must call it)
 __device__ inline int readlane_i32(int v, int l) { return hipsim::wave_readlane(v, l); }
+// round-4 primitives of the march kernel: signed byte B of a packed word times a 24-bit integer (v_mul_i32_i24 with an SDWA byte
+// operand), float of signed byte B (v_cvt_f32_i32 with an SDWA byte operand), min without NaN handling (finite operands only)
+template <int B>
+__device__ inline int mul24_sbyte(uint32_t g, int v) { return (((int)(g << (24 - 8 * B))) >> 24) * v; }
+template <int B>
+__device__ inline float cvt_f32_sbyte(uint32_t g) { return (float)(((int)(g << (24 - 8 * B))) >> 24); }
+__device__ inline float min_f32_finite(float a, float b) { return b < a ? b : a; }
+__device__ inline void acc64_add_i32(long long& acc, int d) { acc += (long long)d; }
 
 #else
 
@@ -146,6 +154,43 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// round-4 primitives of the march kernel (tools/ubench/valu_rates.hip: an SDWA byte operand costs nothing on top of the operation,
+// against a separate v_bfe_i32 at 4.2 cycles):
+//   mul24_sbyte<B>(g, v)   sign-extended byte B of g times the low 24 bits of v        (v_mul_i32_i24_sdwa)
+//   cvt_f32_sbyte<B>(g)    float of the sign-extended byte B of g                       (v_cvt_f32_i32_sdwa)
+//   min_f32_finite(a, b)   one v_min_f32 (fminf() adds a canonicalising v_max_f32 in IEEE mode; the operands here are finite)
+template <int B>
+__device__ __forceinline__ int mul24_sbyte(uint32_t g, int v)
+{
+    int r;
+    static_assert(B >= 0 && B < 3, "guide byte");
+    if constexpr (B == 0) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(g), "v"(v));
+    else if constexpr (B == 1) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(g), "v"(v));
+    else asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(g), "v"(v));
+    return r;
+}
+template <int B>
+__device__ __forceinline__ float cvt_f32_sbyte(uint32_t g)
+{
+    float r;
+    static_assert(B >= 0 && B < 3, "guide byte");
+    if constexpr (B == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(g));
+    else if constexpr (B == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(g));
+    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(g));
+    return r;
+}
+__device__ __forceinline__ float min_f32_finite(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// acc += sign-extended d in ONE instruction (v_mad_i64_i32 with the inline constant 1; the compiler's own lowering of a 64-bit add
+// of a sign-extended word is v_ashrrev + v_add_co + v_addc)
+__device__ __forceinline__ void acc64_add_i32(long long& acc, int d)
+{
+    asm("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(d) : "vcc");
+}
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }    // folds to v_min3_f32
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 

@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 LIB = os.path.join(os.getcwd(), "localexpstereo_amd/csrc/libles_phase_timing.so")
 if "--build" in sys.argv:
     from localexpstereo_amd import build
-    subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-DLES_PHASE_TIMING", os.path.join(build.CSRC, "les_hip.hip"), "-o", LIB], cwd=build.CSRC)
+    subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-DLES_MARCH_LAB", "-DLES_PHASE_TIMING", os.path.join(build.CSRC, "les_hip.hip"), "-o", LIB], cwd=build.CSRC)
     print("built", LIB)
     sys.exit(0)
 os.environ["LES_HIP_LIB"] = os.environ.get("PHASE_LIB", LIB)
