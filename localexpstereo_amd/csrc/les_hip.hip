@@ -440,6 +440,8 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     const size_t P = (size_t)c->p.H * c->p.W;
     const int W = c->p.W, H = c->p.H;
     v.march_ok = false;
+    // the kernel addresses image rows and statistics rows by 32-bit byte offsets (raw buffer access): images of 2^26 pixels or more stay on the strip kernel
+    if ((unsigned long long)P * (4ull * les::kMarchStatWords) >= (1ull << 31)) return LES_HIP_OK;
     // image-based energy: the raw cost min(|dcolor|, th_color) + min(|dgrad|, th_grad) lies in [0, th_color + th_grad] by construction
     const float th = c->naive ? c->th_color + c->th_grad : c->p.th_col;
     if (!(th > 0.0f) || !(th < INFINITY)) return LES_HIP_OK;

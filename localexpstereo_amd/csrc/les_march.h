@@ -75,6 +75,11 @@ __host__ __device__ constexpr int march_pb(int R) { return (2 * R + 1) * (2 * R 
 #define LES_MARCH_STAT_WORDS 9
 #endif
 constexpr int kMarchStatWords = LES_MARCH_STAT_WORDS;
+// which role prefixes the stage-2 tiles in the one-job geometry: 0 = role A (after its own stage-1 tile), 2 = role D (after its rows)
+#ifndef LES_MARCH_T2_PREFIX_ROLE
+#define LES_MARCH_T2_PREFIX_ROLE 0
+#endif
+constexpr bool kMarchT2PrefixOnD = LES_MARCH_T2_PREFIX_ROLE == 2;
 static_assert(kMarchStatWords == 9 || kMarchStatWords == 12, "statistics record of 36 or 48 bytes");
 
 struct MarchView {
@@ -146,9 +151,21 @@ __device__ __forceinline__ void march_prefix_scan8(int4 (&v)[8])
 #pragma unroll
     for (int j = 1; j < 8; j++) { v[j].x += v[j - 1].x; v[j].y += v[j - 1].y; v[j].z += v[j - 1].z; v[j].w += v[j - 1].w; }
     int4 inc = v[7];
+#if defined(LES_SIM) || defined(LES_MARCH_SCAN_PLAIN)
 #define LES_SCAN_STEP(N) { inc.x += dpp_row_shr<N>(inc.x); inc.y += dpp_row_shr<N>(inc.y); inc.z += dpp_row_shr<N>(inc.z); inc.w += dpp_row_shr<N>(inc.w); }
     LES_SCAN_STEP(2) LES_SCAN_STEP(4) LES_SCAN_STEP(8)
 #undef LES_SCAN_STEP
+#else
+    // one v_add_u32_dpp per step and component (the compiler's lowering of the line above is v_mov_b32_dpp + v_add_u32: twice the
+    // instructions).  A DPP operand must have been written at least two wait states earlier: the four components are interleaved, so
+    // only the first step needs the s_nop.
+#define LES_SCAN_ROW(N) "v_add_u32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+                        "v_add_u32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+                        "v_add_u32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+                        "v_add_u32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm("s_nop 1\n" LES_SCAN_ROW(2) LES_SCAN_ROW(4) LES_SCAN_ROW(8) : "+v"(inc.x), "+v"(inc.y), "+v"(inc.z), "+v"(inc.w));
+#undef LES_SCAN_ROW
+#endif
     const int4 off = int4{inc.x - v[7].x, inc.y - v[7].y, inc.z - v[7].z, inc.w - v[7].w};
 #pragma unroll
     for (int j = 0; j < 8; j++) { v[j].x += off.x; v[j].y += off.y; v[j].z += off.z; v[j].w += off.w; }
@@ -205,28 +222,11 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
     }
 }
 
-// wave-uniform base + unsigned 32-bit per-lane byte offset: compiles to the `saddr` form of global_load / global_store, i.e. no
-// 64-bit address arithmetic on the VALU.  (The empty asm pins the offset as a 32-bit value in the block of the access; otherwise its
-// zero-extension is hoisted out of the loops and instruction selection falls back to a 64-bit VGPR address + v_lshl_add_u64.)
-#if defined(LES_SIM)
-#define LES_PIN_U32(x) ((void)0)
-#else
-#define LES_PIN_U32(x) asm volatile("" : "+v"(x))
-#endif
-// (`byte_off` is pinned IN PLACE: the caller passes a mutable per-role copy, so no v_mov precedes the access)
-template <class T>
-__device__ __forceinline__ T ld_sbase(const T* base, uint32_t& byte_off)
-{
-    LES_PIN_U32(byte_off);
-#if defined(LES_MARCH_LAB) && defined(LES_VOL_NT) && !defined(LES_SIM)
-    return __builtin_nontemporal_load((const T*)((const char*)base + byte_off));
-#else
-    return *(const T*)((const char*)base + byte_off);
-#endif
-}
-template <class T>
-__device__ __forceinline__ void st_sbase(T* base, uint32_t& byte_off, T v) { LES_PIN_U32(byte_off); *(T*)((char*)base + byte_off) = v; }
-
+// Memory access of the roles (round 4): raw buffer loads / stores (les_simt.h: buf_load / buf_store) -- descriptor base + the lane's
+// 32-bit byte offset in a row + a wave-uniform row offset that v_readlane hands over from a lane-computed table.  A row costs one
+// v_readlane and no scalar address arithmetic (the global_load `saddr` form took a 64-bit scalar shift-add per row and access, and the
+// flag bits packed into the row word another four scalar instructions; 22 % of the kernel's instructions were scalar).  The row
+// flags of a block travel as ONE ballot of the lane table (bit i = row i) instead.
 // The statistics rows of role C are loop-carried register tuples that are reloaded in place, one row at a time, while the rest of
 // the block is still being consumed.  Written as plain C++ loads, the register allocator lands every reload in a fresh tuple and
 // copies it to the loop-carried one right away, i.e. waits for the load it has just issued.  The loads are therefore issued as
@@ -246,9 +246,11 @@ typedef mstat4 mstat_tail;                      // {M2, mu0, mu1, mu2}
 #endif
 struct MarchStatRow { mstat4 a, b; mstat_tail c; };
 #if defined(LES_SIM)
-__device__ inline void march_stats_load(MarchStatRow& r, const float* base, uint32_t off)
+struct MarchStatDesc { const char* base; };
+__device__ inline MarchStatDesc march_stats_desc(const float* base, uint32_t) { return MarchStatDesc{(const char*)base}; }
+__device__ inline void march_stats_load(MarchStatRow& r, const MarchStatDesc& d, uint32_t voff, uint32_t soff)
 {
-    const char* q = (const char*)base + off;                        // 36-byte records: not 16-byte aligned
+    const char* q = d.base + (size_t)voff + (size_t)soff;          // 36-byte records: not 16-byte aligned
     memcpy(&r.a, q, 16); memcpy(&r.b, q + 16, 16); memcpy(&r.c, q + 32, sizeof r.c);
 }
 template <int N>
@@ -256,14 +258,27 @@ __device__ inline void march_stats_wait(MarchStatRow& r) { (void)r; }
 template <int N>
 __device__ inline void march_stats_wait(MarchStatRow& r, MarchStatRow& q) { (void)r; (void)q; }
 #else
-__device__ __forceinline__ void march_stats_load(MarchStatRow& r, const float* base, uint32_t off)
+typedef int MarchStatDesc __attribute__((ext_vector_type(4)));      // buffer descriptor words (raw, stride 0, num_records in bytes)
+__device__ __forceinline__ MarchStatDesc march_stats_desc(const float* base, uint32_t bytes)
 {
-    asm volatile("global_load_dwordx4 %0, %1, %2" LES_STATS_POLICY : "+v"(r.a) : "v"(off), "s"(base));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" LES_STATS_POLICY : "+v"(r.b) : "v"(off), "s"(base));
+    const unsigned long long a = (unsigned long long)base;
+    MarchStatDesc d;
+    d.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    d.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    d.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    d.w = 0x00027000;
+    return d;
+}
+// soff must be an SGPR that a SCALAR instruction wrote (the caller masks the table word): a v_readlane result used by a vector-memory
+// instruction within five wait states is a hazard the compiler cannot see inside inline assembly
+__device__ __forceinline__ void march_stats_load(MarchStatRow& r, const MarchStatDesc& d, uint32_t voff, uint32_t soff)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" LES_STATS_POLICY : "+v"(r.a) : "v"(voff), "s"(d), "s"(soff));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" LES_STATS_POLICY : "+v"(r.b) : "v"(voff), "s"(d), "s"(soff));
 #if LES_MARCH_STAT_WORDS == 9
-    asm volatile("global_load_dword %0, %1, %2 offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(off), "s"(base));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(voff), "s"(d), "s"(soff));
 #else
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(off), "s"(base));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:32" LES_STATS_POLICY : "+v"(r.c) : "v"(voff), "s"(d), "s"(soff));
 #endif
 }
 template <int N>
@@ -352,7 +367,10 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int gx = job.tx0 - 2 * R + ci;                                  // image column of this lane (p, stage-1 and output column alike)
     const bool col_in = gx >= job.cx0 && gx < job.cx1 && job.th > 0;
     const int sx = min(max(gx, job.cx0), max(job.cx1 - 1, job.cx0));      // clamped: addresses stay inside the image
-    uint32_t sx4 = (uint32_t)sx * 4u;                                     // its byte offset in a row of floats / packed pixels (mutable: pinned in place by ld_sbase)
+    const uint32_t sx4 = (uint32_t)sx * 4u;                               // its byte offset in a row of floats / packed pixels
+    const uint32_t rowB = (uint32_t)g.W * 4u;                             // bytes per image row of floats / packed pixels
+    const uint32_t imgB = (uint32_t)g.H * rowB;                           // bytes per image plane (the host refuses images of 2^29 pixels or more)
+    const BufRsrc rs_guide = make_buf(view.ipk8, imgB);
     const int nx = window_count(gx, R, job.cx0, job.cx1);                 // the same count serves stage 1 and stage 2 (same column)
     // physical columns of P(x+R), P(x-R-1) and, when the window crosses a wave boundary, of the left neighbour's tile total
     const int cP = min(ci + R, WGC - 1), cM = ci - R - 1;
@@ -400,50 +418,50 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         GatherPrep gp[BY];
         float v0[BY], v1[BY];
         uint32_t gw[BY];
-        uint32_t rowbits = 0;            // fronto path: bit i = p-row i of the block is inside the clip and the march
+        uint32_t rowbits = 0, rowbits_nx = 0;   // bit i = p-row i of the block (in flight / being loaded) is inside the clip and the march
         // Row scalars of block b: lane i < BY computes those of p-row b*BY + i, v_readlane hands them to the wave as scalars.
         // Loads are issued one row at a time, right after the same row of the previous block has been consumed ("rolling"
         // prefetch: a whole tick of latency cover without a second set of registers).  Rows beyond the march are clamped to a
         // valid address and flagged off, so the issue needs no branch.
-        int nx_rowpx = 0;
+        int nx_rowB = 0;                 // byte offset of the (clamped) image row
         float nx_dbase = 0.0f;
-        int nx_rowraw = 0;               // KIND 3: float offset of the row in the call's patch
+        int nx_rowraw = 0;               // KIND 3: byte offset of the row in the call's patch
         const int fw = job.cx1 - job.cx0;
-        const float* rawbase = nullptr;
-        if constexpr (KIND == 3) rawbase = view.vol + view.raw_off[job.plane_idx] - job.cx0;
+        // descriptors: the volume slice(s) of a fronto-parallel plane / the call's raw-cost patch (its column 0 = image column cx0)
+        const float* v0base = view.vol + (size_t)i0s;
+        if constexpr (KIND == 3) v0base = view.vol + view.raw_off[job.plane_idx] - job.cx0;
+        const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : imgB);
+        const BufRsrc rs_v1 = make_buf(view.vol + (size_t)i1s, imgB);
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy = job.ty0 - 2 * R + t;
             const int sy = min(max(gy, job.cy0), cy1m);
-            nx_rowpx = (int)(((uint32_t)sy * (uint32_t)g.W) | ((t < Ttot && gy >= job.cy0 && gy < job.cy1) ? 0x80000000u : 0u));
-            if constexpr (KIND == 3) nx_rowraw = (sy - job.cy0) * fw;
+            nx_rowB = (int)((uint32_t)sy * rowB);
+            rowbits_nx = ballot_low(t < Ttot && gy >= job.cy0 && gy < job.cy1, BY);
+            if constexpr (KIND == 3) nx_rowraw = (sy - job.cy0) * fw * 4;
             else nx_dbase = plane.y * (float)sy + plane.z;              // b*y + c, LES/CostVolumeEnergy.h:73
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;
-            const uint32_t rowpx = (uint32_t)readlane_i32(nx_rowpx, i);
-            const uint32_t ro = rowpx & 0x7fffffffu;
-            if (LES_LAB_ABLATE(64)) { rowbits = 0x7f; v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
+            const uint32_t ro = (uint32_t)readlane_i32(nx_rowB, i);
+            if (LES_LAB_ABLATE(64)) { v0[i] = (float)lane; v1[i] = 0.0f; gw[i] = (uint32_t)lane; return; }
             if constexpr (KIND == 3) {
-                rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
-                const float* r0 = rawbase + (size_t)(uint32_t)readlane_i32(nx_rowraw, i);
-                v0[i] = ld_sbase(r0, sx4);
+                v0[i] = buf_load<float>(rs_v0, sx4, (uint32_t)readlane_i32(nx_rowraw, i));
             } else if constexpr (KIND < 2) {
-                rowbits = (rowbits & ~(1u << i)) | ((rowpx >> 31) << i);
-                const float* r0 = view.vol + (size_t)(i0s + ro);          // scalar bases: the loads take them + the lane's column
-                v0[i] = ld_sbase(r0, sx4);
-                if constexpr (KIND == 1) { const float* r1 = view.vol + (size_t)(i1s + ro); v1[i] = ld_sbase(r1, sx4); }
+                v0[i] = buf_load<float>(rs_v0, sx4, ro);
+                if constexpr (KIND == 1) v1[i] = buf_load<float>(rs_v1, sx4, ro);
             } else {
                 const float d_base = readlane_f32(nx_dbase, i);
-                const bool inside = col_in && (rowpx >> 31);
-                gp[i] = gather_prepare(g, g_ax, d_base, ro + (uint32_t)sx, HWu, inside);
+                const bool inside = col_in && ((rowbits_nx >> i) & 1u);
+                gp[i] = gather_prepare(g, g_ax, d_base, (ro >> 2) + (uint32_t)sx, HWu, inside);
                 if (gp[i].f1 == 0.0f) gp[i].i1 = gp[i].i0;
                 v0[i] = view.vol[gp[i].i0];
                 v1[i] = view.vol[gp[i].i1];
             }
-            const uint32_t* rg = view.ipk8 + (size_t)ro;
-            gw[i] = ld_sbase(rg, sx4);
+            gw[i] = buf_load<uint32_t>(rs_guide, sx4, ro);
         };
+        prep(0);
+        rowbits = rowbits_nx;
         prep(0);
         static_for<BY>([&](auto itag) { issue_row(itag); });
         LES_TICK_BEGIN();
@@ -463,14 +481,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             constexpr int OLD = (SLOT + RS - KS) % RS;       // slot of the row that leaves the window (2R+1 rows ago); == SLOT when RS == KS
                             int pi;
                             if constexpr (KIND == 3) {
-                                pi = (__float_as_int(fmaf(v0[i], spj, pmj)) - kMarchMagicBits) & -(int)((rowbits >> i) & 1u);
+                                pi = (__float_as_int(fmaf(v0[i], spj, pmj)) - kMarchMagicBits) & sbfe1(rowbits, i);
                             } else if constexpr (KIND < 2) {
                                 // LES/CostVolumeEnergy.h:78-96 with per-job taps: clamped / interpolated / invalid, then min(C, th_col)
                                 // (one tap: the weight of the second is zero and the volume is finite, so f0 v0 + 0 v1 = v0)
                                 float C = v0[i];
                                 if constexpr (KIND == 1) C = f0s * v0[i] + f1s * v1[i];
                                 const float p = min_f32_finite(C, g.th_col);
-                                pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & -(int)((rowbits >> i) & 1u);
+                                pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & sbfe1(rowbits, i);
                             } else {
                                 const float p = gather_finish(g, gp[i], v0[i], v1[i]);
                                 pi = __float_as_int(fmaf(p, view.sp, view.pmagic)) - kMarchMagicBits;
@@ -488,6 +506,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             T[i][pcS] = int4{Sp, Sc[0] >> kMarchSH, Sc[1] >> kMarchSH, Sc[2] >> kMarchSH};
                             issue_row(itag);                     // the same row of block k + 1
                         });
+                        rowbits = rowbits_nx;                    // (prep(k + 1) above replaced the table; the rows of block k used the old flags)
                         LES_TICK_MARK();
                     }
                     // The prefix sums of this block of stage 1 and of block k - 2 of stage 2 (written by the role-C wave of the same
@@ -495,7 +514,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     {
                         int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
-                        const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
+                        const bool da = k < nblk, db = !kMarchT2PrefixOnD && !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
                         constexpr bool kPair = KIND != 2;
                         if (kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
@@ -522,6 +541,8 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const float kap_x = s1_col ? view.kapS * s_rtab[nx] : 0.0f;
         const float up_x = s1_col ? view.upS * s_rtab[nx] : 0.0f;
         const uint32_t sxS = (uint32_t)sx * (uint32_t)(4 * kMarchStatWords);
+        const uint32_t rowS = (uint32_t)g.W * (uint32_t)(4 * kMarchStatWords);      // bytes per image row of statistics records
+        const MarchStatDesc ds_stats = march_stats_desc(view.mstats, (uint32_t)g.H * rowS);
         MarchStatRow st[BY];
 #pragma unroll
         for (int i = 0; i < BY; i++) {
@@ -533,22 +554,21 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
 #endif
         }
         float rny[BY];                                                    // 1 / count_y of the rows of the block in flight, 0 for rows outside the clip or before the march is primed (wave-uniform: scalar registers)
-        int nx_srow = 0;
+        int nx_srow = 0;                                                  // byte offset of the (clamped) statistics row
         float nx_rny = 0.0f;
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy1 = job.ty0 - 3 * R + t;                          // centre of the vertical window that ends at p-row t
-            nx_rny = s_rtab[window_count(gy1, R, job.cy0, job.cy1)];
-            nx_srow = (int)(((uint32_t)min(max(gy1, job.cy0), cy1m) * (uint32_t)g.W) | ((gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot) ? 0x80000000u : 0u));
+            const bool on = gy1 >= job.cy0 && gy1 < job.cy1 && t >= 2 * R && t < Ttot;
+            nx_rny = on ? s_rtab[window_count(gy1, R, job.cy0, job.cy1)] : 0.0f;
+            nx_srow = (int)((uint32_t)min(max(gy1, job.cy0), cy1m) * rowS);
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {      // rolling prefetch, see role A
             constexpr int i = decltype(itag)::value;
-            const uint32_t srow = (uint32_t)readlane_i32(nx_srow, i);
-            const float r = readlane_f32(nx_rny, i);
-            rny[i] = (srow >> 31) ? r : 0.0f;
-            const float* sp = view.mstats + (size_t)(srow & 0x7fffffffu) * kMarchStatWords;          // scalar row base + the lane's column
+            rny[i] = readlane_f32(nx_rny, i);
+            const uint32_t soff = (uint32_t)readlane_i32(nx_srow, i) & 0xfffffffcu;     // (the mask makes it a scalar-written register: see march_stats_load)
             if (LES_LAB_ABLATE(1)) return;
-            march_stats_load(st[i], sp, sxS);
+            march_stats_load(st[i], ds_stats, sxS, soff);
         };
         prep(0);
         static_for<BY>([&](auto itag) { issue_row(itag); });
@@ -631,7 +651,8 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     } else if (role == 2 && LES_LAB_ROLE_ON(4)) {
         // ================================================= role D =================================================
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
-        uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;                 // byte offset of the lane's output column in a row of the output tile
+        const bool general_plane_d = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2: role C prefixes stage 2 in the two-job geometry)
+        const uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;           // byte offset of the lane's output column in a row of the output tile
         // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
         // ds +- 5a +- 5b must all lie in [MIN, MAX]  <=>  min of the five >= MIN and max <= MAX (a NaN only arises next to an
         // infinity, which fails the range test; an all-NaN set fails the comparison itself)
@@ -646,23 +667,23 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         long long S2[4] = {1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1), 1ll << (kMarchS2 - 1)};
         uint32_t gq[BY];
         float rny2[BY];                                                   // 1 / count_y of the block's output rows
-        uint32_t okbits = 0;
-        int nx_grow = 0;
+        uint32_t okbits = 0;                                              // bit i = row i of the block in flight is an output row
+        int nx_grow = 0;                                                  // byte offset of the (clamped) guide row
         float nx_rny = 0.0f;
+        const BufRsrc rs_out = make_buf(out + job.out_off, 0xfffffffcu);  // the job's output tile: row r at r * out_stride floats
+        const uint32_t ostrideB = (uint32_t)job.out_stride * 4u;
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
             const int gy2 = job.ty0 - 4 * R + t;
             nx_rny = s_rtab[window_count(gy2, R, job.cy0, job.cy1)];
-            nx_grow = (int)(((uint32_t)min(max(gy2, job.cy0), cy1m) * (uint32_t)g.W) | ((t >= 4 * R && t < Ttot) ? 0x80000000u : 0u));
+            nx_grow = (int)((uint32_t)min(max(gy2, job.cy0), cy1m) * rowB);
+            okbits = ballot_low(t >= 4 * R && t < Ttot, BY);
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;
-            const uint32_t grow = (uint32_t)readlane_i32(nx_grow, i);
             rny2[i] = readlane_f32(nx_rny, i);
-            okbits = (okbits & ~(1u << i)) | ((grow >> 31) << i);
-            const uint32_t* rg = view.ipk8 + (size_t)(grow & 0x7fffffffu);
             if (LES_LAB_ABLATE(128)) { gq[i] = (uint32_t)lane; return; }
-            gq[i] = ld_sbase(rg, sx4);
+            gq[i] = buf_load<uint32_t>(rs_guide, sx4, (uint32_t)readlane_i32(nx_grow, i));
         };
         // two specialisations (label check on / off), selected once per job -- see role A
         auto march_d = [&](auto check_tag) __attribute__((always_inline)) {
@@ -721,12 +742,13 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                         if (!(mn >= g.mind && mx <= g.maxd)) q = LES_COST_INVALID;
                                     }
                                     if (!(LES_LAB_ABLATE(128) && q != 12345.0f))
-                                    st_sbase(out + (job.out_off + (long long)(t - 4 * R) * job.out_stride), oc4, q);
+                                    buf_store<float>(rs_out, oc4, (uint32_t)(t - 4 * R) * ostrideB, q);
                                 }
                             });
                             LES_MARCH_SCHED_FENCE();
                         });
                     }
+                    if (kMarchT2PrefixOnD && !(NJ > 1 && general_plane_d) && k >= 2 && k < nblk + 2) march_prefix_tile<BY, PCOLS>(s_T2[(U + UN - 2 % UN) % UN][slot], ci0, lane);
                     if (k >= 2 && k <= nblk + 1) {                // guide rows of the block this role handles at the next tick (BY dwords per
                         prep(k - 2);                              // lane; this role is never the last to arrive at the barrier, and it has no
                         static_for<BY>([&](auto itag) { issue_row(itag); });   // registers to spare for a rolling issue)

@@ -74,6 +74,22 @@ template <int B>
 __device__ inline float cvt_f32_sbyte(uint32_t g) { return (float)(((int)(g << (24 - 8 * B))) >> 24); }
 __device__ inline float min_f32_finite(float a, float b) { return b < a ? b : a; }
 __device__ inline void acc64_add_i32(long long& acc, int d) { acc += (long long)d; }
+// raw buffer access (march kernel, round 4): base + per-lane byte offset + wave-uniform byte offset
+struct BufRsrc { const char* base; };
+__device__ inline BufRsrc make_buf(const void* p, uint32_t) { return BufRsrc{(const char*)p}; }
+template <class T>
+__device__ inline T buf_load(const BufRsrc& r, uint32_t voff, uint32_t soff) { T v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, sizeof(T)); return v; }
+template <class T>
+__device__ inline void buf_store(const BufRsrc& r, uint32_t voff, uint32_t soff, T v) { memcpy(const_cast<char*>(r.base) + (size_t)voff + (size_t)soff, &v, sizeof(T)); }
+// bit i = flag of lane i, for the first n lanes of the wave (every lane of the wave must call it)
+__device__ inline uint32_t ballot_low(bool f, int n)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < n; i++) m |= (uint32_t)(hipsim::wave_readlane(f ? 1 : 0, i) & 1) << i;
+    return m;
+}
+// sign-extended bit `bit` of a wave-uniform word: all ones or zero
+__device__ inline int sbfe1(uint32_t w, int bit) { return -(int)((w >> bit) & 1u); }
 
 #else
 
@@ -191,6 +207,30 @@ __device__ __forceinline__ void acc64_add_i32(long long& acc, int d)
 {
     asm("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(d) : "vcc");
 }
+// Raw buffer access (march kernel, round 4): address = descriptor base + per-lane byte offset (VGPR) + wave-uniform byte offset (SGPR),
+// i.e. a row of an image costs NO scalar address arithmetic (the global_load `saddr` form needs a 64-bit scalar add per row and
+// access); out-of-range offsets read 0.  num_records is in bytes (stride 0).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_buf(const void* p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00027000);
+}
+template <class T>
+__device__ __forceinline__ T buf_load(BufRsrc r, uint32_t voff, uint32_t soff)
+{
+    static_assert(sizeof(T) == 4, "dword access");
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+template <class T>
+__device__ __forceinline__ void buf_store(BufRsrc r, uint32_t voff, uint32_t soff, T v)
+{
+    static_assert(sizeof(T) == 4, "dword access");
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+// bit i = flag of lane i (one v_cmp into a scalar pair; the row flags of a block are then tested with scalar bit operations)
+__device__ __forceinline__ uint32_t ballot_low(bool f, int) { return (uint32_t)__builtin_amdgcn_ballot_w64(f); }
+// sign-extended bit `bit` of a wave-uniform word: all ones or zero (s_bfe_i32)
+__device__ __forceinline__ int sbfe1(uint32_t w, int bit) { return __builtin_amdgcn_sbfe((int)w, (unsigned)bit, 1u); }
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }    // folds to v_min3_f32
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
