@@ -110,7 +110,11 @@ struct MarchEntry { int R; int TW; int NJ; int NT; int BY; MarchKernel fn; };
 // other radii run the strip kernel (R = 12 would need a 100-register ring in role D, R = 5 a block height of 11).
 const MarchEntry kMarch[] = {
     LES_MARCH_ENTRY(10, 256, 1, 7),
+#if defined(LES_MARCH_LAB) && defined(LES_MARCH_NARROW_NJ1)
+    LES_MARCH_ENTRY(10, 128, 1, 7),          // experiment: one narrow job per workgroup, two workgroups per CU (independent tick barriers)
+#else
     LES_MARCH_ENTRY(10, 128, 2, 7),
+#endif
     LES_MARCH_ENTRY(7, 256, 1, 5),
     LES_MARCH_ENTRY(7, 128, 2, 5),
 };

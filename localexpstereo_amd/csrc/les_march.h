@@ -75,11 +75,6 @@ __host__ __device__ constexpr int march_pb(int R) { return (2 * R + 1) * (2 * R 
 #define LES_MARCH_STAT_WORDS 9
 #endif
 constexpr int kMarchStatWords = LES_MARCH_STAT_WORDS;
-// which role prefixes the stage-2 tiles in the one-job geometry: 0 = role A (after its own stage-1 tile), 2 = role D (after its rows)
-#ifndef LES_MARCH_T2_PREFIX_ROLE
-#define LES_MARCH_T2_PREFIX_ROLE 0
-#endif
-constexpr bool kMarchT2PrefixOnD = LES_MARCH_T2_PREFIX_ROLE == 2;
 static_assert(kMarchStatWords == 9 || kMarchStatWords == 12, "statistics record of 36 or 48 bytes");
 
 struct MarchView {
@@ -313,6 +308,27 @@ __device__ __forceinline__ bool march_label_surely_valid(const Geom& g, float4 p
     return (0.0f * pl.w == 0.0f) && mag < 1e30f && (lo - margin >= g.mind) && (hi + margin <= g.maxd);
 }
 
+// A general plane is TAME for a job when its disparity d = a x + (b y + c) stays inside [max(MIN, 0), MAX) at every pixel the job
+// gathers (its clip rectangle cut to the columns and rows of the march), by a margin far above the rounding of the float expression:
+// every pixel then interpolates two slices (LES/CostVolumeEnergy.h:83-92) -- no clamped, invalid or NaN case -- and the slices it
+// touches span less than 2^30 bytes from the lowest one.  Role A then runs the short gather (KIND 4); `slice_lo` receives the lowest
+// slice the job can touch.  Everything else takes the general per-pixel path (KIND 2).
+__device__ __forceinline__ bool march_plane_tame(const Geom& g, float4 pl, const Job& job, int R, int* slice_lo)
+{
+    const int x0 = max(job.tx0 - 2 * R, job.cx0), x1 = min(job.tx0 + job.tw + 2 * R, job.cx1) - 1;
+    const int y0 = max(job.ty0 - 2 * R, job.cy0), y1 = min(job.ty0 + job.th + 2 * R, job.cy1) - 1;
+    const float ax0 = pl.x * (float)x0, ax1 = pl.x * (float)x1, by0 = pl.y * (float)y0, by1 = pl.y * (float)y1;
+    const float lo = (fminf(ax0, ax1) + fminf(by0, by1)) + pl.z, hi = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + pl.z;
+    const float mag = fmaxf(fabsf(ax0), fabsf(ax1)) + fmaxf(fabsf(by0), fabsf(by1)) + fabsf(pl.z);
+    const float margin = 1e-5f * mag + 1e-30f;
+    const bool inside = mag < 1e30f && (lo - margin >= fmaxf(g.mind, 0.0f)) && (hi + margin < g.maxd) && x1 >= x0 && y1 >= y0;
+    if (!inside) { *slice_lo = 0; return false; }
+    const int s0 = (int)floorf(lo - margin) + g.D0, s1 = (int)floorf(hi + margin) + g.D0 + 1;      // lowest / highest slice touched
+    *slice_lo = s0;
+    const unsigned long long HW = (unsigned long long)g.H * (unsigned long long)g.W;
+    return s0 >= 0 && s1 < g.D && HW < (1ull << 24) && (unsigned long long)(s1 - s0 + 1) * HW < (1ull << 28);
+}
+
 template <int R, int WGC, int NJ, int BY>
 __global__ void __launch_bounds__(3 * WGC * NJ)
 les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const float4* __restrict__ planes,
@@ -400,7 +416,9 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const float f0s = 1.0f - f1s;
         // fronto-parallel plane with an invalid label (LES/CostVolumeEnergy.h:80-88: C = 1e6 at every pixel, so p = th_col): the
         // count is a per-job constant -- multiply the loaded cost by 0 and put the count of th_col into the addend
-        const bool inv_job = modes == 2 && !view.raw_off;
+        const bool inv_job = fronto && modes == 2 && !view.raw_off;
+        int slice_lo = 0;
+        const bool tame = !fronto && !view.raw_off && march_plane_tame(g, plane, job, R, &slice_lo);
         // Columns outside the clip contribute count 0: their factor is 0 and their addend the bare 1.5 * 2^23 (per-lane constants, so
         // the column half of the clip test costs nothing per row; the row half is one v_and with a scalar mask)
         const float spj = !col_in ? 0.0f : (inv_job ? 0.0f : view.sp);
@@ -411,12 +429,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         //   KIND 1  fronto-parallel plane, two taps
         //   KIND 2  general plane: taps / weight / mode per lane and row
         //   KIND 3  image-based energy: one tap into the call's raw-cost patch (any plane; no truncation, no invalid mode)
+        //   KIND 4  general plane that is tame over the job (march_plane_tame): two interpolated taps per pixel, no special cases
         // For fronto-parallel planes everything but the clip test is per-job, the row bases are scalars and the loads need no
         // address arithmetic.
         auto march_a = [&](auto kind_tag) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_tag)::value;
         GatherPrep gp[BY];
         float v0[BY], v1[BY];
+        float f1r[BY];                   // KIND 4: interpolation weight of the second tap
         uint32_t gw[BY];
         uint32_t rowbits = 0, rowbits_nx = 0;   // bit i = p-row i of the block (in flight / being loaded) is inside the clip and the march
         // Row scalars of block b: lane i < BY computes those of p-row b*BY + i, v_readlane hands them to the wave as scalars.
@@ -430,7 +450,12 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // descriptors: the volume slice(s) of a fronto-parallel plane / the call's raw-cost patch (its column 0 = image column cx0)
         const float* v0base = view.vol + (size_t)i0s;
         if constexpr (KIND == 3) v0base = view.vol + view.raw_off[job.plane_idx] - job.cx0;
-        const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : imgB);
+        if constexpr (KIND == 4) v0base = view.vol + (size_t)slice_lo * (size_t)HWu;          // the lowest slice the job touches: every tap lies within 2^30 bytes of it
+        // (KIND 4: masked rows beyond the march compute addresses from a disparity outside the tame range -- the descriptor must end where
+        //  the volume ends, so that whatever passes its range check is inside the allocation)
+        const unsigned long long rest4 = (unsigned long long)(g.D - slice_lo) * (unsigned long long)imgB;
+        const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : (KIND == 4 ? (uint32_t)(rest4 < 0xfffffffcull ? rest4 : 0xfffffffcull) : imgB));
+        const int dsub = g.D0 - slice_lo;                                 // KIND 4: slice index relative to the descriptor base
         const BufRsrc rs_v1 = make_buf(view.vol + (size_t)i1s, imgB);
         auto prep = [&](int b) __attribute__((always_inline)) {
             const int t = b * BY + lane;
@@ -450,6 +475,16 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             } else if constexpr (KIND < 2) {
                 v0[i] = buf_load<float>(rs_v0, sx4, ro);
                 if constexpr (KIND == 1) v1[i] = buf_load<float>(rs_v1, sx4, ro);
+            } else if constexpr (KIND == 4) {
+                // LES/CostVolumeEnergy.h:73-92 on the interpolating branch: d0 = int(d) (= floor: d >= 0), f1 = d - floor(d), taps d0 and d0 + 1.
+                // Lanes / rows outside the clip compute on the clamped pixel (inside the tame rectangle) or on rows beyond the march (any
+                // address: the descriptor's range check returns 0) and are masked when the row is consumed.
+                const float d = g_ax + readlane_f32(nx_dbase, i);
+                const float df = floorf(d);
+                f1r[i] = d - df;
+                const uint32_t e = mad_u24((int)df + dsub, (int)HWu, sx);
+                v0[i] = buf_load<float>(rs_v0, e << 2, ro);
+                v1[i] = buf_load<float>(rs_v0, e << 2, ro + imgB);
             } else {
                 const float d_base = readlane_f32(nx_dbase, i);
                 const bool inside = col_in && ((rowbits_nx >> i) & 1u);
@@ -489,6 +524,11 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                 if constexpr (KIND == 1) C = f0s * v0[i] + f1s * v1[i];
                                 const float p = min_f32_finite(C, g.th_col);
                                 pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & sbfe1(rowbits, i);
+                            } else if constexpr (KIND == 4) {
+                                const float f0 = 1.0f - f1r[i];
+                                const float C = f0 * v0[i] + f1r[i] * v1[i];
+                                const float p = min_f32_finite(C, g.th_col);
+                                pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & sbfe1(rowbits, i);
                             } else {
                                 const float p = gather_finish(g, gp[i], v0[i], v1[i]);
                                 pi = __float_as_int(fmaf(p, view.sp, view.pmagic)) - kMarchMagicBits;
@@ -514,7 +554,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                     {
                         int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
-                        const bool da = k < nblk, db = !kMarchT2PrefixOnD && !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
+                        const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
                         constexpr bool kPair = KIND != 2;
                         if (kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
@@ -531,11 +571,13 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         if (view.raw_off) march_a(std::integral_constant<int, 3>{});
         else if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
         else if (fronto) march_a(std::integral_constant<int, 1>{});
+        else if (tame) march_a(std::integral_constant<int, 4>{});
         else march_a(std::integral_constant<int, 2>{});
     } else if (role == 1 && LES_LAB_ROLE_ON(2)) {
         // ================================================= role C =================================================
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
-        const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2)
+        int slice_lo_unused = 0;
+        const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f) && !march_plane_tame(g, plane, job, R, &slice_lo_unused);  // (role A's KIND 2)
         // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
         // normalisation factors, the row part into the row's 1/count_y (0 * finite = 0, and v_cvt_rpi(+-0) = 0)
         const float kap_x = s1_col ? view.kapS * s_rtab[nx] : 0.0f;
@@ -651,7 +693,6 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     } else if (role == 2 && LES_LAB_ROLE_ON(4)) {
         // ================================================= role D =================================================
         const bool out_col = ci >= 2 * R && ci < 2 * R + job.tw && job.th > 0;
-        const bool general_plane_d = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f);  // (role A's KIND 2: role C prefixes stage 2 in the two-job geometry)
         const uint32_t oc4 = (uint32_t)max(ci - 2 * R, 0) * 4u;           // byte offset of the lane's output column in a row of the output tile
         // IsValiLabel (LES/StereoEnergy.h:560-610) without branches: ds = ((x a + y b) + 1 c) + 0 v and the four corner values
         // ds +- 5a +- 5b must all lie in [MIN, MAX]  <=>  min of the five >= MIN and max <= MAX (a NaN only arises next to an
@@ -748,7 +789,6 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             LES_MARCH_SCHED_FENCE();
                         });
                     }
-                    if (kMarchT2PrefixOnD && !(NJ > 1 && general_plane_d) && k >= 2 && k < nblk + 2) march_prefix_tile<BY, PCOLS>(s_T2[(U + UN - 2 % UN) % UN][slot], ci0, lane);
                     if (k >= 2 && k <= nblk + 1) {                // guide rows of the block this role handles at the next tick (BY dwords per
                         prep(k - 2);                              // lane; this role is never the last to arrive at the barrier, and it has no
                         static_for<BY>([&](auto itag) { issue_row(itag); });   // registers to spare for a rolling issue)

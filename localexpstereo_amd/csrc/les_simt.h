@@ -75,10 +75,18 @@ __device__ inline float cvt_f32_sbyte(uint32_t g) { return (float)(((int)(g << (
 __device__ inline float min_f32_finite(float a, float b) { return b < a ? b : a; }
 __device__ inline void acc64_add_i32(long long& acc, int d) { acc += (long long)d; }
 // raw buffer access (march kernel, round 4): base + per-lane byte offset + wave-uniform byte offset
-struct BufRsrc { const char* base; };
-__device__ inline BufRsrc make_buf(const void* p, uint32_t) { return BufRsrc{(const char*)p}; }
+struct BufRsrc { const char* base; uint32_t bytes; };
+__device__ inline BufRsrc make_buf(const void* p, uint32_t bytes) { return BufRsrc{(const char*)p, bytes}; }
 template <class T>
-__device__ inline T buf_load(const BufRsrc& r, uint32_t voff, uint32_t soff) { T v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, sizeof(T)); return v; }
+__device__ inline T buf_load(const BufRsrc& r, uint32_t voff, uint32_t soff)
+{
+    T v = T(0);                                                     // the descriptor's range check: out-of-range offsets read 0
+    const unsigned long long o = (unsigned long long)voff + (unsigned long long)soff;
+    if (o + sizeof(T) <= r.bytes) memcpy(&v, r.base + o, sizeof(T));
+    return v;
+}
+// low 24 bits of a times low 24 bits of b, plus c (v_mad_u32_u24)
+__device__ inline uint32_t mad_u24(int a, int b, int c) { return ((uint32_t)a & 0xffffffu) * ((uint32_t)b & 0xffffffu) + (uint32_t)c; }
 template <class T>
 __device__ inline void buf_store(const BufRsrc& r, uint32_t voff, uint32_t soff, T v) { memcpy(const_cast<char*>(r.base) + (size_t)voff + (size_t)soff, &v, sizeof(T)); }
 // bit i = flag of lane i, for the first n lanes of the wave (every lane of the wave must call it)
@@ -227,6 +235,7 @@ __device__ __forceinline__ void buf_store(BufRsrc r, uint32_t voff, uint32_t sof
     static_assert(sizeof(T) == 4, "dword access");
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ uint32_t mad_u24(int a, int b, int c) { return (uint32_t)__umul24((unsigned)a, (unsigned)b) + (uint32_t)c; }    // folds to v_mad_u32_u24
 // bit i = flag of lane i (one v_cmp into a scalar pair; the row flags of a block are then tested with scalar bit operations)
 __device__ __forceinline__ uint32_t ballot_low(bool f, int) { return (uint32_t)__builtin_amdgcn_ballot_w64(f); }
 // sign-extended bit `bit` of a wave-uniform word: all ones or zero (s_bfe_i32)
