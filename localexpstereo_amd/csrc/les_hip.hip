@@ -41,6 +41,23 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// One line on stderr, once per context and reason, when work that the march kernel could have served goes to the 2.2x slower strip
+// kernel (a perf cliff nobody would otherwise see; les_hip_batch_kernel_kind reports the same fact per batch).  LES_HIP_QUIET=1 silences it.
+enum FallbackReason { FB_RADIUS = 0, FB_NONFINITE, FB_RANGE, FB_THRESHOLD, FB_IMAGE_SIZE, FB_GEOMETRY, FB_PATCHES, FB_COUNT };
+void note_fallback(unsigned& seen, FallbackReason r, const char* fmt, ...)
+{
+    if (seen & (1u << r)) return;
+    seen |= 1u << r;
+    static const bool quiet = [] { const char* e = getenv("LES_HIP_QUIET"); return e && atoi(e) != 0; }();
+    if (quiet) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "localexp_hip: strip kernel instead of the march kernel: %s (LES_HIP_QUIET=1 silences this note)\n", buf);
+}
+
 #define HIPCHECK(expr)                                                                               \
     do {                                                                                             \
         hipError_t e_ = (expr);                                                                      \
@@ -103,11 +120,13 @@ typedef void (*MarchKernel)(les::Geom, les::MarchView, const les::Job*, const fl
 struct MarchEntry { int R; int TW; int NJ; int NT; int BY; MarchKernel fn; };
 #define LES_MARCH_ENTRY(R_, WGC_, NJ_, BY_) \
     { R_, les::MarchCfg<R_, WGC_, NJ_, BY_>::TW, NJ_, les::MarchCfg<R_, WGC_, NJ_, BY_>::NT, BY_, les::les_march_kernel<R_, WGC_, NJ_, BY_> }
-// two geometries per radius: wide jobs (216 output columns: whole-image hypothesis slabs, layer-1/2 cells) and two narrow jobs
-// per workgroup (88 output columns each: layer-0 cells); both run 12 waves per workgroup
-// Radii: 10 (windR 20 / 21, the reference's default in both of its modes) and 7 (windR 14 / 15).  The pipeline needs 2R + 1 = 3 x BY rows per
-// ring (three ticks per unrolled loop iteration, three stage-2 buffers) with BY <= 8 rows per prefix pass, which 2R + 1 = 21 and 15 meet;
-// other radii run the strip kernel (R = 12 would need a 100-register ring in role D, R = 5 a block height of 11).
+// two geometries per radius: wide jobs (WGC - 4R output columns: whole-image hypothesis slabs, layer-1/2 cells) and two narrow jobs
+// per workgroup (128 - 4R output columns each: layer-0 cells); both run 12 waves per workgroup.
+// Radii 4 .. 10 (windR 8 .. 21; the reference's option -filterRadious, LES/main.cpp:48,285,349; its default 20 -> radius 10).  The rings
+// hold RS = 3 x BY >= 2R + 1 rows (three ticks per unrolled loop iteration, three stage-2 buffers; the row that leaves a window is read
+// from slot (s + RS - (2R + 1)) mod RS), with BY <= 8 rows per prefix pass: the smallest such block height per radius.  Radius 11 would
+// need BY = 8 and 176 KB of LDS, radius 12 and beyond more than 24 ring rows: they, and the radii below 4 (windows of at most 7 x 7, not worth
+// two more instantiations each), stay on the strip kernel.
 const MarchEntry kMarch[] = {
     LES_MARCH_ENTRY(10, 256, 1, 7),
 #if defined(LES_MARCH_LAB) && defined(LES_MARCH_NARROW_NJ1)
@@ -117,6 +136,13 @@ const MarchEntry kMarch[] = {
 #endif
     LES_MARCH_ENTRY(7, 256, 1, 5),
     LES_MARCH_ENTRY(7, 128, 2, 5),
+#if !defined(LES_MARCH_FEW_RADII)
+    LES_MARCH_ENTRY(4, 256, 1, 3),  LES_MARCH_ENTRY(4, 128, 2, 3),
+    LES_MARCH_ENTRY(5, 256, 1, 4),  LES_MARCH_ENTRY(5, 128, 2, 4),
+    LES_MARCH_ENTRY(6, 256, 1, 5),  LES_MARCH_ENTRY(6, 128, 2, 5),
+    LES_MARCH_ENTRY(8, 256, 1, 6),  LES_MARCH_ENTRY(8, 128, 2, 6),
+    LES_MARCH_ENTRY(9, 256, 1, 7),  LES_MARCH_ENTRY(9, 128, 2, 7),
+#endif
 };
 // wide != 0: the entry with the widest jobs, else the one with the narrowest
 const MarchEntry* find_march(int R, int wide = 1)
@@ -153,6 +179,7 @@ struct les_hip_ctx {
     const StripEntry* strip;
     const MarchEntry* march = nullptr;   // null: radius not instantiated (or LES_HIP_KERNEL=strip)
     int ncu = 256;                       // compute units of the device (job cutting of the march kernel)
+    unsigned fallback_seen = 0;          // reasons already reported by note_fallback
     hipStream_t stream;
     les::Geom geom;
     ViewData v[2];
@@ -301,7 +328,7 @@ int build_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_h
 
 // The same calls cut for the march kernel: balanced strips of at most TW columns (a 45-column target becomes 23 + 22, never
 // 44 + 1), groups of NJ consecutive jobs per workgroup (padded with empty jobs), and the geometric precondition of the kernel.
-bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs,
+bool build_march_jobs(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs,
                       std::vector<les::Job>& jobs, bool& ok, const MarchEntry*& entry)
 {
     jobs.clear();
@@ -317,7 +344,10 @@ bool build_march_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, cons
         if ((f.x > 0 && t.x - f.x < 2 * R) || (f.x + f.w < W && (f.x + f.w) - (t.x + t.w) < 2 * R) ||
             (f.y > 0 && t.y - f.y < 2 * R) || (f.y + f.h < H && (f.y + f.h) - (t.y + t.h) < 2 * R)) ok = false;
     }
-    if (!ok) return true;
+    if (!ok) {
+        note_fallback(c->fallback_seen, FB_GEOMETRY, "a target rectangle lies closer than 2 x radius = %d pixels to a filterRect border that is not an image border", 2 * R);
+        return true;
+    }
     // Cut: geometry (wide jobs, one per workgroup / narrow jobs, two per workgroup) and rows per job.  A workgroup fills a CU
     // (12 waves, 130 KB LDS) and runs one 7-row block per ~3.4 us tick with a 2-tick pipeline fill and 4R halo rows per job, so
     // the launch time is about rounds(workgroups / CUs) x ticks(rows per job): pick the cut that minimises it.  (Layer-1/2 sets
@@ -445,10 +475,13 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     const int W = c->p.W, H = c->p.H;
     v.march_ok = false;
     // the kernel addresses image rows and statistics rows by 32-bit byte offsets (raw buffer access): images of 2^26 pixels or more stay on the strip kernel
-    if ((unsigned long long)P * (4ull * les::kMarchStatWords) >= (1ull << 31)) return LES_HIP_OK;
+    if ((unsigned long long)P * (4ull * les::kMarchStatWords) >= (1ull << 31)) {
+        note_fallback(c->fallback_seen, FB_IMAGE_SIZE, "image of %d x %d pixels (32-bit row offsets reach 2^26 pixels)", W, H);
+        return LES_HIP_OK;
+    }
     // image-based energy: the raw cost min(|dcolor|, th_color) + min(|dgrad|, th_grad) lies in [0, th_color + th_grad] by construction
     const float th = c->naive ? c->th_color + c->th_grad : c->p.th_col;
-    if (!(th > 0.0f) || !(th < INFINITY)) return LES_HIP_OK;
+    if (!(th > 0.0f) || !(th < INFINITY)) { note_fallback(c->fallback_seen, FB_THRESHOLD, "truncation threshold %g is not positive and finite", (double)th); return LES_HIP_OK; }
     // cost range
     const int nb = 2048;
     std::vector<float> hmin(nb, 0.0f); std::vector<int> hbad(nb, 0);
@@ -466,10 +499,16 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     }
     float vmin = INFINITY; int bad = 0;
     for (int i = 0; i < nb; i++) { vmin = std::min(vmin, hmin[i]); bad |= hbad[i]; }
-    if (bad || !(vmin < INFINITY)) return LES_HIP_OK;              // NaN / inf costs: the fp64 strip kernel reproduces the reference's propagation
+    if (bad || !(vmin < INFINITY)) {                               // NaN / inf costs: the fp64 strip kernel reproduces the reference's propagation
+        note_fallback(c->fallback_seen, FB_NONFINITE, "the cost volume of view %d holds NaN or infinite entries", m);
+        return LES_HIP_OK;
+    }
     vmin = std::min(vmin, 0.5f * th);                                // a volume entirely above th_col: p == th_col everywhere
     const double range = (double)th - (double)vmin;
-    if (!(range <= 8.0 * (double)th)) return LES_HIP_OK;            // the 22-bit fixed point would resolve th_col too coarsely
+    if (!(range <= 8.0 * (double)th)) {                              // the 20-bit fixed point would resolve th_col too coarsely
+        note_fallback(c->fallback_seen, FB_RANGE, "view %d: costs reach %g below the truncation threshold %g (more than 8 x the threshold)", m, range, (double)th);
+        return LES_HIP_OK;
+    }
     // tables
     unsigned dbits = 0;
     {
@@ -599,6 +638,8 @@ static int create_common(les_hip_ctx** out, const les_hip_params* params, const 
     c->R = p.windR / 2;
     c->strip = strip;
     c->march = find_march(p.windR / 2);
+    if (!c->march && !(getenv("LES_HIP_KERNEL") && !strcmp(getenv("LES_HIP_KERNEL"), "strip")))
+        note_fallback(c->fallback_seen, FB_RADIUS, "no march kernel for guided-filter radius %d (windR %d; instantiated: 4 .. 10)", p.windR / 2, p.windR);
 #if !defined(LES_SIM)
     {
         int v = 0;
@@ -751,7 +792,10 @@ int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const l
                 offs[i] = tot;
                 tot += a; amax = std::max(amax, a);
             }
-            if (tot > kRawPatchCapFloats) b->march_ok = false;
+            if (tot > kRawPatchCapFloats) {
+                b->march_ok = false;
+                note_fallback(c->fallback_seen, FB_PATCHES, "the raw-cost patches of one batch of the image-based energy exceed 4 GB");
+            }
             else {
                 b->raw_floats = tot;
                 b->raw_chunks = (int)std::min<long long>(1024, std::max<long long>(1, (amax + 4095) / 4096));

@@ -22,7 +22,7 @@
 //        v_mul_i32_i24 with the guide byte as an SDWA operand, v_add3_u32; int32, exact)
 //        -> LDS T1[row][col] = {Sp, (Sc + 2^4) >> 5}                 (the only rounding of stage 1: 2^-26 of full scale)
 //   B1 (lane = (row, 8-column segment)) in-place prefix sums along x, modulo 2^32 (the 2R+1-column differences are exact)
-//   C  (lane = column)  box sums s, t_c = P(x+R) - P(x-R-1);  N cov_c = t_c - hi32(M_c * 8 s)  (M_c = mean_c in 2^-24 u8 units:
+//   C  (lane = column)  box sums s, t_c = P(x+R) - P(x-R-1);  N cov_c = t_c + hi32(M_c * 8 s)  (M_c = MINUS mean_c in 2^-24 u8 units:
 //        one v_mad_i64_i32, the cancellation is exact);  a = inv * cov,  b = mean_p - a . mean   in fp32 (as les_strip_kernel);
 //        a, b -> int32 with a scale derived from a rigorous bound on |a|, |b|  -> LDS T2
 //   B2 prefix sums of T2
@@ -82,7 +82,7 @@ struct MarchView {
     const uint32_t* ipk8;         // [H*W] guide pixel as three signed bytes u8 - 128 (byte 3 = 0)
     const float* mstats;          // [H*W][kMarchStatWords]: {inv00, inv01, inv02, inv11} {inv12, inv22, M0, M1} {M2 [, mu0, mu1, mu2]}
                                   //   inv = (Sigma + eps U)^-1 of the guide in [0,1] units (LES/GuidedFilter.h:87-101),
-                                  //   M_c = rint((255 mean_I_c - 128) 2^MB) (int32 bits), mu_c = mean_I_c - 128/255 = M_c 2^-MB / 255
+                                  //   M_c = -rint((255 mean_I_c - 128) 2^MB) (int32 bits: MINUS the centred mean), mu_c = mean_I_c - 128/255 = -M_c 2^-MB / 255
     float sp;                     // counts per cost unit: (2^PB - 1) / (th_col - vmin)
     float pmagic;                 // 1.5 * 2^23 + c0,  c0 = rint(-vmin sp) - 2^(PB-1)  (an integer: exact in fp32)
     float poff;                   // the cost that count 0 stands for: -c0 / sp
@@ -651,14 +651,15 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         constexpr int j = decltype(jtag)::value;
                         constexpr int i = LO + j;
                         const int s = pp[CB][j].x - pm[CB][j].x + px[CB][j].x;                         // sum of pi over the window (exact)
-                        const int t0c = pp[CB][j].y - pm[CB][j].y + px[CB][j].y, t1c = pp[CB][j].z - pm[CB][j].z + px[CB][j].z, t2c = pp[CB][j].w - pm[CB][j].w + px[CB][j].w;
                         const mstat4 q0 = st[i].a, q1 = st[i].b;
+                        // the record holds MINUS M_c, so that N cov_c = t_c - mean_c s is a three-operand add of the prefix difference, the
+                        // neighbour tile's total and the high word of (-M_c)(8 s) + 2^31 (the product rounded at 2^-32 of its own scale);
+                        // units: 2^SH (u8 * count)
                         const int M0 = __float_as_int(q1.z), M1 = __float_as_int(q1.w), M2 = march_stat_m2(st[i]);
-                        // N cov_c in units of 2^SH (u8 * count): t_c - mean_c * s, the product rounded at 2^-32 of its own scale
                         const long long s8 = (long long)(s << kMarchSL);
-                        const float d0 = (float)(t0c - (int)(((long long)M0 * s8 + (1ll << 31)) >> 32));
-                        const float d1 = (float)(t1c - (int)(((long long)M1 * s8 + (1ll << 31)) >> 32));
-                        const float d2 = (float)(t2c - (int)(((long long)M2 * s8 + (1ll << 31)) >> 32));
+                        const float d0 = (float)((pp[CB][j].y - pm[CB][j].y) + px[CB][j].y + (int)(((long long)M0 * s8 + (1ll << 31)) >> 32));
+                        const float d1 = (float)((pp[CB][j].z - pm[CB][j].z) + px[CB][j].z + (int)(((long long)M1 * s8 + (1ll << 31)) >> 32));
+                        const float d2 = (float)((pp[CB][j].w - pm[CB][j].w) + px[CB][j].w + (int)(((long long)M2 * s8 + (1ll << 31)) >> 32));
                         // LES/GuidedFilter.h:204-221 with the scale of the integer stage 2 folded into the normalisation
                         const float ka = kap_x * rny[i];
                         const float a0 = fmaf(q0.z, d2, fmaf(q0.y, d1, q0.x * d0)) * ka;     // inv00 inv01 inv02
@@ -667,7 +668,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         const float mp = (float)s * (up_x * rny[i]);
 #if LES_MARCH_STAT_WORDS == 9
                         // b = mean_p - a . mu with mu_c = M_c 2^-MB / 255 (the float of M_c carries the mean to 2^-24 relative, as a stored float would)
-                        const float bb = fmaf(-view.kmu, fmaf(a2, (float)M2, fmaf(a1, (float)M1, a0 * (float)M0)), mp);
+                        const float bb = fmaf(view.kmu, fmaf(a2, (float)M2, fmaf(a1, (float)M1, a0 * (float)M0)), mp);      // (-a . mu: the sign sits in M)
 #else
                         const float bb = fmaf(-a2, st[i].c.w, fmaf(-a1, st[i].c.z, fmaf(-a0, st[i].c.y, mp)));
 #endif
@@ -838,9 +839,10 @@ __global__ void les_march_stats_kernel(const double* __restrict__ hs, const uint
     // mean of exactly 255)
     const double fs = (double)(1ll << kMarchMB);
     const double c0 = m0 * 255.0 - 128.0, c1 = m1 * 255.0 - 128.0, c2 = m2 * 255.0 - 128.0;
-    const int M0 = (int)fmin(fmax(rint(c0 * fs), -2147483648.0), 2147483647.0);
-    const int M1 = (int)fmin(fmax(rint(c1 * fs), -2147483648.0), 2147483647.0);
-    const int M2 = (int)fmin(fmax(rint(c2 * fs), -2147483648.0), 2147483647.0);
+    // stored NEGATED (role C adds -mean_c s): -c in [-127, 128], and +128 * 2^24 = 2^31 is clamped to 2^31 - 1 (an error of 2^-24 u8 on a black window)
+    const int M0 = (int)fmin(fmax(rint(-c0 * fs), -2147483648.0), 2147483647.0);
+    const int M1 = (int)fmin(fmax(rint(-c1 * fs), -2147483648.0), 2147483647.0);
+    const int M2 = (int)fmin(fmax(rint(-c2 * fs), -2147483648.0), 2147483647.0);
     float* o = mstats + px * kMarchStatWords;
     o[0] = (float)irr; o[1] = (float)irg; o[2] = (float)irb; o[3] = (float)igg;
     o[4] = (float)igb; o[5] = (float)ibb; o[6] = __int_as_float(M0); o[7] = __int_as_float(M1);

@@ -94,7 +94,7 @@ def test_gpu_other_radii(oracle_mod):
         try:
             layer = pc.om.Layer(pr.W, pr.H, windR, 11)
             b = pc.api.Batch(pr.e, layer.filter[layer.sets[0]], layer.shared[layer.sets[0]])
-            assert b.kernel_kind(0) == (1 if windR // 2 in (7, 10) else 0), windR       # radii 7 and 10 are served by the march kernel
+            assert b.kernel_kind(0) == (1 if 4 <= windR // 2 <= 10 else 0), windR       # radii 4 .. 10 are served by the march kernel
             b.destroy()
             for s in (0, 6):
                 cells = layer.sets[s]

@@ -121,8 +121,8 @@ def emulate(S, fr, p, variant="r4", PB=None, SH=5, S2=4):
         t = [box(x, R, 1) for x in tV]
         assert np.abs(s << 3).max() < 2 ** 31 and max(np.abs(x).max() for x in t) < 2 ** 31
         MBITS = 32 - SH - 3
-        M = np.clip(np.rint(mu_u8 * 2.0 ** MBITS), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
-        d = [(t[c] - ((M[c] * (s << 3) + (1 << 31)) >> 32)).astype(f32) for c in range(3)]
+        M = np.clip(np.rint(-mu_u8 * 2.0 ** MBITS), -2 ** 31, 2 ** 31 - 1).astype(np.int64)      # the record holds MINUS the centred mean
+        d = [(t[c] + ((M[c] * (s << 3) + (1 << 31)) >> 32)).astype(f32) for c in range(3)]
         Mf = M.astype(f32)
         kmu = f32(1.0 / (2.0 ** MBITS * 255.0))
     kapS, upS = f32((1 << SH) * up / 255.0 * scale), f32(up * scale)
@@ -142,7 +142,7 @@ def emulate(S, fr, p, variant="r4", PB=None, SH=5, S2=4):
         tmu = (a[0] * Mf[0]).astype(f32)
         tmu = fma32(a[1], Mf[1], tmu)
         tmu = fma32(a[2], Mf[2], tmu)
-        b = fma32(-kmu * np.ones_like(tmu), tmu, mp)
+        b = fma32(kmu * np.ones_like(tmu), tmu, mp)
     q4 = [np.floor(x.astype(np.float64) + 0.5).astype(np.int64) for x in (a[0], a[1], a[2], b)]       # v_cvt_rpi_i32_f32
     hq = [box(x, R, 1) for x in q4]
     assert max(np.abs(x).max() for x in hq) < 2 ** 30, "stage-2 overflow"
