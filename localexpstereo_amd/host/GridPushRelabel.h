@@ -137,7 +137,7 @@ private:
                 for (int k = 0; k < 8 && e > 0; k++) {
                     if (!(r[k] > 0)) continue;
                     const int u = v + off_[k];
-                    if (dv != d_[u] + 1 || !allowed(band, u)) continue;
+                    if (!allowed(band, u) || dv != d_[u] + 1) continue;      // (band test first: another band's heights are being written by its thread)
                     const float f = e < r[k] ? e : r[k];
                     r[k] -= f; rc_[(size_t)u * 8 + (k ^ 1)] += f; e -= f;
                     const float eu = ex_[u];

@@ -106,6 +106,7 @@ class PMRunner:
                 fr = np.stack([x0, y0, x1 - x0, y1 - y0], 1).astype(np.int32).view(api.RECT_DT).reshape(-1)
                 self.init = _Shard(self, units, shared, fr, np.arange(len(units)), seeds_for(len(units), seed + 777), target_is_unit=True)
         self.bytes_exchanged = 0
+        self.exchanges = 0                       # all-gathers issued
 
     # -- exchange: one all-gather of the updated tiles of a set (labels 16 B/px + cost 4 B/px).  Pack and unpack are kernels of the
     # library on the runner's stream; with the nccl backend the collective is enqueued on the same stream by torch, so nothing here
@@ -127,6 +128,7 @@ class PMRunner:
             self._sync()
         dist.all_gather_into_tensor(recv, send, group=self.group)
         self.bytes_exchanged += recv.numel() * 4
+        self.exchanges += 1
         x.unpack(recv.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr())
 
     def _sync(self):

@@ -39,6 +39,19 @@ class FastGCStereo:
             self._swap_view_threads = v == "concurrent-swapped"
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
         self.device_cuts = None                  # None: cut the cells that fit a workgroup's LDS on the GPU when there is one (pm.PMRunner.begin_gc)
+        self._view_groups = None                 # two-view runs on several ranks: one process group per view, created once, destroyed by close()
+        self.bytes_exchanged, self.all_gathers = 0, 0       # of the last run(): payload received by this rank in the per-set tile all-gathers, and their number
+
+    def close(self):
+        """Releases the per-view process groups of multi-rank two-view runs (the energy context belongs to the caller)."""
+        if self._view_groups is not None:
+            import torch.distributed as dist
+            for gr in self._view_groups:
+                try:
+                    dist.destroy_process_group(gr)
+                except Exception:
+                    pass
+            self._view_groups = None
 
     def addLayer(self, unit_region_size, proposers):
         """proposers: list of (kind, K) with kind in api.PROPOSE_EXPANSION / _RANDOM / _RANSAC (LES/FastGCStereo.h:88-92)."""
@@ -91,7 +104,9 @@ class FastGCStereo:
         if self.world > 1 and len(all_views) == 2:
             import torch.distributed as dist
             n0 = (self.world + 1) // 2
-            groups = [dist.new_group(list(range(0, n0))), dist.new_group(list(range(n0, self.world)))]      # (every rank creates both)
+            if self._view_groups is None:                      # (every rank creates both groups; once per object, not per run)
+                self._view_groups = [dist.new_group(list(range(0, n0))), dist.new_group(list(range(n0, self.world)))]
+            groups = self._view_groups
             mine = 0 if self.rank < n0 else 1
             view_group, view_rank, view_world = groups[mine], self.rank - (0 if mine == 0 else n0), (n0 if mine == 0 else self.world - n0)
             view_root = {all_views[0]: 0, all_views[1]: n0}
@@ -190,13 +205,15 @@ class FastGCStereo:
             final = {m: runners[m].labels for m in all_views}
         raw = final[0].cpu().numpy().copy() if 0 in final else None
         if len(all_views) == 2:
-            self.e.post_process(final[all_views[0]].data_ptr(), final[all_views[1]].data_ptr(), 1.5, self.p["omega"])     # LES/FastGCStereo.h:202
+            self.e.post_process(final[0].data_ptr(), final[1].data_ptr(), 1.5, self.p["omega"])     # (left, right) whatever the order of viewModes; LES/FastGCStereo.h:202
             if 0 in runners:
                 self._evaluate(maxIteration + 1 + pmInit, 0, runners[0], None, t0)
             # (the rows of the log belong to the ranks of the left view's group)
         lab = final[0].cpu().numpy().copy() if 0 in final else None
         self.seconds = time.perf_counter() - t0 - self.eval_seconds          # evaluation excluded (as in the reference), set-up and initialisation included (unlike it)
         self.seconds_reference_clock = self.seconds - self.init_seconds
+        self.bytes_exchanged = sum(r.bytes_exchanged for r in runners.values())
+        self.all_gathers = sum(r.exchanges for r in runners.values())
         for r in runners.values():
             r.close()
         if g is not None:
@@ -228,6 +245,7 @@ def MidV2(data, iterations=5, pmIterations=2, doDual=False, smooth_weight=1.0, f
     st.setEvaluator(io.Evaluator(data["dispGT"], data["nonocc"], 0.5), precision=data.get("gt_prec", -1.0))
     _layers(st, (5, 15, 25))
     lab, raw = st.run(iterations, (0, 1) if doDual else (0,), pmIterations)
+    st.close()
     e.close()
     return st, lab, raw
 
@@ -246,6 +264,7 @@ def MidV3(data, volL, volR, iterations=5, pmIterations=2, doDual=False, smooth_w
     st.setEvaluator(io.Evaluator(data["dispGT"], data["nonocc"], error_threshold), precision=-1.0)
     _layers(st, (int(W * 0.01), int(W * 0.03), int(W * 0.09)))
     lab, raw = st.run(iterations, (0, 1) if doDual else (0,), pmIterations)
+    st.close()
     e.close()
     del tl, tr
     return st, lab, raw
