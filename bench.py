@@ -10,9 +10,13 @@ evaluations (gather the volume taps -> truncate -> colour guided filter), inputs
 Multi-GPU (--gpus N > 1, launched by torch.distributed.run, one rank per GPU): the shard of BASELINE.json configs[4] --
 hypotheses (disparity slices) are independent, so every rank aggregates 64 slices of a 3000 x 2000 image (= 384 M evaluations,
 the evaluation count of the 1-GPU workload) with no data-path collective and replicated guide statistics; at N = 8 the ranks
-together hold exactly the 3000 x 2000 x 512 volume of configs[4].  Per-GPU work is fixed for every N: "weak" scaling.  N = 1
-stays on configs[2] (the configuration the metric is quoted on) and also reports the per-rank shape of the N > 1 runs as the
-sub-record `n8_rank_shape`, so that a 1 -> 8 curve has a like-for-like baseline.
+together hold exactly the 3000 x 2000 x 512 volume of configs[4].  Per-GPU work is fixed for every N: "weak" scaling (the
+default; `--scaling strong` splits the 512 slices of configs[4] as 512 / N per rank instead -- the two coincide at N = 8 -- and the
+record says which one ran).  N = 1 stays on configs[2] (the configuration the metric is quoted on) and also reports the per-rank
+shape of the N > 1 runs as the sub-record `n8_rank_shape`, so that a 1 -> 8 curve has a like-for-like baseline.  At N > 1 the line
+also carries `e2e_sharded`: BASELINE configs[3] -- the two-view optimiser at the Adirondack-H shape with the views split over two
+rank groups, the cells of every disjoint set sharded inside a group and one RCCL all-gather of the updated tiles per set -- so
+that the first multi-GPU run measures the path that HAS a collective, not only the collective-free one.
 
 At N = 1 the JSON line also carries the H2 (slanted planes, two volume taps) and H3 (LayerManager cell batches, the
 optimiser's geometry) measurements of the same build as sub-records (`h2`, `h3`), the copy ceiling measured in the same run
@@ -57,7 +61,10 @@ def main():
     ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3"])
     ap.add_argument("--height", type=int, default=0, help="default: 1000 at N = 1 (configs[2]), 2000 at N > 1 (configs[4])")
     ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 64 at N > 1")
+    ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 64 at N > 1 (weak) or 512 / N (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = 64 slices of 3000 x 2000 per rank whatever N (default); strong = the 512 slices of configs[4] split as 512 / N per rank")
+    ap.add_argument("--e2e-sharded", type=int, default=1, help="N > 1: 1 = add the sharded two-view end-to-end record (configs[3]); 0: skip it")
     ap.add_argument("--e2e", type=int, default=1, help="1: add the end-to-end sub-record (N = 1, ~15 s); 0: skip it")
     ap.add_argument("--sub-steps", type=int, default=20, help="steps of the H2 / H3 sub-records at N = 1 (0: skip them)")
     ap.add_argument("--cpu-planes", type=int, default=-1, help="planes of the CPU-baseline sample (-1: auto, 0: skip)")
@@ -92,7 +99,7 @@ def main():
     multi = world > 1
     H = args.height or (2000 if multi else 1000)
     W = args.width or (3000 if multi else 1500)
-    D = args.ndisp or (64 if multi else 256)                         # slices of this rank
+    D = args.ndisp or ((64 if args.scaling == "weak" else max(1, 512 // world)) if multi else 256)      # slices of this rank
     P = H * W
     # ---- synthetic inputs (seeded); the volume shard is generated directly in HBM
     guide = synth.make_guide(H, W, 1234)
@@ -210,15 +217,20 @@ def main():
     # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, separate passes,
     # tools/collect_profiles.sh): cannot be collected live inside this process, so the committed measurement is quoted --
     # only when it was taken on exactly these kernel sources and this shape.
-    traffic = None
+    traffic, traffic_source, co_bounds = None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf)).get(args.workload)
             if t and t.get("kernel_source_sha1") == kernel_source_hash() and [H, W, D] == list(t.get("shape", ())):
                 traffic = t["bytes_per_launch"]
-        except Exception:
-            traffic = None
+                traffic_source = t.get("source")
+                co_bounds = t.get("co_bounds")
+            elif t:
+                traffic_source = (f"profiles/traffic.json was collected on kernel sources {t.get('kernel_source_sha1')} / shape {t.get('shape')}, "
+                                  f"not on this run's ({kernel_source_hash()} / {[H, W, D]}): not quoted")
+        except Exception as ex:
+            traffic, traffic_source = None, f"profiles/traffic.json unreadable: {ex!r}"
 
     result = {
         "metric": "Mcost-evals/s (pixels x hypotheses / s), guided-filter cost aggregation, 1500x1000x256 vol",
@@ -229,12 +241,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if multi else "weak",
         "vs_baseline": None,
-        "dtype": "i32/i64 fixed-point box sums (exact), f32 3x3 algebra, f64 final combine" if kind == 1 else "f64 sums / f32 algebra",
+        "dtype": "i32 fixed-point box sums (exact; i64 stage-2 window sums), f32 3x3 algebra and combination" if kind == 1 else "f64 sums / f32 algebra",
         "data": "synthetic",
         "config": {
-            "workload": desc + (f"; the per-rank shard of BASELINE configs[4] ({D} slices of {W}x{H} per rank, {D * world} in total)" if multi else "; BASELINE configs[2]"),
+            "workload": desc + (f"; the per-rank shard of BASELINE configs[4] ({D} slices of {W}x{H} per rank, {D * world} in total; --scaling {args.scaling})" if multi else "; BASELINE configs[2]"),
             "evals_per_step_per_gpu": int(evals_rank),
             "sharding": "hypotheses (disparity slices) split across ranks, no data-path collective",
             "workgroups_per_launch": batch.num_jobs,
@@ -249,6 +261,13 @@ def main():
             "frac_of_achievable": round(achieved / ceiling, 5) if ceiling else None,
             "peak_achievable_guide": HBM_ACHIEVABLE_GUIDE_GBS,
             "traffic": traffic,
+            # where `traffic` and `co_bounds` come from: rocprofv3 --pmc passes of this very command (tools/collect_profiles.sh), quoted from the
+            # committed file only when it was taken on exactly these kernel sources and this shape (counters cannot be read inside this process)
+            "traffic_source": traffic_source,
+            # what else bounds the kernel besides HBM -- instruction issue (the VALU instructions per launch at the measured issue
+            # costs of the two instruction classes, with every wait hidden), the share of instructions outside the dual-issue class, how busy
+            # the LDS pipe is, and the occupancy the 155 KB of LDS per workgroup leave
+            "co_bounds": co_bounds,
             "kernel": kernel_name,
             "kernel_ms": round(kern_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -321,6 +340,42 @@ def main():
             except Exception as ex:
                 result["e2e"] = {"error": repr(ex)}
 
+    # ---- N > 1: BASELINE configs[3], the path WITH a collective -- the two-view optimiser at the Adirondack-H shape, views split over two rank
+    # groups, the cells of every disjoint set sharded inside a group, one all-gather of the updated tiles per set (RCCL over xGMI)
+    if multi and args.e2e_sharded and args.workload == "h1":
+        rec = None
+        try:
+            del batch, out, vol, e                               # the headline's buffers (1.5 GB volume + output) make room
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import e2e_bench
+            small = os.environ.get("LES_BENCH_ONE_DEVICE") == "1"          # the one-GPU functional test runs a small scene
+            shape = dict(width=360, height=240, ndisp=32, iterations=1, pm_iterations=1) if small else {}
+            barrier()
+            t0 = time.perf_counter()
+            mine = e2e_bench.run_sharded(rank, world, f"cuda:{dev_index}", **shape)
+            barrier()
+            wall = torch.tensor([time.perf_counter() - t0], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+            allrec = [None] * world
+            dist.all_gather_object(allrec, mine)
+            rec = {
+                "workload": ("BASELINE configs[3] on a synthetic pair at the Adirondack-H shape (1436x992x256; the data set is not in the container): MidV3 defaults, 2 PatchMatch + 5 "
+                             "graph-cut iterations, doDual = 1; ranks split into one group per view, the cells of every disjoint set sharded inside a group, one all-gather of the "
+                             "updated tiles (labels 16 B/px + cost 4 B/px) per set, one broadcast per view of its final label map, post-processing replicated") if not small else
+                            "functional test shape 360x240x32, 1 PatchMatch + 1 graph-cut iteration",
+                "seconds": round(float(wall.item()), 3),                                   # scene ingest + optimiser + post-processing, max over ranks
+                "seconds_optimiser_max": max(r["seconds_optimiser"] for r in allrec),
+                "bytes_exchanged_per_rank": [r["bytes_exchanged"] for r in allrec],
+                "all_gathers_per_rank": [r["all_gathers"] for r in allrec],
+                "host_cut_seconds_per_rank": [r["host_cut_seconds"] for r in allrec],
+                "bad_all_last": next((r["bad_all_last"] for r in allrec if r["bad_all_last"] is not None), None),
+                "host_cpus_shared_by_all_ranks": os.cpu_count(),
+            }
+        except Exception as ex:                      # never lose the headline line to a sub-record
+            rec = {"error": repr(ex)}
+        result["e2e_sharded"] = rec
+
     # ---- CPU baseline: the oracle (CPU restatement, double guided filter like the reference default),
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.
     if rank == 0 and world == 1 and args.cpu_planes != 0 and planes is not None:
@@ -331,7 +386,7 @@ def main():
         cores = cpu_budget()
         ns = args.cpu_planes if args.cpu_planes > 0 else D - 1          # (almost) the whole workload: ~12 CPU-seconds on 16 cores
         ns = min(ns, D - 1)
-        vol_host = vol[: ns + 1].cpu().numpy()
+        vol_host = vol.cpu().numpy() if args.sub_steps > 0 else vol[: ns + 1].cpu().numpy()      # (the H2 / H3 samples below gather from every slice)
         o = om.Oracle(guide, None, vol_host, None, windR=20, eps=1e-4, th_col=0.5, max_disp=D - 1)
         o.aggregate_planes(planes[: min(ns, cores)], nthreads=cores)                 # warm the thread scratch
         c0 = time.perf_counter()
@@ -352,6 +407,37 @@ def main():
             "single_thread_value": round(P / (s1 - s0) / 1e6, 2),
             "gpu_vs_oracle_max_abs_err_on_sample": err,
         }
+        del ref, got
+        # ---- the same for the other two workloads of SURVEY 8(d) (bounded samples: a few CPU-seconds each)
+        if args.sub_steps > 0 and args.workload == "h1":
+            try:
+                n2 = min(4 * cores, D)
+                pl2 = synth.slanted_planes(D, H, W, D - 1, seed=7 + rank)[:n2]
+                c0 = time.perf_counter()
+                o.aggregate_planes(pl2, nthreads=cores)
+                c1 = time.perf_counter()
+                result["cpu_baseline"]["h2"] = {"value": round(n2 * P / (c1 - c0) / 1e6, 2), "unit": "Mcost-evals/s", "cores": cores,
+                                                "sample": f"first {n2} of the {D} slanted planes of H2 ({n2 * P / 1e6:.0f} M evals, {c1 - c0:.1f} s, OpenMP over hypotheses)"}
+                from localexpstereo_amd import pm
+                rng3 = np.random.default_rng(7 + rank)
+                ev3, t3, nl3 = 0, 0.0, 0
+                for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
+                    units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
+                    for cells in sets[:2]:                                  # two of the 16 disjoint sets of each layer, one proposal slot each
+                        pl = np.zeros((len(cells), 4), np.float32)
+                        pl[:, 0] = rng3.uniform(-0.05, 0.05, len(cells)); pl[:, 1] = rng3.uniform(-0.05, 0.05, len(cells))
+                        cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
+                        pl[:, 2] = rng3.uniform(0.2, 0.8, len(cells)) * (D - 1) - pl[:, 0] * cx - pl[:, 1] * cy
+                        c0 = time.perf_counter()
+                        o.unary_batch(filt[cells], shared[cells], pl, mode=0, check=True, nthreads=cores)
+                        t3 += time.perf_counter() - c0
+                        ev3 += int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
+                        nl3 += 1
+                result["cpu_baseline"]["h3"] = {"value": round(ev3 / t3 / 1e6, 2), "unit": "Mcost-evals/s (filter-domain)", "cores": cores,
+                                                "sample": f"{nl3} of the 240 lock-steps of H3: two disjoint sets of each layer, one plane per cell ({ev3 / 1e6:.0f} M filter-domain "
+                                                          f"evals, {t3:.1f} s, OpenMP over cells as the reference does)"}
+            except Exception as ex:                  # never lose the headline line to a sub-record
+                result["cpu_baseline"]["h2_h3_error"] = repr(ex)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -126,7 +126,13 @@ class PMRunner:
         x.pack(self.labels.data_ptr(), self.cur.data_ptr(), send.data_ptr())
         if self.device.type != "cuda":
             self._sync()
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional tests of the multi-rank path on a box with ONE GPU (bench.py: LES_BENCH_BACKEND=gloo): gloo moves host memory
+            send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(recv_h, send_h, group=self.group)
+            recv.copy_(recv_h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
         self.bytes_exchanged += recv.numel() * 4
         self.exchanges += 1
         x.unpack(recv.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr())

@@ -200,7 +200,12 @@ class FastGCStereo:
             other = {m: torch.zeros((H_, W_, 4), dtype=torch.float32, device=torch.device(self.device)) for m in all_views if m not in runners}
             final = {m: (runners[m].labels if m in runners else other[m]) for m in all_views}
             for m in all_views:
-                dist.broadcast(final[m], src=view_root[m])
+                if final[m].is_cuda and dist.get_backend() == "gloo":          # (one-GPU functional tests of the multi-rank path: gloo moves host memory)
+                    h = final[m].cpu()
+                    dist.broadcast(h, src=view_root[m])
+                    final[m].copy_(h)
+                else:
+                    dist.broadcast(final[m], src=view_root[m])
         else:
             final = {m: runners[m].labels for m in all_views}
         raw = final[0].cpu().numpy().copy() if 0 in final else None

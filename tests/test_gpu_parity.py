@@ -753,7 +753,7 @@ def test_multi_gpu_rank_shape_whole_image_planes_vs_oracle(oracle_mod):
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():
-    """`bench.py --gpus 2` launched exactly as the driver does (torch.distributed.run, one process per rank), with both ranks on
+    """`bench.py --gpus 4` launched exactly as the driver does (torch.distributed.run, one process per rank), with all ranks on
     cuda:0 and gloo for the rendezvous / max-over-ranks reductions (LES_BENCH_BACKEND / LES_BENCH_ONE_DEVICE: test hooks, the
     measured configuration is RCCL with one GPU per rank): rank 0 prints one JSON line for the whole job."""
     import json
@@ -762,12 +762,19 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LES_BENCH_BACKEND="gloo", LES_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "500", "--width", "700", "--ndisp", "8", "--cpu-planes", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--height", "500", "--width", "700", "--ndisp", "8", "--cpu-planes", "0"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 4 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["evals_per_step_per_gpu"] == 500 * 700 * 8
+    # the leg WITH a collective (BASELINE configs[3]): view split x cell split -- four ranks = two per view group, so every disjoint set
+    # ends with an all-gather inside its group, and the groups meet for the broadcast of the final label maps
+    x = d["e2e_sharded"]
+    assert "error" not in x, x
+    assert x["seconds"] > 0 and len(x["bytes_exchanged_per_rank"]) == 4 and len(x["host_cut_seconds_per_rank"]) == 4
+    assert min(x["all_gathers_per_rank"]) > 0 and min(x["bytes_exchanged_per_rank"]) > 0
+    assert x["bad_all_last"] is not None and x["bad_all_last"] < 50.0

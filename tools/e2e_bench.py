@@ -60,6 +60,27 @@ def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0
                 gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, cgroup_cpu=cpu, host_threads=host_threads, log=rows)
 
 
+def run_sharded(rank, world, device, width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, smooth_weight=0.5):
+    """BASELINE configs[3]: the two-view run with the views split over two rank groups and the cells of every disjoint set sharded
+    inside a group (stereo.FastGCStereo.run; one all-gather of the updated tiles per set, LES/FastGCStereo.h:22-72, 172-185, 199-203).
+    Every rank calls it (torch.distributed is initialised by the caller); returns this rank's record."""
+    import torch
+    from localexpstereo_amd import stereo
+    H, W, D = height, width, ndisp
+    imL, imR, gt = make_scene(H, W, D)
+    volL = ad_volume(imL, imR, D, device).cpu().numpy()
+    data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
+    torch.cuda.synchronize(torch.device(device))
+    t1 = time.perf_counter()
+    st, lab, raw = stereo.MidV3(data, volL, None, iterations=iterations, pmIterations=pm_iterations, doDual=True, smooth_weight=smooth_weight,
+                                mc_threshold=0.5, error_threshold=1.0, device=device, rank=rank, world=world)
+    t_total = time.perf_counter() - t1
+    bad = [r.get("all") for r in st.log if r.get("all") is not None]
+    return dict(seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), bytes_exchanged=int(st.bytes_exchanged),
+                all_gathers=int(st.all_gathers), host_cut_seconds=round(float(st.gc_seconds.get("host_cuts", st.gc_seconds.get("cuts", 0.0))), 3),
+                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, bad_all_last=(round(bad[-1], 3) if bad else None))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1436)
