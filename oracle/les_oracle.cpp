@@ -663,37 +663,20 @@ extern "C" int les_ransac_sample_count(int ni, int ptNum, int pf, double conf)
 // solution through the SVD with singular values below (sum of w) * 2*FLT_EPSILON treated as zero.
 // Restated through the 3x3 eigen-decomposition of A^T A in double (same pseudo-inverse; OpenCV runs a
 // one-sided Jacobi SVD in float, so agreement is to float round-off, not bitwise).
-static void solve_svd_mx3(const float* A, const float* b, int m, float x[3], int row_width = 0)
+static void solve_svd_mx3(const float* A, const float* b, int m, float x[3])
 {
-    // Normal equations in double.  The accumulation order is part of this restatement's definition (the
-    // reference delegates to OpenCV's float SVD, whose internal order is unknowable here): rows are accumulated
-    // in increasing order into 4 partial sums by image row, partial = (i / row_width) mod 4, combined as
-    // (p0 + p1) + (p2 + p3).  The device implementation (localexpstereo_amd/csrc/les_propose.h) scans one quad of
-    // lanes per candidate in exactly this order, so both give bit-identical planes.  row_width == 0: one sum.
+    // Normal equations in double, rows accumulated in their natural order.  (The reference delegates to OpenCV's float SVD, whose
+    // internal order is unknowable here; round 4 removed an accumulation order that had been shaped after the device kernel's -- the
+    // product's RANSAC is now compared with this restatement to float round-off, and this solve with an order-free numpy
+    // least-squares solve in double, tests/test_oracle_proposers.py.)
     double M[3][3] = {{0}}, rhs[3] = {0};
-    if (row_width <= 0) {
-        for (int i = 0; i < m; i++) {
-            const double c[3] = {A[i * 3], A[i * 3 + 1], A[i * 3 + 2]};
-            const double d = b[i];
-            for (int r = 0; r < 3; r++) {
-                rhs[r] += c[r] * d;
-                for (int q = 0; q < 3; q++) M[r][q] += c[r] * c[q];
-            }
+    for (int i = 0; i < m; i++) {
+        const double c[3] = {A[i * 3], A[i * 3 + 1], A[i * 3 + 2]};
+        const double d = b[i];
+        for (int r = 0; r < 3; r++) {
+            rhs[r] += c[r] * d;
+            for (int q = 0; q < 3; q++) M[r][q] += c[r] * c[q];
         }
-    } else {
-        double p[4][9] = {{0}};
-        for (int i = 0; i < m; i++) {
-            if (A[i * 3 + 2] == 0.0f) continue;                // non-inlier rows are all-zero (A keeps original indices)
-            double* t = p[(i / row_width) % 4];
-            const double dx = A[i * 3], dy = A[i * 3 + 1], dd = b[i];
-            t[0] += dx * dx; t[1] += dx * dy; t[2] += dx; t[3] += dy * dy; t[4] += dy; t[5] += 1.0;
-            t[6] += dx * dd; t[7] += dy * dd; t[8] += dd;
-        }
-        double t[9];
-        for (int k = 0; k < 9; k++) t[k] = (p[0][k] + p[1][k]) + (p[2][k] + p[3][k]);
-        M[0][0] = t[0]; M[0][1] = M[1][0] = t[1]; M[0][2] = M[2][0] = t[2];
-        M[1][1] = t[3]; M[1][2] = M[2][1] = t[4]; M[2][2] = t[5];
-        rhs[0] = t[6]; rhs[1] = t[7]; rhs[2] = t[8];
     }
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 16; sweep++) {
@@ -730,6 +713,9 @@ static void solve_svd_mx3(const float* A, const float* b, int m, float x[3], int
     }
     for (int r = 0; r < 3; r++) x[r] = (float)out[r];
 }
+
+// cv::solve(A, b, x, DECOMP_SVD) of an m x 3 float system as restated above (exported for the order-free check against numpy)
+extern "C" void les_oracle_solve_mx3(const float* A, const float* b, int m, float* x) { solve_svd_mx3(A, b, m, x); }
 
 extern "C" les_plane les_ransac_proposal(les_rng* r, const les_plane* labels, int W, les_rect unit,
                                          int MAX_SAM, float conf, float threshold)
@@ -783,17 +769,16 @@ extern "C" les_plane les_ransac_proposal(les_rng* r, const les_plane* labels, in
         int no_i = count_inliers(N);                                                 // :204-206
         if (max_i < no_i) {
             // :211-222 -- QUIRK kept: the copy loop runs i < no_i (not i < len), so only inliers among
-            // the first no_i points are used and the remaining rows of A, b stay zero.
-            // (rows are left at their original index i instead of being compacted to j: zero rows add
-            //  nothing to the normal equations, and the interleaved accumulation order then only depends on i)
+            // the first no_i points are used (compacted to rows j = 0, 1, ...) and the remaining rows of A, b stay zero.
             A.assign((size_t)no_i * 3, 0.0f);
             b.assign(no_i, 0.0f);
-            for (int i = 0; i < no_i; i++)
+            for (int i = 0, j = 0; i < no_i; i++)
                 if (v[i]) {
-                    for (int c = 0; c < 3; c++) A[i * 3 + c] = pts[i * 3 + c];
-                    b[i] = disp[i];
+                    for (int c = 0; c < 3; c++) A[j * 3 + c] = pts[i * 3 + c];
+                    b[j] = disp[i];
+                    j++;
                 }
-            solve_svd_mx3(A.data(), b.data(), no_i, N, unit.w);                      // :224
+            solve_svd_mx3(A.data(), b.data(), no_i, N);                              // :224
             int no = count_inliers(N);                                               // :225-227
             if (no > no_i_c) {                                                       // :229-236
                 result[0] = N[0]; result[1] = N[1]; result[2] = N[2];

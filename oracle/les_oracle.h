@@ -141,6 +141,7 @@ int       les_random_is_continued(int iter, int K, int outerIter, float min_disp
 les_plane les_ransac_proposal(les_rng* r, const les_plane* labels, int W, les_rect unit,
                               int max_sam, float conf, float threshold);
 int       les_ransac_sample_count(int ni, int ptNum, int pf, double conf); /* :243-262 */
+void      les_oracle_solve_mx3(const float* A, const float* b, int m, float* x); /* cv::solve(A, b, x, DECOMP_SVD), m x 3 (Proposer.h:203,224) */
 
 /* ---------------- volume preparation (LES/main.cpp:146-199), "next" row N3 ---------------- */
 void les_fill_out_of_view(float* vol, int D, int H, int W, int mode);

@@ -105,6 +105,7 @@ def lib():
         "les_random_is_continued": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
         "les_ransac_proposal": (Plane, [C.POINTER(Rng), vp, C.c_int, Rect, C.c_int, C.c_float, C.c_float]),
         "les_ransac_sample_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double]),
+        "les_oracle_solve_mx3": (None, [fp, fp, C.c_int, fp]),
         "les_fill_out_of_view": (None, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "les_convert_volume_l2r": (None, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "les_consistency_check": (None, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),

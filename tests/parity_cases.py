@@ -410,11 +410,13 @@ def case_proposers(pr, unit=14, set_index=5, seed=11):
                         blk = lab_after[u["y"]:u["y"] + u["h"], u["x"]:u["x"] + u["w"]]
                         assert np.all(blk == got[i])
             else:
-                # RANSAC has no trigonometry: the defined accumulation order of the eigen-solve makes device and oracle proposals
-                # bit-identical on the MI355X as in the simulator (630 / 630 cells over three layers and noise levels,
-                # tools/ransac_agreement.py), generator states included
-                assert got.tobytes() == ref.tobytes(), f"ransac proposals differ in {int((~np.all(g4 == r4, axis=1)).sum())} of {n} cells"
-                assert np.array_equal(st, rst)
+                # RANSAC has no trigonometry.  The oracle accumulates the normal equations in the natural row order (round 4: no longer
+                # shaped after the device's quad-interleaved order); both work in double and round once to float, so the planes agree to
+                # float round-off and the sample / inlier decisions -- hence the generator states -- coincide.  Measured: bit-identical in
+                # every cell tried (tools/ransac_agreement.py), which is a fact about the data, not part of the contract.
+                assert np.array_equal(st, rst), f"ransac generator states differ in {int((st != rst).sum())} of {n} cells"
+                np.testing.assert_allclose(g4, r4, rtol=1e-5, atol=1e-5)
+                assert np.mean(np.all(g4 == r4, axis=1)) > 0.9
     finally:
         for d in (d_lab, d_rng, d_pl):
             d.free()

@@ -142,6 +142,45 @@ def test_random_label_and_proposers(oracle_mod):
     assert L.les_ransac_sample_count(50, 100, 3, 0.95) == int(math.log(0.05) / math.log(1 - (48 * 49 * 50) / (98 * 99 * 100)))
 
 
+def test_ransac_solve_against_order_free_least_squares(oracle_mod):
+    """cv::solve(A, b, x, DECOMP_SVD) as the oracle restates it (LES/Proposer.h:203,224), against numpy's double-precision least-squares
+    / minimum-norm solve, which knows nothing of the oracle's accumulation order: three-point solves, refits on inlier sets with the
+    reference's zero rows (:216), and rank-deficient systems (collinear points, a single point)."""
+    import ctypes as C
+    L = oracle_mod.lib()
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(5)
+
+    def solve(A, b):
+        A = np.ascontiguousarray(A, np.float32); b = np.ascontiguousarray(b, np.float32)
+        x = np.zeros(3, np.float32)
+        L.les_oracle_solve_mx3(A.ctypes.data_as(fp), b.ctypes.data_as(fp), len(b), x.ctypes.data_as(fp))
+        return x
+
+    worst = 0.0
+    for trial in range(300):
+        m = int(rng.choice([3, 3, 20, 196, 900]))
+        x0, y0 = rng.integers(0, 1400), rng.integers(0, 900)
+        A = np.stack([x0 + rng.integers(0, 45, m), y0 + rng.integers(0, 45, m), np.ones(m)], 1).astype(np.float32)
+        plane = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(0, 255)])
+        b = (A.astype(np.float64) @ plane + rng.normal(0, 0.3, m)).astype(np.float32)
+        kind = trial % 4
+        if kind == 1 and m > 3:                          # the reference's quirk: trailing all-zero rows
+            A[m // 2:] = 0; b[m // 2:] = 0
+        if kind == 2:                                    # collinear points: rank 2, minimum-norm solution
+            A[:, 1] = A[:, 0] - x0 + y0
+            b = (A.astype(np.float64) @ plane).astype(np.float32)
+        if kind == 3 and trial % 8 == 3:                 # one distinct point: rank 1
+            A[:] = A[0]; b[:] = b[0]
+        got = solve(A, b)
+        ref = np.linalg.lstsq(A.astype(np.float64), b.astype(np.float64), rcond=2 * 1.1920929e-07)[0]
+        # compare what the plane is used for: its disparities over the points (the coefficients of an ill-conditioned system -- 45 px of
+        # support at x ~ 1400 -- are not determined to 1e-5 individually by float data)
+        dg, dr = A.astype(np.float64) @ got.astype(np.float64), A.astype(np.float64) @ ref
+        worst = max(worst, float(np.max(np.abs(dg - dr)) / max(1.0, float(np.max(np.abs(dr))))))
+    assert worst <= 1e-5, worst
+
+
 def test_volume_preparation(oracle_mod):
     """LES/main.cpp:146-199 (N3): out-of-view fill and left->right volume conversion."""
     L = oracle_mod.lib()
