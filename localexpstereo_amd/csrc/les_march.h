@@ -180,7 +180,7 @@ __device__ __forceinline__ void march_prefix_tile(int4 (*T)[PCOLS], int ci0, int
     march_prefix_scan8(v);
     if (act) {
 #pragma unroll
-        for (int j = 0; j < SEGL; j++) p[j] = v[j];
+        for (int j = 0; j < SEGL; j++) lds_store4(&p[j], v[j].x, v[j].y, v[j].z, v[j].w);
     }
 }
 
@@ -207,13 +207,13 @@ __device__ __forceinline__ void march_prefix_pair(int4 (*TA)[PCOLS], int4 (*TB)[
     march_prefix_scan8(vb);
     if (act) {
 #pragma unroll
-        for (int j = 0; j < SEGL; j++) pb[j] = vb[j];
+        for (int j = 0; j < SEGL; j++) lds_store4(&pb[j], vb[j].x, vb[j].y, vb[j].z, vb[j].w);
     }
     LES_MARCH_SCHED_FENCE();
     march_prefix_scan8(va);
     if (act) {
 #pragma unroll
-        for (int j = 0; j < SEGL; j++) pa[j] = va[j];
+        for (int j = 0; j < SEGL; j++) lds_store4(&pa[j], va[j].x, va[j].y, va[j].z, va[j].w);
     }
 }
 
@@ -543,7 +543,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                             Sc[0] = Sc[0] + mul24_sbyte<0>(gi, pi) + mul24_sbyte<0>(go, no);
                             Sc[1] = Sc[1] + mul24_sbyte<1>(gi, pi) + mul24_sbyte<1>(go, no);
                             Sc[2] = Sc[2] + mul24_sbyte<2>(gi, pi) + mul24_sbyte<2>(go, no);
-                            T[i][pcS] = int4{Sp, Sc[0] >> kMarchSH, Sc[1] >> kMarchSH, Sc[2] >> kMarchSH};
+                            lds_store4(&T[i][pcS], Sp, Sc[0] >> kMarchSH, Sc[1] >> kMarchSH, Sc[2] >> kMarchSH);
                             issue_row(itag);                     // the same row of block k + 1
                         });
                         rowbits = rowbits_nx;                    // (prep(k + 1) above replaced the table; the rows of block k used the old flags)
@@ -555,7 +555,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
                         const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
-                        constexpr bool kPair = KIND != 2;
+                        constexpr bool kPair = KIND != 2 && KIND != 4;       // (the general-plane marches hold two taps and a weight per row in flight: the paired pass, 32 more registers, would spill)
                         if (kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
                             if (da) { wave_sync(); march_prefix_tile<BY, PCOLS>(s_T1[k & 1][slot], ci0, lane); }
@@ -672,12 +672,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
 #else
                         const float bb = fmaf(-a2, st[i].c.w, fmaf(-a1, st[i].c.z, fmaf(-a0, st[i].c.y, mp)));
 #endif
-                        int4 o;
-                        o.x = cvt_rpi_i32(a0);
-                        o.y = cvt_rpi_i32(a1);
-                        o.z = cvt_rpi_i32(a2);
-                        o.w = cvt_rpi_i32(bb);
-                        T2[i][pcS] = o;
+                        lds_store4(&T2[i][pcS], cvt_rpi_i32(a0), cvt_rpi_i32(a1), cvt_rpi_i32(a2), cvt_rpi_i32(bb));
                     });
                     LES_MARCH_SCHED_FENCE();
                     static_for<N>([&](auto jtag) { issue_row(std::integral_constant<int, LO + decltype(jtag)::value>{}); });   // the same rows of block k

@@ -98,6 +98,8 @@ __device__ inline uint32_t ballot_low(bool f, int n)
 }
 // sign-extended bit `bit` of a wave-uniform word: all ones or zero
 __device__ inline int sbfe1(uint32_t w, int bit) { return -(int)((w >> bit) & 1u); }
+// one 16-byte LDS store
+__device__ inline void lds_store4(int4* p, int x, int y, int z, int w) { *p = int4{x, y, z, w}; }
 
 #else
 
@@ -221,7 +223,13 @@ __device__ __forceinline__ void acc64_add_i32(long long& acc, int d)
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_buf(const void* p, uint32_t bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00027000);
+    // The descriptor must be PROVABLY wave-uniform (base and size go through v_readfirstlane): a descriptor the compiler takes for
+    // divergent -- e.g. a base computed from a job field -- makes every access a "waterfall" loop (4 x v_readfirstlane, two 64-bit
+    // compares, s_and_saveexec, the access, a branch back).  All callers pass wave-uniform values.
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    void* q = (void*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00027000);
 }
 template <class T>
 __device__ __forceinline__ T buf_load(BufRsrc r, uint32_t voff, uint32_t soff)
@@ -240,6 +248,13 @@ __device__ __forceinline__ uint32_t mad_u24(int a, int b, int c) { return (uint3
 __device__ __forceinline__ uint32_t ballot_low(bool f, int) { return (uint32_t)__builtin_amdgcn_ballot_w64(f); }
 // sign-extended bit `bit` of a wave-uniform word: all ones or zero (s_bfe_i32)
 __device__ __forceinline__ int sbfe1(uint32_t w, int bit) { return __builtin_amdgcn_sbfe((int)w, (unsigned)bit, 1u); }
+// ONE ds_write_b128.  (An int4 struct store is four scalar stores to the optimiser, which the load / store merger re-pairs as it sees fit:
+// under register pressure role A's row stores came out as two ds_write2_b32 each -- twice the LDS instructions, with bank conflicts.)
+__device__ __forceinline__ void lds_store4(int4* p, int x, int y, int z, int w)
+{
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<v4i*>(p) = v4i{x, y, z, w};
+}
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }    // folds to v_min3_f32
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 

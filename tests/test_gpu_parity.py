@@ -227,7 +227,7 @@ def test_gpu_kernel_dispatch(mid, oracle_mod):
     im = synth.make_guide(H, W, 3)
     vol = synth.make_volume(D, H, W, 5)
     cells = [(0, 0, W, H)]
-    for v, kw, kind in ((vol, {}, 1), (np.where(vol > 0.999, np.nan, vol).astype(np.float32), {}, 0), (vol - 9.0, {}, 0), (vol, {"windR": 8}, 0)):
+    for v, kw, kind in ((vol, {}, 1), (np.where(vol > 0.999, np.nan, vol).astype(np.float32), {}, 0), (vol - 9.0, {}, 0), (vol, {"windR": 8}, 1), (vol, {"windR": 30}, 0)):
         ee = api.HipCostVolumeEnergy(im, None, v, None, **kw)
         bb = api.Batch(ee, cells, cells)
         assert bb.kernel_kind(0) == kind
