@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3"])
+    ap.add_argument("--workload", default="h1", choices=["h1", "h2", "h3", "h3b"])
     ap.add_argument("--height", type=int, default=0, help="default: 1000 at N = 1 (configs[2]), 2000 at N > 1 (configs[4])")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--ndisp", type=int, default=0, help="slices per rank; default 256 at N = 1, 64 at N > 1 (weak) or 512 / N (strong)")
@@ -120,7 +120,7 @@ def main():
     def make_workload(name):
         """-> (step function, evaluations per step of this rank, algorithmic bytes per evaluation, representative batch,
         description, planes or None)"""
-        if name == "h3":
+        if name in ("h3", "h3b"):
             # H3 (SURVEY.md 8(d)): the optimiser's geometry -- LayerManager cells of units 1 % / 3 % / 9 % of the width, one
             # random plane per cell and proposal slot (9 / 3 / 3 per cell), one launch per disjoint set and slot; the contract
             # number counts filter-domain pixels x hypotheses
@@ -130,12 +130,16 @@ def main():
             for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
                 units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
                 for cells in sets:
-                    b = api.Batch(e, filt[cells], shared[cells])
+                    # h3b: the proposal slots of a set in ONE launch, slot s into cost map s (out_slabs = cells per slot) -- the same evaluations
+                    # in 48 launches instead of 240.  NOT what the optimiser does (its proposals depend on the previous fusion, LES/FastGCStereo.h:
+                    # 30-64): it shows what the kernel delivers once a launch fills the GPU.
+                    b = (api.Batch(e, np.tile(filt[cells], slots), np.tile(shared[cells], slots), out_slabs=len(cells)) if name == "h3b"
+                         else api.Batch(e, filt[cells], shared[cells]))
                     pl = np.zeros((slots, len(cells), 4), np.float32)
                     pl[..., 0] = rng.uniform(-0.05, 0.05, pl.shape[:2]); pl[..., 1] = rng.uniform(-0.05, 0.05, pl.shape[:2])
                     cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
                     pl[..., 2] = rng.uniform(0.2, 0.8, pl.shape[:2]) * (D - 1) - pl[..., 0] * cx - pl[..., 1] * cy
-                    batches.append((b, [torch.from_numpy(pl[k]).to(dev) for k in range(slots)]))
+                    batches.append((b, [torch.from_numpy(pl.reshape(-1, 4)).to(dev)] if name == "h3b" else [torch.from_numpy(pl[k]).to(dev) for k in range(slots)]))
                     evals += slots * int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
             nl = sum(len(p) for _, p in batches)
 
@@ -145,6 +149,10 @@ def main():
                         b.run(p.data_ptr(), out.data_ptr(), mode=0, check=True, planes_on_device=True)
             desc = (f"H3: LayerManager cells (units 1/3/9 % of W={W}), 9/3/3 random planes per cell, one launch per disjoint set and "
                     f"slot ({nl} launches per step), filter-domain evaluations counted; volume {W}x{H}x{D} f32 U[0,1)")
+            if name == "h3b":
+                desc = (f"H3 with the proposal slots of a set batched: the same cells, planes and evaluations as H3, one launch per disjoint set with all its "
+                        f"9/3/3 slots, slot s into cost map s ({nl} launches per step instead of 240).  An upper bound for the kernel on this geometry, not "
+                        f"the optimiser's schedule: its proposals depend on the previous fusion (LES/FastGCStereo.h:30-64)")
             return step, float(evals), 12.0, batches[0][0], desc, None
         if name == "h1":
             planes = synth.fronto_planes(D)
@@ -277,11 +285,11 @@ def main():
 
     # ---- sub-records: the other two workloads of SURVEY.md 8(d) on the same context
     if world == 1 and args.sub_steps > 0 and args.workload == "h1":
-        for name in ("h2", "h3"):
+        for name in ("h2", "h3", "h3b"):
             st, ev, bpe, bt, ds, _ = make_workload(name)
             el, km = measure(st, args.sub_steps, 2)
             ab = ev * bpe + float(P) * 48.0
-            result[name] = {
+            result["h3_batched" if name == "h3b" else name] = {
                 "workload": ds,
                 "ms_per_step": round(el / args.sub_steps * 1e3, 4),
                 "value": round(ev * args.sub_steps / el / 1e6, 2),

@@ -113,8 +113,10 @@ int les_hip_unary_batch(les_hip_ctx* ctx, int mode, int n, const les_hip_rect* f
 
 /* Prepared form for the hot loop: geometry is uploaded once, then reused for every proposal.
  * out_slabs == 0: outputs go into one H x W map (element (y,x) of call i at y*W+x);
- * out_slabs != 0: call i writes its target rect into slab i of a [n][H][W] array (used for whole-image
- * aggregation of many hypothesis planes). */
+ * out_slabs == k > 0: call i writes its target rect into slab i / k of a [ceil(n / k)][H][W] array.  k = 1: every call
+ * its own slab (whole-image aggregation of many hypothesis planes); k = cells of a disjoint set,
+ * n = k * slots: several proposal slots of the set evaluated in ONE launch, slot s into map s (the calls of a slot are
+ * consecutive) -- the launch then fills the GPU where a single lock-step of a coarse layer cannot. */
 int les_hip_batch_create(les_hip_ctx* ctx, int n, const les_hip_rect* filterRects, const les_hip_rect* targetRects,
                          int out_slabs, les_hip_batch** out);
 void les_hip_batch_destroy(les_hip_batch* b);

@@ -229,11 +229,13 @@ class Exchange:
 
 class Batch:
     def __init__(self, energy, filter_rects, target_rects, out_slabs=False):
+        """out_slabs: False / 0 = every call writes the one H x W map; True / 1 = call i writes slab i of [n][H][W]; k > 1 = call i writes slab
+        i // k (k consecutive calls -- the cells of a disjoint set -- share a map: several proposal slots of the set in one launch)."""
         self.e = energy
         self.frs = _rects(filter_rects)
         self.trs = _rects(target_rects)
         self.n = len(self.frs)
-        self.out_slabs = bool(out_slabs)
+        self.out_slabs = int(out_slabs)
         h = C.c_void_p()
         energy._chk(energy.L.les_hip_batch_create(energy.h, self.n, _ptr(self.frs), _ptr(self.trs), int(out_slabs), C.byref(h)))
         self.h = h

@@ -312,7 +312,7 @@ int build_jobs(const les_hip_ctx* c, int n, const les_hip_rect* frs, const les_h
                 j.tx0 = t.x + sx; j.ty0 = t.y + sy;
                 j.tw = std::min(TW, t.w - sx); j.th = std::min(max_rows, t.h - sy);
                 j.cx0 = f.x; j.cy0 = f.y; j.cx1 = f.x + f.w; j.cy1 = f.y + f.h;
-                j.out_off = (out_slabs ? (long long)i * P : 0) + (long long)j.ty0 * c->p.W + j.tx0;
+                j.out_off = (out_slabs ? (long long)(i / out_slabs) * P : 0) + (long long)j.ty0 * c->p.W + j.tx0;
                 j.out_stride = c->p.W;
                 j.plane_idx = i;
                 jobs.push_back(j);
@@ -398,7 +398,7 @@ bool build_march_jobs(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_
                 j.tx0 = t.x + sx; j.ty0 = t.y + sy;
                 j.tw = std::min(sw, t.w - sx); j.th = std::min(sh, t.h - sy);
                 j.cx0 = f.x; j.cy0 = f.y; j.cx1 = f.x + f.w; j.cy1 = f.y + f.h;
-                j.out_off = (out_slabs ? (long long)i * P : 0) + (long long)j.ty0 * W + j.tx0;
+                j.out_off = (out_slabs ? (long long)(i / out_slabs) * P : 0) + (long long)j.ty0 * W + j.tx0;
                 j.out_stride = W;
                 j.plane_idx = i;
                 jobs.push_back(j);
@@ -735,6 +735,7 @@ int les_hip_synchronize(les_hip_ctx* c)
 int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs, les_hip_batch** out)
 {
     if (!c || !out || n < 0 || (n > 0 && (!frs || !trs))) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (out_slabs < 0) return fail(LES_HIP_ERR_ARG, "out_slabs must be 0 (one map) or the number of consecutive calls that share a slab");
     *out = nullptr;
     std::vector<les::Job> jobs;
     int rc = build_jobs(c, n, frs, trs, out_slabs, jobs);

@@ -151,7 +151,7 @@ __global__ void les_init_labels_kernel(const Rect4* __restrict__ units, float4* 
 
 // ---------------------------------------------------------------------------------------------------
 // RANSAC.  cv::solve(A, b, x, DECOMP_SVD) of an m x 3 system is restated as the pseudo-inverse through
-// the 3x3 eigen-decomposition of A^T A in double, exactly as oracle/les_oracle.cpp:solve_svd_mx3.
+// the 3x3 eigen-decomposition of A^T A in double (cyclic Jacobi; LES/Proposer.h:203,224).
 // ---------------------------------------------------------------------------------------------------
 __device__ inline void solve_normal_3x3(double M[3][3], const double rhs[3], float x[3])
 {
@@ -266,8 +266,9 @@ __global__ void les_ransac_draw_kernel(const Rect4* __restrict__ units, const ui
 
 // One QUAD of lanes per (cell, candidate): lane s of the quad scans the rows yy = s (mod 4) of the unit region.
 // Inlier counts are integer sums over the quad.  The normal equations of the refit are accumulated per lane in
-// increasing (row, column) order and combined as (p0 + p1) + (p2 + p3) -- oracle/les_oracle.cpp:solve_svd_mx3
-// uses the same order (row_width argument), so both give bit-identical planes.
+// increasing (row, column) order and combined as (p0 + p1) + (p2 + p3): a DEFINED order, shared with the host RansacProposer
+// (host/Proposer.h), so that the per-call drop-in loop and the device proposals are bit-identical.  (The test oracle sums in the
+// natural row order since round 4; the comparison with it is to float round-off.)
 __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold)
 {
     const int cell = (int)blockIdx.x;

@@ -291,6 +291,30 @@ def case_plane_slabs(pr, n=5, mode=1):
     return worst
 
 
+def case_grouped_slots(pr, unit=14, set_index=3, slots=3, mode=0):
+    """Several proposal slots of one disjoint set in ONE launch (les_hip_batch_create with out_slabs = cells per slot): slot s of every cell
+    into cost map s.  Every map must equal the single-slot lock-step of the oracle, written pixels and sentinels included."""
+    layer = om.Layer(pr.W, pr.H, 20, unit)
+    cells = layer.sets[min(set_index, len(layer.sets) - 1)]
+    n = len(cells)
+    frs, trs = np.tile(layer.filter[cells], slots), np.tile(layer.shared[cells], slots)
+    planes = random_planes(n * slots, pr.D, pr.H, pr.W, 31, slant=0.1)
+    b = api.Batch(pr.e, frs, trs, out_slabs=n)
+    buf = api.DeviceBuffer(pr.e, slots * pr.H * pr.W * 4)
+    buf.fill(0xFF)                                      # NaN pattern: unwritten pixels stay NaN like the oracle's fresh map
+    b.run(planes, buf.ptr, mode=mode, check=True)
+    pr.e.synchronize()
+    out = buf.download((slots, pr.H, pr.W), np.float32)
+    buf.free()
+    kind = b.kernel_kind(mode)
+    b.destroy()
+    worst = 0.0
+    for s_ in range(slots):
+        ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes[s_ * n:(s_ + 1) * n], mode=mode, check=True)
+        worst = max(worst, compare_maps(out[s_], ref))
+    return worst, kind
+
+
 def case_wta(pr, seed=5):
     """Device WTA update vs LES/FastGCStereo.h:56-60."""
     import ctypes as C

@@ -106,6 +106,13 @@ def test_gpu_other_radii(oracle_mod):
             pr.close()
 
 
+def test_gpu_grouped_slots(mid):
+    """Three proposal slots of a disjoint set in one launch, each into its own cost map (out_slabs = cells per slot)."""
+    for unit, si in ((14, 3), (43, 1)):
+        worst, kind = pc.case_grouped_slots(mid, unit=unit, set_index=si, slots=3)
+        assert kind == 1
+
+
 def test_gpu_repeatable(mid):
     """Same inputs -> bit-identical outputs (no atomics / order dependence)."""
     layer = pc.om.Layer(mid.W, mid.H, 20, 15)

@@ -98,6 +98,11 @@ def test_sim_plane_slabs(cones):
     pc.case_plane_slabs(cones, n=3)
 
 
+def test_sim_grouped_slots(cones):
+    worst, kind = pc.case_grouped_slots(cones, unit=10, set_index=2, slots=3)
+    assert kind == 1
+
+
 def test_sim_small_radius(sim_lib, oracle_mod):
     # windR = 4 -> guided-filter radius 2 (a different kernel instantiation), tiny image, min_disp != 0 is not
     # exercised by the reference's shipped modes but the arithmetic (D0) is restated
