@@ -352,6 +352,20 @@ def main():
     # groups, the cells of every disjoint set sharded inside a group, one all-gather of the updated tiles per set (RCCL over xGMI)
     if multi and args.e2e_sharded and args.workload == "h1":
         rec = None
+        # A collective that one rank never reaches would hang the whole job and lose the headline line with it (this leg has never run on more
+        # than one GPU).  A watchdog bounds it: after LES_BENCH_E2E_TIMEOUT seconds (default 240; the one-GPU two-view run takes 6) rank 0 prints
+        # the line with an error in place of the sub-record and every rank leaves.
+        import threading
+        leg_done = threading.Event()
+
+        def watchdog():
+            if leg_done.wait(timeout=float(os.environ.get("LES_BENCH_E2E_TIMEOUT", "240"))):
+                return
+            if rank == 0:
+                result["e2e_sharded"] = {"error": "timeout: the sharded end-to-end leg did not finish (a rank failed or a collective hung); headline measured before it"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
         try:
             del batch, out, vol, e                               # the headline's buffers (1.5 GB volume + output) make room
             torch.cuda.empty_cache()
@@ -383,6 +397,11 @@ def main():
         except Exception as ex:                      # never lose the headline line to a sub-record
             rec = {"error": repr(ex)}
         result["e2e_sharded"] = rec
+        if rank == 0 and "error" in rec:
+            # (the other ranks may be waiting in a collective this rank left: print now, the watchdogs end them)
+            print(json.dumps(result), flush=True)
+            os._exit(0)
+        leg_done.set()
 
     # ---- CPU baseline: the oracle (CPU restatement, double guided filter like the reference default),
     # rank 0 at N = 1 only, on a bounded sample of the same workload: the first `ns` hypotheses.
