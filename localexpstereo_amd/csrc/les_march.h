@@ -385,7 +385,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
     const int sx = min(max(gx, job.cx0), max(job.cx1 - 1, job.cx0));      // clamped: addresses stay inside the image
     const uint32_t sx4 = (uint32_t)sx * 4u;                               // its byte offset in a row of floats / packed pixels
     const uint32_t rowB = (uint32_t)g.W * 4u;                             // bytes per image row of floats / packed pixels
-    const uint32_t imgB = (uint32_t)g.H * rowB;                           // bytes per image plane (the host refuses images of 2^29 pixels or more)
+    const uint32_t imgB = (uint32_t)g.H * rowB;                           // bytes per image plane (the host keeps images of 2^26 pixels or more on the strip kernel)
     const BufRsrc rs_guide = make_buf(view.ipk8, imgB);
     const int nx = window_count(gx, R, job.cx0, job.cx1);                 // the same count serves stage 1 and stage 2 (same column)
     // physical columns of P(x+R), P(x-R-1) and, when the window crosses a wave boundary, of the left neighbour's tile total
