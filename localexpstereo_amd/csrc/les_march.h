@@ -308,25 +308,33 @@ __device__ __forceinline__ bool march_label_surely_valid(const Geom& g, float4 p
     return (0.0f * pl.w == 0.0f) && mag < 1e30f && (lo - margin >= g.mind) && (hi + margin <= g.maxd);
 }
 
-// A general plane is TAME for a job when its disparity d = a x + (b y + c) stays inside [max(MIN, 0), MAX) at every pixel the job
-// gathers (its clip rectangle cut to the columns and rows of the march), by a margin far above the rounding of the float expression:
-// every pixel then interpolates two slices (LES/CostVolumeEnergy.h:83-92) -- no clamped, invalid or NaN case -- and the slices it
-// touches span less than 2^30 bytes from the lowest one.  Role A then runs the short gather (KIND 4); `slice_lo` receives the lowest
-// slice the job can touch.  Everything else takes the general per-pixel path (KIND 2).
-__device__ __forceinline__ bool march_plane_tame(const Geom& g, float4 pl, const Job& job, int R, int* slice_lo)
+// The SHORT GATHER of a general plane (role A's KIND 4): with MIN_DISPARITY = 0 and MAX_DISPARITY = D - 1 (the reference's own setting,
+// LES/main.cpp:341) the three branches of LES/CostVolumeEnergy.h:78-92 are ONE expression of the clamped disparity dc = min(max(d, 0), D - 1):
+//     d0 = floor(dc),  f1 = dc - d0,  C = (1 - f1) vol[d0] + f1 vol[d0 + (f1 > 0)]
+// -- below the range d0 = 0, f1 = 0: C = vol[0] exactly; at or above it d0 = D - 1, f1 = 0: C = vol[D - 1] exactly; inside it the reference's
+// own interpolation (int(d) = floor(d) for d >= 0); a tap beyond the last slice never happens (d0 = D - 1 only with f1 = 0).  It needs a plane with finite coefficients of moderate size (no NaN
+// disparity: a NaN takes the reference's invalid branch) and taps that fit a 32-bit byte offset from one descriptor base: the whole volume
+// (below 2^30 floats), or -- for larger volumes -- a plane that is TAME over the job, i.e. whose disparity stays inside the range, by a margin far
+// above float rounding, at every pixel the job gathers, so that its slices span less than 2^30 bytes from the lowest one (`slice_lo`).
+// Everything else (NaN / infinite planes, other disparity ranges, images of 2^24 pixels or more) takes the general per-pixel path (KIND 2).
+__device__ __forceinline__ bool march_plane_short_gather(const Geom& g, float4 pl, const Job& job, int R, int* slice_lo)
 {
+    *slice_lo = 0;
+    const unsigned long long HW = (unsigned long long)g.H * (unsigned long long)g.W;
+    const bool moderate = fabsf(pl.x) < 1e30f && fabsf(pl.y) < 1e30f && fabsf(pl.z) < 1e30f;      // (false for NaN)
+    if (!(moderate && g.mind == 0.0f && g.D0 == 0 && g.maxd == (float)(g.D - 1) && g.D >= 2 && HW < (1ull << 24))) return false;
+    if ((unsigned long long)g.D * HW < (1ull << 30)) return true;                                   // every tap within 4 GB of slice 0
     const int x0 = max(job.tx0 - 2 * R, job.cx0), x1 = min(job.tx0 + job.tw + 2 * R, job.cx1) - 1;
     const int y0 = max(job.ty0 - 2 * R, job.cy0), y1 = min(job.ty0 + job.th + 2 * R, job.cy1) - 1;
+    if (x1 < x0 || y1 < y0) return false;
     const float ax0 = pl.x * (float)x0, ax1 = pl.x * (float)x1, by0 = pl.y * (float)y0, by1 = pl.y * (float)y1;
     const float lo = (fminf(ax0, ax1) + fminf(by0, by1)) + pl.z, hi = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + pl.z;
     const float mag = fmaxf(fabsf(ax0), fabsf(ax1)) + fmaxf(fabsf(by0), fabsf(by1)) + fabsf(pl.z);
     const float margin = 1e-5f * mag + 1e-30f;
-    const bool inside = mag < 1e30f && (lo - margin >= fmaxf(g.mind, 0.0f)) && (hi + margin < g.maxd) && x1 >= x0 && y1 >= y0;
-    if (!inside) { *slice_lo = 0; return false; }
-    const int s0 = (int)floorf(lo - margin) + g.D0, s1 = (int)floorf(hi + margin) + g.D0 + 1;      // lowest / highest slice touched
+    if (!((lo - margin >= 0.0f) && (hi + margin < g.maxd))) return false;
+    const int s0 = (int)floorf(lo - margin), s1 = (int)floorf(hi + margin) + 1;                     // lowest / highest slice touched
     *slice_lo = s0;
-    const unsigned long long HW = (unsigned long long)g.H * (unsigned long long)g.W;
-    return s0 >= 0 && s1 < g.D && HW < (1ull << 24) && (unsigned long long)(s1 - s0 + 1) * HW < (1ull << 28);
+    return s0 >= 0 && s1 < g.D && (unsigned long long)(s1 - s0 + 1) * HW < (1ull << 28);
 }
 
 template <int R, int WGC, int NJ, int BY>
@@ -418,7 +426,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // count is a per-job constant -- multiply the loaded cost by 0 and put the count of th_col into the addend
         const bool inv_job = fronto && modes == 2 && !view.raw_off;
         int slice_lo = 0;
-        const bool tame = !fronto && !view.raw_off && march_plane_tame(g, plane, job, R, &slice_lo);
+        const bool tame = !fronto && !view.raw_off && march_plane_short_gather(g, plane, job, R, &slice_lo);
         // Columns outside the clip contribute count 0: their factor is 0 and their addend the bare 1.5 * 2^23 (per-lane constants, so
         // the column half of the clip test costs nothing per row; the row half is one v_and with a scalar mask)
         const float spj = !col_in ? 0.0f : (inv_job ? 0.0f : view.sp);
@@ -429,7 +437,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         //   KIND 1  fronto-parallel plane, two taps
         //   KIND 2  general plane: taps / weight / mode per lane and row
         //   KIND 3  image-based energy: one tap into the call's raw-cost patch (any plane; no truncation, no invalid mode)
-        //   KIND 4  general plane that is tame over the job (march_plane_tame): two interpolated taps per pixel, no special cases
+        //   KIND 4  general plane with the short gather (march_plane_short_gather): two taps of the clamped disparity per pixel, no special cases
         // For fronto-parallel planes everything but the clip test is per-job, the row bases are scalars and the loads need no
         // address arithmetic.
         auto march_a = [&](auto kind_tag) __attribute__((always_inline)) {
@@ -476,15 +484,17 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 v0[i] = buf_load<float>(rs_v0, sx4, ro);
                 if constexpr (KIND == 1) v1[i] = buf_load<float>(rs_v1, sx4, ro);
             } else if constexpr (KIND == 4) {
-                // LES/CostVolumeEnergy.h:73-92 on the interpolating branch: d0 = int(d) (= floor: d >= 0), f1 = d - floor(d), taps d0 and d0 + 1.
-                // Lanes / rows outside the clip compute on the clamped pixel (inside the tame rectangle) or on rows beyond the march (any
-                // address: the descriptor's range check returns 0) and are masked when the row is consumed.
+                // LES/CostVolumeEnergy.h:73-92 as one expression of the clamped disparity (see march_plane_short_gather): taps d0 and d0 + 1.
+                // Lanes / rows outside the clip compute on the clamped pixel and are masked when the row is consumed.
                 const float d = g_ax + readlane_f32(nx_dbase, i);
-                const float df = floorf(d);
-                f1r[i] = d - df;
+                const float dc = med3_f32(d, 0.0f, g.maxd);
+                const float df = floorf(dc);
+                f1r[i] = dc - df;
+                // (the second tap coincides with the first where its weight is zero -- integer and clamped disparities, the top slice
+                //  included: df = D - 1 only with f1 = 0 -- so clamped regions cost one slice of traffic, not two)
                 const uint32_t e = mad_u24((int)df + dsub, (int)HWu, sx);
                 v0[i] = buf_load<float>(rs_v0, e << 2, ro);
-                v1[i] = buf_load<float>(rs_v0, e << 2, ro + imgB);
+                v1[i] = buf_load<float>(rs_v0, (e << 2) + (f1r[i] > 0.0f ? imgB : 0u), ro);
             } else {
                 const float d_base = readlane_f32(nx_dbase, i);
                 const bool inside = col_in && ((rowbits_nx >> i) & 1u);
@@ -577,7 +587,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         // ================================================= role C =================================================
         const bool s1_col = col_in && ci >= R && ci < WGC - R;            // stage-1 column with a complete horizontal window
         int slice_lo_unused = 0;
-        const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f) && !march_plane_tame(g, plane, job, R, &slice_lo_unused);  // (role A's KIND 2)
+        const bool general_plane = !view.raw_off && !(plane.x == 0.0f && plane.y == 0.0f) && !march_plane_short_gather(g, plane, job, R, &slice_lo_unused);  // (role A's KIND 2)
         // a, b are zero outside the clip and before the march is primed: the column part of that rule is folded into the lane's
         // normalisation factors, the row part into the row's 1/count_y (0 * finite = 0, and v_cvt_rpi(+-0) = 0)
         const float kap_x = s1_col ? view.kapS * s_rtab[nx] : 0.0f;

@@ -73,6 +73,8 @@ __device__ inline int mul24_sbyte(uint32_t g, int v) { return (((int)(g << (24 -
 template <int B>
 __device__ inline float cvt_f32_sbyte(uint32_t g) { return (float)(((int)(g << (24 - 8 * B))) >> 24); }
 __device__ inline float min_f32_finite(float a, float b) { return b < a ? b : a; }
+// median of three (v_med3_f32): clamps x to [lo, hi] for lo <= hi; a NaN x gives lo here (the callers exclude NaN)
+__device__ inline float med3_f32(float x, float lo, float hi) { return !(x > lo) ? lo : (x > hi ? hi : x); }
 __device__ inline void acc64_add_i32(long long& acc, int d) { acc += (long long)d; }
 // raw buffer access (march kernel, round 4): base + per-lane byte offset + wave-uniform byte offset
 struct BufRsrc { const char* base; uint32_t bytes; };
@@ -209,6 +211,12 @@ __device__ __forceinline__ float min_f32_finite(float a, float b)
 {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float med3_f32(float x, float lo, float hi)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
     return r;
 }
 // acc += sign-extended d in ONE instruction (v_mad_i64_i32 with the inline constant 1; the compiler's own lowering of a 64-bit add
