@@ -102,6 +102,9 @@ def test_gpu_other_radii(oracle_mod):
                 ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], planes)
                 got = pr.e.unary_batch(layer.filter[cells], layer.shared[cells], planes)
                 pc.compare_maps(got, ref)
+            # whole-image slabs: fronto-parallel planes with one and two taps and slanted planes (the other specialisations of role A, the
+            # wide geometry, rings longer than the window for radii 5, 6, 8, 9)
+            pc.case_plane_slabs(pr, n=5, mode=0)
         finally:
             pr.close()
 
