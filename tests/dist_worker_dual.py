@@ -35,6 +35,7 @@ def main():
         dist.broadcast(ref, src=0)
         assert torch.equal(t, ref), f"rank {rank}: final labelling differs from rank 0"
         dist.barrier()
+        st.close()                      # the per-view process groups of the run
         dist.destroy_process_group()
     e.close()
 
