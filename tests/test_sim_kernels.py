@@ -118,7 +118,7 @@ def test_sim_small_radius(sim_lib, oracle_mod):
         pr.close()
 
 
-@pytest.mark.parametrize("windR", [8, 10, 13, 14, 17, 18, 30])
+@pytest.mark.parametrize("windR", [8, 10, 14, 17, 30])     # radii 4, 5 (ring longer than the window), 7, 8 (the same), 15 (strip kernel); the GPU sweep runs all
 def test_sim_other_radii(sim_lib, oracle_mod, windR):
     pr = pc.synth_pair(sim_lib, 60, 100, 6, windR=windR, eps=1e-4, th_col=0.5)
     try:
