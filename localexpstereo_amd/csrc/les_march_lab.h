@@ -4,7 +4,7 @@
 //
 //   -DLES_MARCH_ROLE_MASK=m    bit 0 / 1 / 2 = compile role A / C / D in; the waves of the other roles exit at once
 //   -DLES_MARCH_ROLE_ORDER=o   which role gets the oldest waves of a job slot (index into kRoleOf)
-//   -DLES_MARCH_EXP=bits       1 role C issues no statistics loads, 2 role C reads no LDS, 16 role D reads no LDS,
+//   -DLES_MARCH_EXP=bits       1 role C issues no statistics loads, 2 role C reads no LDS, 4 role C loads the statistics of image row 0 for every row, 16 role D reads no LDS,
 //                              64 role A loads nothing, 128 role D loads / stores nothing
 //   -DLES_STATS_POLICY='" nt"' cache-policy bits of the statistics loads (" nt", " sc0", " sc1", " sc0 sc1")
 //   -DLES_VOL_NT               streaming (non-temporal) loads of volume / guide rows
