@@ -781,6 +781,39 @@ def test_multi_gpu_rank_shape_whole_image_planes_vs_oracle(oracle_mod):
     e.close()
 
 
+def test_bench_record_fields_on_one_gpu():
+    """The driver's contract for the N = 1 line: one JSON line with the metric fields, the roofline object (with the co-bounds and the
+    source of the traffic figure) and the CPU baseline with its H2 / H3 samples; the sub-records of the other workloads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--sub-steps", "2", "--e2e", "0", "--cpu-planes", "8"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "co_bounds", "kernel_ms", "peak_achievable"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.05 < rf["frac"] < 1.0
+    if rf["traffic"] is not None:                    # quoted only when profiles/traffic.json was taken on exactly these kernel sources
+        assert rf["traffic"] > rf["algorithmic_bytes_per_launch"] * 0.9 and rf["co_bounds"]["waves_per_simd"] == 3
+    else:
+        assert "not quoted" in rf["traffic_source"] or "unreadable" in rf["traffic_source"]
+    for k in ("h2", "h3", "h3_batched", "n8_rank_shape"):
+        assert d[k]["ms_per_step"] > 0, k
+    assert d["h3_batched"]["ms_per_step"] < d["h3"]["ms_per_step"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["h2"]["value"] > 0 and cb["h3"]["value"] > 0
+    assert cb["gpu_vs_oracle_max_abs_err_on_sample"] <= 2e-6
+
+
 def test_bench_multi_rank_code_path_on_one_gpu():
     """`bench.py --gpus 4` launched exactly as the driver does (torch.distributed.run, one process per rank), with all ranks on
     cuda:0 and gloo for the rendezvous / max-over-ranks reductions (LES_BENCH_BACKEND / LES_BENCH_ONE_DEVICE: test hooks, the
