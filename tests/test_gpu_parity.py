@@ -215,7 +215,7 @@ def test_full_size_linearity_in_cost(full):
 # Which kernel serves what: the fixed-point march kernel (csrc/les_march.h) takes every LayerManager cell batch and every
 # whole-image hypothesis slab; everything outside its preconditions runs the fp64 strip kernel (csrc/les_kernels.h).
 # ---------------------------------------------------------------------------------------------------
-def test_gpu_kernel_dispatch(mid, oracle_mod):
+def test_gpu_kernel_dispatch(mid, oracle_mod, capfd):
     from localexpstereo_amd import api, synth
     e = mid.e
     for unit in (5, 15, 25):
@@ -237,12 +237,23 @@ def test_gpu_kernel_dispatch(mid, oracle_mod):
     im = synth.make_guide(H, W, 3)
     vol = synth.make_volume(D, H, W, 5)
     cells = [(0, 0, W, H)]
-    for v, kw, kind in ((vol, {}, 1), (np.where(vol > 0.999, np.nan, vol).astype(np.float32), {}, 0), (vol - 9.0, {}, 0), (vol, {"windR": 8}, 1), (vol, {"windR": 30}, 0)):
+    # ... and the library says so on stderr, once per context and reason (a 2x slower path nobody would otherwise notice)
+    quiet = os.environ.get("LES_HIP_QUIET", "0") not in ("", "0")
+    for v, kw, kind, note in ((vol, {}, 1, None), (np.where(vol > 0.999, np.nan, vol).astype(np.float32), {}, 0, "NaN or infinite"), (vol - 9.0, {}, 0, "below the truncation threshold"),
+                              (vol, {"windR": 8}, 1, None), (vol, {"windR": 30}, 0, "no march kernel for guided-filter radius 15")):
+        capfd.readouterr()
         ee = api.HipCostVolumeEnergy(im, None, v, None, **kw)
         bb = api.Batch(ee, cells, cells)
         assert bb.kernel_kind(0) == kind
+        bb2 = api.Batch(ee, cells, cells)                # a second batch of the same context: no second note
+        bb2.destroy()
         bb.destroy()
         ee.close()
+        err = capfd.readouterr().err
+        if note is None or quiet:
+            assert "strip kernel instead of the march kernel" not in err
+        else:
+            assert err.count("strip kernel instead of the march kernel") == 1 and note in err, err
 
 
 @pytest.fixture()
