@@ -330,7 +330,7 @@ def main():
             out[: saved.shape[0]].copy_(saved)
             del saved
 
-        # ---- end to end (north_star: Adirondack-H wall-clock < 10 s): the MidV3 loop of tools/e2e_bench.py on a synthetic pair
+        # ---- end to end (north_star: Adirondack-H wall-clock < 10 s): the MidV3 loop of tools/e2e_bench.py on a synthetic pair of the Adirondack-H shape
         if args.e2e:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
