@@ -248,6 +248,13 @@ int les_hip_get_stats(les_hip_ctx* ctx, int mode, float* out_host);
 /* Strip geometry the build was compiled with for radius R (0 if unsupported): output columns per
  * workgroup. */
 int les_hip_strip_width(int R);
+/* Bytes of the TILED copy of view `mode`'s cost volume ([H][ceil(W/8)][D][8] floats: 8 columns x all slices contiguous), which the
+ * march kernel's gather reads for planes that are steep along x (their two taps per pixel then lie within a few contiguous 32-byte
+ * pieces instead of one 128-byte line per slice of [D][H][W]).  0 when the context holds none: LES_HIP_TILED=0, the image-based energy,
+ * a view on the strip kernel, a copy of 2^30 floats or more, or an allocation that failed -- every plane then gathers from [D][H][W]
+ * (identical costs).  A second resident copy of the volume is the price: this many bytes per view.
+ * (no reference counterpart; LES/CostVolumeEnergy.h:73-96 reads its cv::Mat volume in place) */
+size_t les_hip_tiled_volume_bytes(les_hip_ctx* ctx, int mode);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
     "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
-    "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width",
+    "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width", "les_hip_tiled_volume_bytes",
     "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_exchange_create", "les_hip_exchange_destroy", "les_hip_exchange_slot_floats",
     "les_hip_exchange_pack", "les_hip_exchange_unpack", "les_hip_exchange_tiles", "les_hip_fill_out_of_view", "les_hip_convert_volume_l2r", "les_hip_consistency_check", "les_hip_post_process",
 ]
@@ -117,6 +117,7 @@ def load(path=None):
         "les_hip_memset": (ci, [vp, vp, ci, C.c_size_t]),
         "les_hip_get_stats": (ci, [vp, ci, vp]),
         "les_hip_strip_width": (ci, [ci]),
+        "les_hip_tiled_volume_bytes": (C.c_size_t, [vp, ci]),
         "les_hip_fill_out_of_view": (ci, [vp, ci, ci, ci, ci, ci, vp]),
         "les_hip_convert_volume_l2r": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     }
@@ -389,6 +390,10 @@ class HipCostVolumeEnergy:
 
     def strip_width(self):
         return self.L.les_hip_strip_width(self.params.windR // 2)
+
+    def tiled_volume_bytes(self, mode=0):
+        """Bytes of the tiled copy of the view's volume the gather of steep planes reads (0: none, see include/localexp_hip.h)."""
+        return int(self.L.les_hip_tiled_volume_bytes(self.h, mode))
 
     def stats(self, mode=0):
         out = np.empty((self.H, self.W, 3, 4), np.float32)

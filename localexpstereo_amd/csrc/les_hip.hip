@@ -167,6 +167,7 @@ struct ViewData {
     // march kernel (les_march.h): guide as signed bytes, statistics in its format, cost range of the volume
     uint32_t* ipk8 = nullptr;
     float* mstats = nullptr;
+    float* vol_t = nullptr;              // the volume once more, tiled [H][ceil(W/8)][D][8]: the taps of steep planes (les_march.h, role A's KIND 5); null when not built
     bool march_ok = false;               // volume finite, range condition met, tables built
     les::MarchView mv = {};
 };
@@ -544,6 +545,25 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     mv.qscale = (float)((double)(1 << les::kMarchS2) / (255.0 * scale));
     mv.kmu = (float)(1.0 / ((double)(1ll << les::kMarchMB) * 255.0));
     mv.raw_off = nullptr;
+    mv.vol_t = nullptr;
+    // The tiled copy for the taps of planes that are steep along x (a second resident copy of the volume: 1.5 GB more at 1500 x 1000 x 256, of
+    // 288 GB).  Optional: LES_HIP_TILED=0 turns it off, a failing allocation or a copy of 2^30 floats or more (32-bit tap offsets) leaves it out
+    // -- such planes then gather from [D][H][W] as every other plane does (same values, more HBM traffic).
+    if (!c->naive && v.vol) {
+        const char* e = getenv("LES_HIP_TILED");
+        const unsigned long long nt = (unsigned long long)H * (unsigned long long)((W + 7) / 8) * 8ull * (unsigned long long)c->p.D;
+        if (!(e && atoi(e) == 0) && nt < (1ull << 30)) {
+            if (v.vol_t) { (void)hipFree(v.vol_t); v.vol_t = nullptr; }
+            if (hipMalloc((void**)&v.vol_t, nt * sizeof(float)) == hipSuccess) {
+                hipLaunchKernelGGL(les::les_tile_volume_kernel, dim3((unsigned)(((W + 7) / 8 * 8 + 63) / 64), (unsigned)H), dim3(256), 0, cur_stream(c), v.vol, v.vol_t, c->p.D, H, W);
+                HIPCHECK(hipGetLastError());
+                mv.vol_t = v.vol_t;
+            } else {
+                (void)hipGetLastError();
+                v.vol_t = nullptr;
+            }
+        }
+    }
     v.mv = mv;
     v.march_ok = true;
     return LES_HIP_OK;
@@ -699,6 +719,7 @@ void les_hip_destroy(les_hip_ctx* c)
         if (c->v[m].feat) (void)hipFree(c->v[m].feat);
         if (c->v[m].ipk8) (void)hipFree(c->v[m].ipk8);
         if (c->v[m].mstats) (void)hipFree(c->v[m].mstats);
+        if (c->v[m].vol_t) (void)hipFree(c->v[m].vol_t);
     }
     for (les_hip_scratch* sc : c->own_scratch) les_hip_scratch_destroy(sc);
     c->own_scratch.clear();
@@ -1593,6 +1614,12 @@ int les_hip_memset(les_hip_ctx* c, void* d, int value, size_t bytes)
     if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
     HIPCHECK(hipMemsetAsync(d, value, bytes, cur_stream(c)));
     return LES_HIP_OK;
+}
+
+size_t les_hip_tiled_volume_bytes(les_hip_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 1 || !c->v[mode].vol_t) return 0;
+    return (size_t)c->p.H * (size_t)((c->p.W + 7) / 8) * 8u * (size_t)c->p.D * sizeof(float);
 }
 
 int les_hip_get_stats(les_hip_ctx* c, int mode, float* out)

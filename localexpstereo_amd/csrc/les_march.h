@@ -94,7 +94,19 @@ struct MarchView {
     // float offset of call i's filterRect patch in it (row stride = filterRect width), vmin = 0, th_col -> th_color + th_grad.
     // Null for a cost-volume context.
     const long long* raw_off;
+    // the same volume once more in a TILED layout, [H][ceil(W/8)][D][8] (8 columns x all slices contiguous: 32 bytes per slice), or null:
+    // what the taps of a slanted plane read (role A's KIND 5).  In [D][H][W] the two taps of 8 neighbouring pixels lie in 8|a| + 2 different slices,
+    // i.e. in as many 128-byte lines of which 4 .. 32 bytes are used; here they lie within (8|a| + 2) x 32 contiguous bytes.
+    const float* vol_t;
 };
+// planes with |a| (disparity change per column) at or above this take their taps from the tiled copy: whole-image slabs and wide cells (one job
+// per workgroup) / the two-job geometry of the small cells
+#ifndef LES_TILED_MIN_SLOPE_WIDE
+#define LES_TILED_MIN_SLOPE_WIDE 0.05f
+#endif
+#ifndef LES_TILED_MIN_SLOPE
+#define LES_TILED_MIN_SLOPE 0.125f
+#endif
 
 template <int R, int WGC, int NJ, int BY>
 struct MarchCfg {
@@ -427,6 +439,9 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const bool inv_job = fronto && modes == 2 && !view.raw_off;
         int slice_lo = 0;
         const bool tame = !fronto && !view.raw_off && march_plane_short_gather(g, plane, job, R, &slice_lo);
+        const uint32_t W8 = ((uint32_t)g.W + 7u) >> 3;
+        // (tiled taps: 32-bit byte offsets from the base of the copy -- the whole copy below 2^30 floats)
+        const bool tiled = tame && view.vol_t && fabsf(plane.x) >= (NJ == 1 ? LES_TILED_MIN_SLOPE_WIDE : LES_TILED_MIN_SLOPE) && (unsigned long long)g.H * W8 * 8ull * (unsigned long long)g.D < (1ull << 30);
         // Columns outside the clip contribute count 0: their factor is 0 and their addend the bare 1.5 * 2^23 (per-lane constants, so
         // the column half of the clip test costs nothing per row; the row half is one v_and with a scalar mask)
         const float spj = !col_in ? 0.0f : (inv_job ? 0.0f : view.sp);
@@ -438,13 +453,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         //   KIND 2  general plane: taps / weight / mode per lane and row
         //   KIND 3  image-based energy: one tap into the call's raw-cost patch (any plane; no truncation, no invalid mode)
         //   KIND 4  general plane with the short gather (march_plane_short_gather): two taps of the clamped disparity per pixel, no special cases
+        //   KIND 5  the same from the tiled copy of the volume (MarchView::vol_t): planes steep along x
         // For fronto-parallel planes everything but the clip test is per-job, the row bases are scalars and the loads need no
         // address arithmetic.
         auto march_a = [&](auto kind_tag) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_tag)::value;
         GatherPrep gp[BY];
         float v0[BY], v1[BY];
-        float f1r[BY];                   // KIND 4: interpolation weight of the second tap
+        float f1r[BY];                   // KIND 4, 5: interpolation weight of the second tap
         uint32_t gw[BY];
         uint32_t rowbits = 0, rowbits_nx = 0;   // bit i = p-row i of the block (in flight / being loaded) is inside the clip and the march
         // Row scalars of block b: lane i < BY computes those of p-row b*BY + i, v_readlane hands them to the wave as scalars.
@@ -454,15 +470,21 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         int nx_rowB = 0;                 // byte offset of the (clamped) image row
         float nx_dbase = 0.0f;
         int nx_rowraw = 0;               // KIND 3: byte offset of the row in the call's patch
+        int nx_rowT = 0;                 // KIND 5: byte offset of the (clamped) image row's tiles in the tiled copy
         const int fw = job.cx1 - job.cx0;
         // descriptors: the volume slice(s) of a fronto-parallel plane / the call's raw-cost patch (its column 0 = image column cx0)
         const float* v0base = view.vol + (size_t)i0s;
         if constexpr (KIND == 3) v0base = view.vol + view.raw_off[job.plane_idx] - job.cx0;
         if constexpr (KIND == 4) v0base = view.vol + (size_t)slice_lo * (size_t)HWu;          // the lowest slice the job touches: every tap lies within 2^30 bytes of it
+        if constexpr (KIND == 5) v0base = view.vol_t;
         // (KIND 4: masked rows beyond the march compute addresses from a disparity outside the tame range -- the descriptor must end where
         //  the volume ends, so that whatever passes its range check is inside the allocation)
         const unsigned long long rest4 = (unsigned long long)(g.D - slice_lo) * (unsigned long long)imgB;
-        const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : (KIND == 4 ? (uint32_t)(rest4 < 0xfffffffcull ? rest4 : 0xfffffffcull) : imgB));
+        const uint32_t tiledB = (uint32_t)g.H * W8 * 32u * (uint32_t)g.D;                // bytes of the tiled copy (KIND 5 only runs when this is below 2^32)
+        const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : (KIND == 4 ? (uint32_t)(rest4 < 0xfffffffcull ? rest4 : 0xfffffffcull) : (KIND == 5 ? tiledB : imgB)));
+        // KIND 5: byte offset of (slice 0, image row 0, this lane's column) in the tiled copy, bytes per image row of tiles, the slice the range starts at
+        const uint32_t tcol = (((uint32_t)sx >> 3) * (uint32_t)g.D * 8u + ((uint32_t)sx & 7u)) * 4u;
+        const uint32_t trowB = W8 * (uint32_t)g.D * 32u;
         const int dsub = g.D0 - slice_lo;                                 // KIND 4: slice index relative to the descriptor base
         const BufRsrc rs_v1 = make_buf(view.vol + (size_t)i1s, imgB);
         auto prep = [&](int b) __attribute__((always_inline)) {
@@ -473,6 +495,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             rowbits_nx = ballot_low(t < Ttot && gy >= job.cy0 && gy < job.cy1, BY);
             if constexpr (KIND == 3) nx_rowraw = (sy - job.cy0) * fw * 4;
             else nx_dbase = plane.y * (float)sy + plane.z;              // b*y + c, LES/CostVolumeEnergy.h:73
+            if constexpr (KIND == 5) nx_rowT = (int)((uint32_t)sy * trowB);
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;
@@ -495,6 +518,16 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                 const uint32_t e = mad_u24((int)df + dsub, (int)HWu, sx);
                 v0[i] = buf_load<float>(rs_v0, e << 2, ro);
                 v1[i] = buf_load<float>(rs_v0, (e << 2) + (f1r[i] > 0.0f ? imgB : 0u), ro);
+            } else if constexpr (KIND == 5) {
+                // the same two taps at their addresses in the tiled copy: slice d0 of this pixel's tile is 32 d0 bytes into the tile, slice d0 + 1 the next 32
+                const float d = g_ax + readlane_f32(nx_dbase, i);
+                const float dc = med3_f32(d, 0.0f, g.maxd);
+                const float df = floorf(dc);
+                f1r[i] = dc - df;
+                const uint32_t e = (((uint32_t)(int)df + (uint32_t)g.D0) << 5) + tcol;
+                const uint32_t rt = (uint32_t)readlane_i32(nx_rowT, i);
+                v0[i] = buf_load<float>(rs_v0, e, rt);
+                v1[i] = buf_load<float>(rs_v0, e + (f1r[i] > 0.0f ? 32u : 0u), rt);
             } else {
                 const float d_base = readlane_f32(nx_dbase, i);
                 const bool inside = col_in && ((rowbits_nx >> i) & 1u);
@@ -534,7 +567,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                                 if constexpr (KIND == 1) C = f0s * v0[i] + f1s * v1[i];
                                 const float p = min_f32_finite(C, g.th_col);
                                 pi = (__float_as_int(fmaf(p, spj, pmj)) - kMarchMagicBits) & sbfe1(rowbits, i);
-                            } else if constexpr (KIND == 4) {
+                            } else if constexpr (KIND == 4 || KIND == 5) {
                                 const float f0 = 1.0f - f1r[i];
                                 const float C = f0 * v0[i] + f1r[i] * v1[i];
                                 const float p = min_f32_finite(C, g.th_col);
@@ -565,7 +598,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
                         int4 (*TB)[PCOLS] = s_T2[(decltype(utag)::value + UN - 2 % UN) % UN][slot];
                         // (general planes in the two-job geometry: role C prefixes its own block one tick later instead, see there)
                         const bool da = k < nblk, db = !(NJ > 1 && KIND == 2) && k >= 2 && k < nblk + 2;
-                        constexpr bool kPair = KIND != 2 && KIND != 4;       // (the general-plane marches hold two taps and a weight per row in flight: the paired pass, 32 more registers, would spill)
+                        constexpr bool kPair = KIND != 2 && KIND != 4 && KIND != 5;       // (the general-plane marches hold two taps and a weight per row in flight: the paired pass, 32 more registers, would spill)
                         if (kPair && da && db) march_prefix_pair<BY, PCOLS>(s_T1[k & 1][slot], TB, ci0, lane);
                         else {
                             if (da) { wave_sync(); march_prefix_tile<BY, PCOLS>(s_T1[k & 1][slot], ci0, lane); }
@@ -581,6 +614,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         if (view.raw_off) march_a(std::integral_constant<int, 3>{});
         else if (fronto && f1s == 0.0f) march_a(std::integral_constant<int, 0>{});
         else if (fronto) march_a(std::integral_constant<int, 1>{});
+        else if (tiled) march_a(std::integral_constant<int, 5>{});
         else if (tame) march_a(std::integral_constant<int, 4>{});
         else march_a(std::integral_constant<int, 2>{});
     } else if (role == 1 && LES_LAB_ROLE_ON(2)) {
@@ -859,6 +893,20 @@ __global__ void les_march_stats_kernel(const double* __restrict__ hs, const uint
     ipk8[px] = b0 | (b1 << 8) | (b2 << 16);
     const float dmax = fmaxf(fmaxf((float)irr, (float)igg), (float)ibb);
     if (dmax > 0.0f) atomicMax(inv_diag_max, __float_as_uint(dmax));
+}
+
+// the tiled copy of the volume (MarchView::vol_t): dst[((y W8 + x / 8) D + d) 8 + x % 8] = src[(d H + y) W + x]; columns beyond W are zero.
+// One workgroup = one image row x 64 columns (8 tiles) x all slices: reads 256 contiguous bytes per slice, writes 8 x 32 bytes (the tiles'
+// slices are filled in order, so the 32-byte pieces of a line meet in the L2 before it is written back).
+__global__ void les_tile_volume_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W)
+{
+    const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)blockIdx.y;
+    const int W8 = (W + 7) >> 3;
+    if (x >= W8 * 8) return;
+    const size_t HW = (size_t)H * W;
+    float* o = dst + (((size_t)y * W8 + (size_t)(x >> 3)) * D) * 8 + (x & 7);
+    for (int d = (int)(threadIdx.x >> 6); d < D; d += (int)(blockDim.x >> 6))
+        o[(size_t)d * 8] = x < W ? src[(size_t)d * HW + (size_t)y * W + x] : 0.0f;
 }
 
 // min of a float array and whether every element is finite: part[2*b] = min bits of block b, part[2*b+1] = 1 if a non-finite value was seen

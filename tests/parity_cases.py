@@ -291,6 +291,43 @@ def case_plane_slabs(pr, n=5, mode=1):
     return worst
 
 
+def case_tiled_taps(lib, H=150, W=203, D=24, monkeypatch=None):
+    """Steep planes take their two taps from the tiled copy of the volume ([H][W/8][D][8], csrc/les_march.h role A KIND 5), all others from
+    [D][H][W]: the same values at other addresses, so a context with the copy (default) and one without (LES_HIP_TILED=0) agree BIT FOR BIT,
+    and both agree with the oracle.  W is not a multiple of the tile width; planes leave the disparity range on both sides (clamped taps),
+    slopes on both sides of the thresholds, both views, whole-image slabs (wide jobs) and layer-0 cells (two narrow jobs per workgroup)."""
+    rng = np.random.default_rng(5)
+    n = 10
+    planes = np.zeros((n, 4), np.float32)
+    planes[:, 0] = [0.5, -0.5, 0.3, -0.26, 0.13, -0.12, 0.06, -0.04, 0.9, -1.7]
+    planes[:, 1] = rng.uniform(-0.2, 0.2, n)
+    planes[:, 2] = rng.uniform(0.2, 0.8, n) * (D - 1) - planes[:, 0] * W / 2 - planes[:, 1] * H / 2
+    outs, worst = [], 0.0
+    for tiled in ("1", "0"):
+        monkeypatch.setenv("LES_HIP_TILED", tiled)            # read when a context builds its march tables
+        pr = synth_pair(lib, H, W, D)
+        try:
+            assert [pr.e.tiled_volume_bytes(m) for m in (0, 1)] == ([H * ((W + 7) // 8) * 8 * D * 4] * 2 if tiled == "1" else [0, 0])
+            res = [run_slabs(pr, planes, mode=m, check=True) for m in (0, 1)]
+            layer = om.Layer(pr.W, pr.H, 20, 15)
+            cells = layer.sets[3]
+            cp = np.tile(planes, (len(cells) // n + 1, 1))[:len(cells)]
+            res.append(pr.e.unary_batch(layer.filter[cells], layer.shared[cells], cp, mode=0, check=True))
+            if tiled == "1":
+                ref = pr.o.unary_batch(layer.filter[cells], layer.shared[cells], cp, mode=0, check=True)
+                worst = max(worst, compare_maps(res[2], ref))
+                for m in (0, 1):
+                    for i in range(n):
+                        ref = pr.o.unary((0, 0, pr.W, pr.H), (0, 0, pr.W, pr.H), tuple(planes[i]), mode=m, check=True)
+                        worst = max(worst, compare_maps(res[m][i], ref))
+            outs.append(res)
+        finally:
+            pr.close()
+    for m in (0, 1, 2):
+        assert np.array_equal(outs[0][m].view(np.uint32), outs[1][m].view(np.uint32)), "tiled and planar taps must give identical costs"
+    return worst
+
+
 def case_grouped_slots(pr, unit=14, set_index=3, slots=3, mode=0):
     """Several proposal slots of one disjoint set in ONE launch (les_hip_batch_create with out_slabs = cells per slot): slot s of every cell
     into cost map s.  Every map must equal the single-slot lock-step of the oracle, written pixels and sentinels included."""

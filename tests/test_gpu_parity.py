@@ -300,6 +300,10 @@ def test_gpu_march_vs_strip_kernel(oracle_mod, monkeypatch):
         assert np.max(np.abs(a[v] - b[v])) <= 1e-6
 
 
+def test_gpu_tiled_copy_taps_equal_planar_taps(oracle_mod, monkeypatch):
+    assert pc.case_tiled_taps(None, H=300, W=701, D=40, monkeypatch=monkeypatch) <= pc.TIGHT
+
+
 def test_gpu_unary_one_reentrant_16_threads(mid):
     """The operator is const and is called from an OpenMP team in the reference (LES/FastGCStereo.h:30-49, one Reusable per
     thread): 16 host threads, each with its own scratch handle, evaluate disjoint cells concurrently (ctypes releases the GIL),

@@ -98,6 +98,10 @@ def test_sim_plane_slabs(cones):
     pc.case_plane_slabs(cones, n=3)
 
 
+def test_sim_tiled_copy_taps_equal_planar_taps(sim_lib, oracle_mod, monkeypatch):
+    assert pc.case_tiled_taps(sim_lib, H=110, W=139, D=12, monkeypatch=monkeypatch) <= pc.TIGHT
+
+
 def test_sim_grouped_slots(cones):
     worst, kind = pc.case_grouped_slots(cones, unit=10, set_index=2, slots=3)
     assert kind == 1
