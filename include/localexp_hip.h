@@ -49,7 +49,10 @@ typedef struct {
     float min_disparity;          /* MIN_DISPARITY                                                     */
     int device;                   /* HIP device ordinal                                                */
     int volumes_on_device;        /* != 0: volL/volR are device pointers owned by the caller (shared, not
-                                     copied -- like the ref-counted cv::Mat headers, :20-21)           */
+                                     copied -- like the ref-counted cv::Mat headers, :20-21).  Their
+                                     contents must not change while the context exists: the cost range
+                                     of the fixed-point kernel and the tiled copy that steep planes
+                                     gather from (les_hip_tiled_volume_bytes) are taken at creation   */
 } les_hip_params;
 
 /* replaces: CostVolumeEnergy::CostVolumeEnergy (LES/CostVolumeEnergy.h:16-43) including the two
