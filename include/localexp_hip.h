@@ -192,6 +192,19 @@ long long les_hip_batch_max_cell_nodes(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
                                double* d_flows);
 
+/* The same replacement (LES/FastGCStereo.h:553-559 on the graph of :411-551) for cells of ANY size -- the coarse layers, whose cells
+ * (129 x 129 ... 404 x 387 nodes at the Adirondack shape) do not fit a workgroup's LDS: the graphs stay in device memory, a cell is
+ * cut into tiles of <= 1920 nodes, one workgroup per tile, and the lock-step is a sequence of launches in which every cell moves
+ * through exact relabelling / discharge phases on its own (region-parallel push-relabel, csrc/les_maxflow_tiled.h).  Same payload,
+ * masks, status (0 = solved, non-zero = launch limit reached: cut that cell with the host solver) and flows as
+ * les_hip_batch_solve_graphs; same cut (SINK side = the nodes that can still reach the sink).  Bit-reproducible from run to run.
+ * d_workspace: caller-owned device scratch of at least les_hip_batch_tiled_workspace_bytes(batch) bytes, 256-byte aligned, not
+ * shared between host threads that call concurrently (109 bytes per graph node + 64 per cell).  The call synchronises the calling
+ * thread's stream (it reads "cells done" between groups of launches); launches_out (or NULL): launches enqueued. */
+long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* batch);
+int les_hip_batch_solve_graphs_tiled(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
+                                     double* d_flows, void* d_workspace, long long workspace_bytes, int* launches_out);
+
 /* replaces: the mask updates after a graph cut -- subProposalCost.copyTo(subCurrentCost, updateMask);
  * subCurrentLabeling.setTo(label, updateMask) (LES/FastGCStereo.h:61-62) -- for all cells of the batch.  d_masks: one
  * byte per graph node in the payload order of les_hip_batch_expansion_graph (non-zero = the node takes the proposal). */

@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_set_thread_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_solve_graphs", "les_hip_batch_solve_graphs_tiled", "les_hip_batch_tiled_workspace_bytes", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width", "les_hip_tiled_volume_bytes",
     "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_exchange_create", "les_hip_exchange_destroy", "les_hip_exchange_slot_floats",
@@ -80,6 +80,8 @@ def load(path=None):
         "les_hip_batch_apply_masks": (ci, [vp, vp, vp, vp, vp, vp, vp]),
         "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
+        "les_hip_batch_solve_graphs_tiled": (ci, [vp, vp, vp, vp, vp, vp, vp, C.c_longlong, C.POINTER(ci)]),
+        "les_hip_batch_tiled_workspace_bytes": (C.c_longlong, [vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_calib_copy_wide": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_exchange_create": (ci, [vp, ci, ci, ci, vp, vp, C.POINTER(vp)]),
@@ -304,6 +306,20 @@ class Batch:
         cell, optional) are device pointers."""
         self.e._chk(self.e.L.les_hip_batch_solve_graphs(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
                                                         C.c_void_p(int(flows_dev)) if flows_dev else None))
+
+    def tiled_workspace_bytes(self):
+        """Device scratch les_hip_batch_solve_graphs_tiled needs for this batch (109 bytes per graph node)."""
+        return int(self.e.L.les_hip_batch_tiled_workspace_bytes(self.h))
+
+    def solve_graphs_tiled(self, payload_dev, masks_dev, status_dev, workspace_dev, workspace_bytes, flows_dev=None):
+        """The same for cells of any size (the coarse layers): region-parallel push-relabel over tiles of the cells, graphs resident in
+        device memory (csrc/les_maxflow_tiled.h).  workspace: 256-byte aligned device scratch of tiled_workspace_bytes().  Synchronises
+        the calling thread's stream.  -> launches enqueued."""
+        n = C.c_int(0)
+        self.e._chk(self.e.L.les_hip_batch_solve_graphs_tiled(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
+                                                              C.c_void_p(int(flows_dev)) if flows_dev else None, C.c_void_p(int(workspace_dev)),
+                                                              C.c_longlong(int(workspace_bytes)), C.byref(n)))
+        return n.value
 
     def apply_masks(self, planes_dev, masks_dev, cur_dev, prop_dev, labels_dev):
         """Mask updates of a lock-step on the device (LES/FastGCStereo.h:61-62); masks in graph-node order."""

@@ -35,7 +35,7 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("les_hip.hip", "les_kernels.h", "les_march.h", "les_march_lab.h", "les_propose.h", "les_post.h", "les_pairwise.h", "les_maxflow.h", "les_simt.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("les_hip.hip", "les_kernels.h", "les_march.h", "les_march_lab.h", "les_propose.h", "les_post.h", "les_pairwise.h", "les_maxflow.h", "les_maxflow_tiled.h", "les_simt.h")]
     srcs.append(os.path.join(ROOT, "include", "localexp_hip.h"))
     if not force and _newer(HIP_SO, srcs):
         return HIP_SO

@@ -11,6 +11,7 @@
 #include "les_post.h"
 #include "les_pairwise.h"
 #include "les_maxflow.h"
+#include "les_maxflow_tiled.h"
 
 #include <algorithm>
 #include <atomic>
@@ -198,6 +199,7 @@ struct les_hip_ctx {
     unsigned long long gen = 0;          // unique id of this context: thread-local bindings compare it, not the address (an address can be reused)
     std::vector<les_hip_scratch*> idle_scratch;  // hidden scratches whose owning thread has exited, ready for the next new thread
     bool maxflow_lds_ready = false;      // the per-device dynamic-LDS opt-in of les_maxflow_kernel has been made on this context's device
+    bool maxflow_tiled_lds_ready = false;   // ... and of les_maxflow_tiled_kernel
     std::vector<les_hip_scratch*> own_scratch;   // scratch objects created behind les_hip_unary_one (one per calling thread), freed with the context
 };
 
@@ -229,6 +231,11 @@ struct les_hip_batch {
     long long graph_nodes = 0;
     long long* d_graph_off = nullptr;
     double* d_flow0 = nullptr;           // n * wta_chunks partial sums
+    // tiled device max-flow (les_maxflow_tiled.h): the cells cut into tiles, built on first use (two host threads -- the two views -- may share a batch)
+    mutable std::mutex mt_mu;
+    mutable les::MtTile* d_mt_tiles = nullptr;
+    mutable int* d_mt_tiles_per_cell = nullptr;
+    mutable int mt_ntiles = -1;          // -1: not built yet
 };
 
 // Caller-owned scratch of the one-call operator (the reference's `Reusable`, LES/StereoEnergy.h:616-623): its own stream, a
@@ -853,6 +860,8 @@ void les_hip_batch_destroy(les_hip_batch* b)
     if (b->d_targets) (void)hipFree(b->d_targets);
     if (b->d_graph_off) (void)hipFree(b->d_graph_off);
     if (b->d_flow0) (void)hipFree(b->d_flow0);
+    if (b->d_mt_tiles) (void)hipFree(b->d_mt_tiles);
+    if (b->d_mt_tiles_per_cell) (void)hipFree(b->d_mt_tiles_per_cell);
     if (b->rs.disp) (void)hipFree(b->rs.disp);
     if (b->rs.idx) (void)hipFree(b->rs.idx);
     if (b->rs.state) (void)hipFree(b->rs.state);
@@ -1042,6 +1051,130 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     else
         hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     HIPCHECK(hipGetLastError());
+    return LES_HIP_OK;
+}
+
+// ---- tiled device max-flow: cells of any size (les_maxflow_tiled.h) ------------------------------------------------------------
+namespace {
+// Cuts a w x h cell into tiles of at most kMtMaxTileNodes nodes and kMtMaxSide a side: the fewest tiles, then the most square ones.
+void mt_partition(int w, int h, int& tw, int& th)
+{
+    long long best = -1;
+    tw = th = 1;
+    for (int ntx = (w + les::kMtMaxSide - 1) / les::kMtMaxSide; ntx <= w; ntx++) {
+        const int cw = (w + ntx - 1) / ntx;
+        const int chmax = std::min(les::kMtMaxSide, les::kMtMaxTileNodes / cw);
+        if (chmax < 1) continue;
+        const int nty = (h + chmax - 1) / chmax;
+        const int ch = (h + nty - 1) / nty;
+        const long long tiles = (long long)ntx * nty;
+        const long long score = tiles * 1000 + std::abs(cw - ch);            // fewest tiles first
+        if (best < 0 || score < best) { best = score; tw = cw; th = ch; }
+        if (cw * 2 < ch) break;                                              // narrower tiles only get worse from here
+    }
+}
+int mt_build_tiles(const les_hip_batch* b)
+{
+    std::lock_guard<std::mutex> lk(b->mt_mu);
+    if (b->mt_ntiles >= 0) return LES_HIP_OK;
+    std::vector<les::MtTile> tiles;
+    std::vector<int> per_cell((size_t)std::max(1, b->n), 0);
+    // tiles of one cell are neighbours in the launch order (they share halos in L2), cells in batch order
+    for (int i = 0; i < b->n; i++) {
+        const int w = std::max(0, b->targets[i].w), h = std::max(0, b->targets[i].h);
+        if (w == 0 || h == 0) continue;
+        int tw, th;
+        mt_partition(w, h, tw, th);
+        for (int y0 = 0; y0 < h; y0 += th)
+            for (int x0 = 0; x0 < w; x0 += tw) {
+                tiles.push_back(les::MtTile{i, x0, y0, std::min(tw, w - x0), std::min(th, h - y0), w, h, 0, b->graph_off[i], 0});
+                per_cell[i]++;
+            }
+    }
+    les::MtTile* d_t = nullptr;
+    int* d_p = nullptr;
+    if (hipMalloc((void**)&d_t, std::max<size_t>(1, tiles.size()) * sizeof(les::MtTile)) != hipSuccess ||
+        hipMalloc((void**)&d_p, per_cell.size() * sizeof(int)) != hipSuccess ||
+        (tiles.size() && hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(les::MtTile), hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemcpy(d_p, per_cell.data(), per_cell.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d_t) (void)hipFree(d_t);
+        if (d_p) (void)hipFree(d_p);
+        return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: tile table allocation failed");
+    }
+    b->d_mt_tiles = d_t;
+    b->d_mt_tiles_per_cell = d_p;
+    b->mt_ntiles = (int)tiles.size();
+    return LES_HIP_OK;
+}
+}  // namespace
+
+long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* b)
+{
+    if (!b) return 0;
+    return (long long)les::mt_layout(std::max<long long>(1, b->graph_nodes), std::max(1, b->n)).total;
+}
+
+int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows,
+                                     void* d_workspace, long long workspace_bytes, int* launches_out)
+{
+    if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
+    if (!c || !b || !d_payload || !d_masks || !d_status || !d_workspace) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (launches_out) *launches_out = 0;
+    if (b->n == 0) return LES_HIP_OK;
+    if (workspace_bytes < les_hip_batch_tiled_workspace_bytes(b))
+        return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs_tiled: workspace of %lld bytes, %lld needed (les_hip_batch_tiled_workspace_bytes)", workspace_bytes,
+                    les_hip_batch_tiled_workspace_bytes(b));
+    if (((uintptr_t)d_workspace & 255) != 0) return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs_tiled: the workspace must be 256-byte aligned");
+    if (b->graph_nodes >= (1ll << 31) - 16) return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs_tiled: %lld graph nodes exceed the 32-bit height range", b->graph_nodes);
+    int rc = mt_build_tiles(b);
+    if (rc) return rc;
+#if !defined(LES_SIM)
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->maxflow_tiled_lds_ready) {
+            HIPCHECK(hipSetDevice(c->p.device));
+            const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)les::kMtLdsBytes);
+            if (arc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: device max-flow unavailable on device %d (hipFuncSetAttribute max dynamic LDS: %s); cut on the host",
+                                               c->p.device, hipGetErrorString(arc));
+            c->maxflow_tiled_lds_ready = true;
+        }
+    }
+#endif
+    hipStream_t st = cur_stream(c);
+    les::MtArgs a;
+    a.cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
+    a.offsets = b->d_graph_off;
+    a.payload = d_payload;
+    a.tiles = b->d_mt_tiles;
+    a.ws = reinterpret_cast<char*>(d_workspace);
+    a.nodes = b->graph_nodes;
+    a.ncells = b->n;
+    a.K = 8; a.S = 12;                                     // short sweeps, a dozen of them between exact relabellings (measured: K = 8 / 16 / 32 / 64 -> 4.5 / 5.2 / 6.8 / 9.7 ms on a hard layer-1 lock-step)
+    a.max_launches = 2000;
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_K")) a.K = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_S")) a.S = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) a.max_launches = std::max(1, atoi(ev));      // tests of the callers' host fall-back
+    a.masks = d_masks;
+    a.status = d_status;
+    a.flows = d_flows;
+    hipLaunchKernelGGL(les::les_maxflow_tiled_init_kernel, dim3((b->n + 255) / 256), dim3(256), 0, st, a.ws, a.nodes, a.ncells, b->d_mt_tiles_per_cell, d_status, d_flows);
+    HIPCHECK(hipGetLastError());
+    // Launches are enqueued in groups; after each group the host reads "cells done" (the only synchronisation).  Launches that come
+    // after the last cell finished return at once.
+    int total = 0, group = 12;
+    for (;;) {
+        for (int i = 0; i < group; i++)
+            hipLaunchKernelGGL(les::les_maxflow_tiled_kernel, dim3(std::max(1, b->mt_ntiles)), dim3(les::kMtThreads), les::kMtLdsBytes, st, a);
+        total += group;
+        HIPCHECK(hipGetLastError());
+        les::MtHeader hdr;
+        HIPCHECK(hipMemcpyAsync(&hdr, d_workspace, sizeof(hdr), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (hdr.cells_done >= b->n) break;
+        if (total >= a.max_launches + group) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: %d of %d cells still open after %d launches", b->n - hdr.cells_done, b->n, total);
+        group = 16;
+    }
+    if (launches_out) *launches_out = total;
     return LES_HIP_OK;
 }
 

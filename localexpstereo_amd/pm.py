@@ -205,8 +205,18 @@ class PMRunner:
         # device_cuts: cells small enough for a workgroup's LDS (the finest layer) are also CUT on the GPU (les_hip_batch_solve_graphs),
         # so neither their graphs nor their masks cross PCIe and the host cores only see the larger cells.  On by default on a GPU
         # (the simulator build used by the CPU tests would spend minutes in it).
-        if not hasattr(self, "device_cuts"):
-            self.device_cuts = self.device.type == "cuda"
+        # "all" (default on a GPU): the larger cells as well, by the tiled solver (les_hip_batch_solve_graphs_tiled: graphs resident in device
+        # memory, a workgroup per tile); "fine": only the cells that fit the LDS (rounds 2-4); "none": every cut on the host.
+        dc = getattr(self, "device_cuts", None)
+        if dc is None:
+            dc = "all" if self.device.type == "cuda" else "none"     # (the simulator build used by the CPU tests would spend minutes in it)
+        elif dc is True:
+            dc = "all"
+        elif dc is False:
+            dc = "none"
+        if dc not in ("all", "fine", "none"):
+            raise ValueError(f"device_cuts: {dc!r} (all | fine | none)")
+        self.device_cuts = dc
         self._gc_mode = self.mode if mode is None else mode
         self.sync_gc_state()
         pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
@@ -275,12 +285,26 @@ class PMRunner:
                                                          sh.payload.data_ptr(), mode=m, lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"],
                                                          epsilon=p["epsilon"])
                                 on_dev = False
-                                if self.device_cuts and sh.n and sh.batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES:
+                                small = sh.batch.max_cell_nodes <= api.Batch.MAXFLOW_MAX_NODES
+                                if sh.n and (self.device_cuts == "all" or (self.device_cuts == "fine" and small)):
                                     if getattr(self, "_gc_status", None) is None:
                                         nmax = max([1] + [s_.n for layer_ in self.shards for s_ in layer_])
                                         self._gc_status = torch.zeros(nmax, dtype=torch.int32, device=self.device)
                                     st = self._gc_status[: sh.n]
-                                    sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr())
+                                    if small:
+                                        sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr())
+                                    else:
+                                        if getattr(self, "_gc_tiled_ws", None) is None:      # one scratch per runner (= per view and host thread)
+                                            nb = max(s_.batch.tiled_workspace_bytes() for layer_ in self.shards for s_ in layer_
+                                                     if s_.n and s_.batch.max_cell_nodes > api.Batch.MAXFLOW_MAX_NODES)
+                                            self._gc_tiled_ws = torch.empty(nb + 256, dtype=torch.uint8, device=self.device)
+                                        ws = self._gc_tiled_ws
+                                        wp = (ws.data_ptr() + 255) & ~255
+                                        tl0 = time.perf_counter()
+                                        nl = sh.batch.solve_graphs_tiled(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr(), wp, ws.numel() - (wp - ws.data_ptr()))
+                                        self.gc_seconds["tiled_launches"] = self.gc_seconds.get("tiled_launches", 0) + nl
+                                        self.gc_seconds["tiled_locksteps"] = self.gc_seconds.get("tiled_locksteps", 0) + 1
+                                        self.gc_seconds[f"tiled_seconds_layer{li}"] = self.gc_seconds.get(f"tiled_seconds_layer{li}", 0.0) + time.perf_counter() - tl0
                                     on_dev = not bool(st.any().item())          # (the only synchronisation of the lock-step)
                                     if on_dev:
                                         self.gc_seconds["cells_cut_on_device"] = self.gc_seconds.get("cells_cut_on_device", 0) + sh.n

@@ -17,7 +17,7 @@ PARAMS_GF = dict(lambda_=1.0, windR=20, eps=1e-4, alpha=0.9, omega=10.0, th_grad
 
 
 class FastGCStereo:
-    def __init__(self, energy, imL, imR, params, device="cuda", rank=0, world=1, seed=1, host_threads=0):
+    def __init__(self, energy, imL, imR, params, device="cuda", rank=0, world=1, seed=1, host_threads=0, device_cuts=None):
         self.e, self.imL, self.imR, self.p = energy, imL, imR, dict(PARAMS_GF, **params)
         self.device, self.rank, self.world, self.seed = device, rank, world, seed
         self.units, self.table = [], []
@@ -38,7 +38,9 @@ class FastGCStereo:
             self.concurrent_views = v.startswith("concurrent")
             self._swap_view_threads = v == "concurrent-swapped"
         self.host_threads = host_threads         # threads of the host max-flows (0: library default = at most 16)
-        self.device_cuts = None                  # None: cut the cells that fit a workgroup's LDS on the GPU when there is one (pm.PMRunner.begin_gc)
+        # which cells are CUT on the GPU: None / "all" = every layer when there is a GPU (cells that fit a workgroup's LDS by les_maxflow_kernel, larger
+        # ones by the tiled solver, csrc/les_maxflow_tiled.h), "fine" = only the cells that fit the LDS (rounds 2-4), "none" / False = all cuts on the host
+        self.device_cuts = device_cuts
         self._view_groups = None                 # two-view runs on several ranks: one process group per view, created once, destroyed by close()
         self.bytes_exchanged, self.all_gathers = 0, 0       # of the last run(): payload received by this rank in the per-set tile all-gathers, and their number
 
@@ -133,7 +135,7 @@ class FastGCStereo:
         if maxIteration > 0:
             for m in viewModes:
                 if self.device_cuts is not None:
-                    runners[m].device_cuts = bool(self.device_cuts)
+                    runners[m].device_cuts = self.device_cuts
                 runners[m].begin_gc(g, mode=m)
             main_device = torch.cuda.current_device() if torch.device(self.device).type == "cuda" else 0
 

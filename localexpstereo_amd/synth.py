@@ -116,3 +116,45 @@ def ad_volume(imL, imR, D, device):
     return vol
 
 
+
+
+def make_scene_three_surfaces(H, W, D, seed=4242):
+    """The scene of the C++ host demo (localexpstereo_amd/host/DemoScene.h: make_scene) for the Python driver: three large slanted
+    surfaces separated by a vertical and a diagonal boundary, a guide image whose colour follows the surface, and a noisy truncated
+    absolute-difference volume built from the ground truth -- `min(1, 0.12 |d - gt|) * 0.8 + U[0, 0.2)`.  Proposals flip most of a
+    coarse cell at once on it, which is what makes its expansion moves hard for a max-flow code.  Same
+    construction as the C++ one with numpy's generator instead of cv::RNG.  Returns (imL, imR, gt, volL): the right image is the left
+    one warped by the ground truth as in make_scene; volL is float32 [D][H][W]."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    surf = [(0.02, 0.01, 0.25 * D), (-0.03, 0.0, 0.6 * D), (0.0, -0.02, 0.45 * D)]
+    col = np.array([[200, 60, 40], [40, 180, 70], [60, 70, 210]], np.int64)
+    k = np.where(xs < W // 3, 0, np.where(xs + ys // 2 < (2 * W) // 3, 1, 2))
+    gt = np.zeros((H, W), np.float32)
+    for i, (a, b, c) in enumerate(surf):
+        z = (np.float32(a) * xs.astype(np.float32) + np.float32(b) * ys.astype(np.float32)) + np.float32(c)
+        gt = np.where(k == i, z, gt)
+    gt = np.clip(gt, 1.0, D - 2.0).astype(np.float32)
+    wave = (10.0 * np.sin(0.15 * xs + 0.1 * ys)).astype(np.int64)                     # (int) of a double: truncation towards zero
+    noise = np.trunc(rng.uniform(-12.0, 12.0, (H, W, 3))).astype(np.int64)
+    imL = np.clip(col[k] + noise + wave[..., None], 0, 255).astype(np.uint8)
+    imR = np.zeros_like(imL)
+    filled = np.zeros((H, W), bool)
+    order = np.argsort(gt, axis=None)
+    yy, xx = np.unravel_index(order, gt.shape)
+    xr = np.rint(xx - gt[yy, xx]).astype(int)
+    ok = (xr >= 0) & (xr < W)
+    imR[yy[ok], xr[ok]] = imL[yy[ok], xx[ok]]
+    filled[yy[ok], xr[ok]] = True
+    for y in range(H):
+        row = filled[y]
+        if not row.all():
+            idx = np.where(row, np.arange(W), -1)
+            np.maximum.accumulate(idx, out=idx)
+            idx[idx < 0] = np.argmax(row)
+            imR[y] = imR[y, idx]
+    vol = np.empty((D, H, W), np.float32)
+    for d in range(D):
+        e = np.abs(np.float32(d) - gt)
+        vol[d] = np.minimum(np.float32(1.0), np.float32(0.12) * e) * np.float32(0.8) + rng.random((H, W), dtype=np.float32) * np.float32(0.2)
+    return imL, imR, gt, vol

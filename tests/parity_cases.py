@@ -1069,7 +1069,8 @@ def _random_cell_payloads(rng, shapes, dyadic):
     return pays
 
 
-def _solve_cells_on_device(pr, shapes, pays):
+def _solve_cells_on_device(pr, shapes, pays, tiled=False):
+    """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel."""
     H, W = pr.H, pr.W
     rects, x, y, rowh = [], 0, 0, 0
     for (w, h) in shapes:
@@ -1088,7 +1089,12 @@ def _solve_cells_on_device(pr, shapes, pays):
     pay = np.ascontiguousarray(pay.reshape(-1))
     dp, dm, ds, df = api.DeviceBuffer(pr.e, nn * 20), api.DeviceBuffer(pr.e, nn), api.DeviceBuffer(pr.e, 4 * k), api.DeviceBuffer(pr.e, 8 * k)
     dp.upload(pay)
-    batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
+    if tiled:
+        ws = api.DeviceBuffer(pr.e, batch.tiled_workspace_bytes())
+        batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
+        ws.free()
+    else:
+        batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
     pr.e.synchronize()
     status = ds.download((k,), np.int32)
     masks, flows = dm.download((nn,), np.uint8), df.download((k,), np.float64)
@@ -1098,7 +1104,7 @@ def _solve_cells_on_device(pr, shapes, pays):
     return off, status, masks, flows
 
 
-def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45):
+def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45, tiled=False):
     """les_maxflow_kernel against an INDEPENDENT checker (networkx preflow-push + residual reachability), not against the host solver:
       * dyadic capacities (arithmetic exact in float and double): the device mask equals the canonical minimum cut node for node and the
         flow is equal;
@@ -1115,7 +1121,7 @@ def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45):
         if side_hi >= 42:
             shapes[1] = (42, 42)
         pays = _random_cell_payloads(rng, shapes, dyadic)
-        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays)
+        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled)
         assert not status.any(), "a cell hit the iteration limit"
         for i, ((w, h), p) in enumerate(zip(shapes, pays)):
             ref_flow, ref_src = _grid_graph_reference(p, w, h)
@@ -1133,14 +1139,14 @@ def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45):
     return ncells // 2 * 2, total_nodes, total_diff
 
 
-def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40):
+def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40, tiled=False):
     """Cells of at most 4 x 4 nodes: every one of the 2^n labelings is enumerated; the device mask must be THE canonical minimum cut
     (the minimum-capacity labeling whose sink side is the intersection of all minimum sink sides).  Dyadic capacities: exact."""
     rng = np.random.default_rng(seed)
     shapes = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(ncells)]
     shapes[0] = (4, 4)
     pays = _random_cell_payloads(rng, shapes, dyadic=True)
-    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays)
+    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled)
     assert not status.any()
     for i, ((w, h), p) in enumerate(zip(shapes, pays)):
         n = w * h

@@ -24,18 +24,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-from localexpstereo_amd.synth import make_scene, ad_volume      # noqa: E402
+from localexpstereo_amd.synth import make_scene, make_scene_three_surfaces, ad_volume      # noqa: E402
 
 
-def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0, smooth_weight=0.5, host_threads=0, quiet=False):
+def scene_inputs(scene, H, W, D, dev):
+    """(imL, imR, gt, volL as a host array): "objects" = synth.make_scene + absolute-difference volume (nine small objects), "three_surfaces" = the
+    C++ host demo's scene (DemoScene.h; large slanted surfaces: the hard one for the cuts)."""
+    if scene == "three_surfaces":
+        return make_scene_three_surfaces(H, W, D)
+    if scene != "objects":
+        raise ValueError(f"unknown scene {scene!r}")
+    imL, imR, gt = make_scene(H, W, D)
+    return imL, imR, gt, ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
+
+
+def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0, smooth_weight=0.5, host_threads=0, quiet=False, scene="objects", device_cuts=None):
     """One end-to-end run; returns the record `main` prints."""
     import torch  # noqa: F401
     from localexpstereo_amd import stereo
     dev = "cuda"
     H, W, D = height, width, ndisp
     t0 = time.perf_counter()
-    imL, imR, gt = make_scene(H, W, D)
-    volL = ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
+    imL, imR, gt, volL = scene_inputs(scene, H, W, D, dev)
     t_scene = time.perf_counter() - t0
     data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
     def cpu_stat():
@@ -47,7 +57,7 @@ def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0
     c0 = cpu_stat()
     t1 = time.perf_counter()
     st, lab, raw = stereo.MidV3(data, volL, None, iterations=iterations, pmIterations=pm_iterations, doDual=bool(dual),
-                                smooth_weight=smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=host_threads)
+                                smooth_weight=smooth_weight, mc_threshold=0.5, error_threshold=1.0, device=dev, host_threads=host_threads, device_cuts=device_cuts)
     t_total = time.perf_counter() - t1
     c1 = cpu_stat()
     cpu = {k: c1[k] - c0[k] for k in c0 if k in c1}
@@ -55,20 +65,19 @@ def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0
         cpu = {"cpu_seconds": round(cpu["usage_usec"] * 1e-6, 2), "mean_cpus_busy": round(cpu["usage_usec"] * 1e-6 / t_total, 2),
                "periods_throttled": cpu.get("nr_throttled"), "seconds_throttled": round(cpu.get("throttled_usec", 0) * 1e-6, 3)}
     rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
-    return dict(shape=[W, H, D], iterations=iterations, pm_iterations=pm_iterations, dual=bool(dual), host_cores=os.cpu_count(),
+    return dict(scene=scene, shape=[W, H, D], iterations=iterations, pm_iterations=pm_iterations, dual=bool(dual), host_cores=os.cpu_count(),
                 seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_reference_clock=round(getattr(st, "seconds_reference_clock", st.seconds), 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
                 gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, cgroup_cpu=cpu, host_threads=host_threads, log=rows)
 
 
-def run_sharded(rank, world, device, width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, smooth_weight=0.5):
+def run_sharded(rank, world, device, width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, smooth_weight=0.5, scene="objects"):
     """BASELINE configs[3]: the two-view run with the views split over two rank groups and the cells of every disjoint set sharded
     inside a group (stereo.FastGCStereo.run; one all-gather of the updated tiles per set, LES/FastGCStereo.h:22-72, 172-185, 199-203).
     Every rank calls it (torch.distributed is initialised by the caller); returns this rank's record."""
     import torch
     from localexpstereo_amd import stereo
     H, W, D = height, width, ndisp
-    imL, imR, gt = make_scene(H, W, D)
-    volL = ad_volume(imL, imR, D, device).cpu().numpy()
+    imL, imR, gt, volL = scene_inputs(scene, H, W, D, device)
     data = dict(imL=imL, imR=imR, dispGT=gt, nonocc=np.ones((H, W), bool), ndisp=D, gt_prec=-1.0)
     torch.cuda.synchronize(torch.device(device))
     t1 = time.perf_counter()
@@ -91,8 +100,10 @@ def main():
     ap.add_argument("--dual", type=int, default=0)
     ap.add_argument("--smooth-weight", type=float, default=0.5)
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--scene", default="objects", choices=["objects", "three_surfaces"])
+    ap.add_argument("--device-cuts", default=None, choices=[None, "none", "fine", "all"], help="which layers are cut on the GPU (default: all that the library supports)")
     args = ap.parse_args()
-    print(json.dumps(run(args.width, args.height, args.ndisp, args.iterations, args.pm_iterations, args.dual, args.smooth_weight, args.host_threads)))
+    print(json.dumps(run(args.width, args.height, args.ndisp, args.iterations, args.pm_iterations, args.dual, args.smooth_weight, args.host_threads, scene=args.scene, device_cuts=args.device_cuts)))
 
 
 if __name__ == "__main__":
