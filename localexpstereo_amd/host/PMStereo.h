@@ -292,7 +292,8 @@ public:
             unsigned char* d_masks = nullptr;
             int* d_status = nullptr;
             std::vector<int> status;
-            long long payload_cap = 0, status_cap = 0;
+            long long payload_cap = 0, status_cap = 0, tiled_cap = 0;
+            void* d_tiled = nullptr;                 // scratch of the tiled device max-flow (this thread's: one per runDevice call)
             // deviceGraph: the solution stays on the GPU; the host receives the ready-made graphs and returns one mask byte
             // per node.  Otherwise (or with the self-check on): host-resident solution and host graph construction.
             const bool devGraph = deviceGraph && !checkFlowEnergy;
@@ -324,8 +325,11 @@ public:
                                                                       params.omega, params.epsilon, d_payload, nullptr));
                                     // cells that fit a workgroup's LDS (the finest layer) are also CUT on the device: neither their graphs
                                     // nor their masks cross PCIe (LES/FastGCStereo.h:553-559 -> les_hip_batch_solve_graphs)
+                                    // ... and since round 5 the larger cells (the coarse layers) as well: their graphs stay in device memory and
+                                    // are cut by the tiled solver, one workgroup per tile (les_hip_batch_solve_graphs_tiled)
                                     bool cutOnDevice = false;
-                                    if (deviceCuts && ok && les_hip_batch_max_cell_nodes(sb.b) <= LES_HIP_MAXFLOW_MAX_NODES) {
+                                    const bool fitsLds = les_hip_batch_max_cell_nodes(sb.b) <= LES_HIP_MAXFLOW_MAX_NODES;
+                                    if (deviceCuts && ok && (fitsLds || deviceCutsCoarse)) {
                                         if (sb.n > status_cap) {
                                             if (d_status) les_hip_free(ctx, d_status);
                                             d_status = nullptr;
@@ -333,7 +337,20 @@ public:
                                             chk(les_hip_malloc(ctx, (void**)&d_status, sizeof(int) * (size_t)sb.n));
                                         }
                                         status.assign((size_t)sb.n, 1);
-                                        chk(les_hip_batch_solve_graphs(ctx, sb.b, d_payload, d_masks, d_status, nullptr));
+                                        if (fitsLds) {
+                                            chk(les_hip_batch_solve_graphs(ctx, sb.b, d_payload, d_masks, d_status, nullptr));
+                                        } else {
+                                            const long long need = les_hip_batch_tiled_workspace_bytes(sb.b);
+                                            if (need > tiled_cap) {
+                                                if (d_tiled) les_hip_free(ctx, d_tiled);
+                                                d_tiled = nullptr;
+                                                tiled_cap = need;
+                                                chk(les_hip_malloc(ctx, &d_tiled, (size_t)need));
+                                            }
+                                            int launches = 0;
+                                            if (ok) chk(les_hip_batch_solve_graphs_tiled(ctx, sb.b, d_payload, d_masks, d_status, nullptr, d_tiled, tiled_cap, &launches));
+                                            gcTiledLaunches += launches;
+                                        }
                                         if (ok) chk(les_hip_memcpy_d2h(ctx, status.data(), d_status, sizeof(int) * (size_t)sb.n));
                                         cutOnDevice = ok && std::all_of(status.begin(), status.end(), [](int v) { return v == 0; });
                                     }
@@ -391,6 +408,7 @@ public:
             if (d_payload) les_hip_free(ctx, d_payload);
             if (d_masks) les_hip_free(ctx, d_masks);
             if (d_status) les_hip_free(ctx, d_status);
+            if (d_tiled) les_hip_free(ctx, d_tiled);
         }
         // two-view runs end with the left-right post-processing (LES/FastGCStereo.h:199-203)
         if (ok && viewModes.size() == 2) ok = postProcess(1.5f);
@@ -453,6 +471,8 @@ public:
     long gcLockSteps = 0;
     bool deviceGraph = true;            // runDevice: pairwise terms / graph capacities of the moves computed on the GPU (N1)
     bool deviceCuts = true;             // runDevice: cells of at most LES_HIP_MAXFLOW_MAX_NODES nodes are cut on the GPU as well
+    bool deviceCutsCoarse = true;       // ... and the larger cells too, by the tiled solver (false: the coarse layers' cuts stay on the host cores, rounds 2-4)
+    long long gcTiledLaunches = 0;      // launches of the tiled solver in the last runDevice
     long gcCellsCutOnDevice = 0;
     int hostThreads = 0;                // threads of the host graph cuts in runDevice (0: at most 24 and one per cell -- larger teams are slower)
     // runDevice on several GPUs (one process -- or, in the self-test, one host thread -- per GPU): this rank's place among the ranks that share

@@ -239,6 +239,7 @@ static int cmd_full(int argc, char** argv)
 {
     const int W = argc > 2 ? atoi(argv[2]) : 1436, H = argc > 3 ? atoi(argv[3]) : 992, D = argc > 4 ? atoi(argv[4]) : 256;
     const int iters = argc > 5 ? atoi(argv[5]) : 5, pm = argc > 6 ? atoi(argv[6]) : 2;
+    const int coarse = argc > 7 ? atoi(argv[7]) : 1;                  // 0: the coarse layers' cuts on the host cores (rounds 2-4)
     const auto t0 = std::chrono::steady_clock::now();
     Scene s = make_scene(W, H, D);
     const double t_scene = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -254,11 +255,12 @@ static int cmd_full(int argc, char** argv)
     st->addLayer(std::max(4, int(W * 0.03)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
     st->addLayer(std::max(8, int(W * 0.09)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
     double sec = 0;
+    st->deviceCutsCoarse = coarse != 0;
     if (!st->runDevice(pm, {0}, &sec, iters)) { printf("FAIL: runDevice\n"); return 1; }
     const double bad = bad_pixels(st->computeDisparities(0), s, 1.0f), e = st->totalEnergy(0);
     printf("full %dx%dx%d  pm %d + gc %d: optimiser %.3f s  (context + upload %.3f s, scene %.2f s)  E=%.1f  bad1.0=%.2f%%\n", W, H, D, pm, iters, sec, t_ctx, t_scene, e, bad);
-    printf("full graph-cut lock-steps: %ld   GPU propose+unary+graphs+device cuts %.3f s   host cuts %.3f s   H2D labels %.3f s   cells cut on the GPU %ld\n",
-           st->gcLockSteps, st->gcSeconds[0], st->gcSeconds[1], st->gcSeconds[2], st->gcCellsCutOnDevice);
+    printf("full graph-cut lock-steps: %ld   GPU propose+unary+graphs+device cuts %.3f s   host cuts %.3f s   H2D labels %.3f s   cells cut on the GPU %ld   tiled-solver launches %lld\n",
+           st->gcLockSteps, st->gcSeconds[0], st->gcSeconds[1], st->gcSeconds[2], st->gcCellsCutOnDevice, st->gcTiledLaunches);
     int fail = 0;
     if (st->gcCellsCutOnDevice == 0 && iters > 0) { printf("FAIL: no cell was cut on the device\n"); fail = 1; }
     if (bad > 10.0) { printf("FAIL: did not converge\n"); fail = 1; }

@@ -930,7 +930,7 @@ def case_device_cuts_vs_host_cuts(lib, device, gc_iters=2, units=(14, 43)):
     return worst, energies
 
 
-def case_device_maxflow_edge_cells(pr, seed=3):
+def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
     """les_hip_batch_solve_graphs on hand-made graphs of awkward shapes -- single rows and columns, 1 x 1 and 2 x 2 cells, cells with no
     arcs, with only source or only sink terminals, with terminals of 1e6 next to capacities below 1, and one cell just under the
     node limit -- against the host solver on the same payload: identical masks, equal flows.  Also: a cell above the limit is refused."""
@@ -972,7 +972,12 @@ def case_device_maxflow_edge_cells(pr, seed=3):
     pay = np.ascontiguousarray(pay.reshape(-1))
     dp, dm, ds, df = api.DeviceBuffer(pr.e, nn * 20), api.DeviceBuffer(pr.e, nn), api.DeviceBuffer(pr.e, 4 * k), api.DeviceBuffer(pr.e, 8 * k)
     dp.upload(pay)
-    batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
+    if tiled:                                                 # the region-parallel solver (any cell size) on the same awkward shapes
+        ws = api.DeviceBuffer(pr.e, batch.tiled_workspace_bytes())
+        batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
+        ws.free()
+    else:
+        batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
     pr.e.synchronize()
     assert not ds.download((k,), np.int32).any()
     dev_m, dev_f = dm.download((nn,), np.uint8), df.download((k,), np.float64)
@@ -985,7 +990,7 @@ def case_device_maxflow_edge_cells(pr, seed=3):
     for b_ in (dp, dm, ds, df):
         b_.free()
     batch.destroy()
-    if W >= 49 and H >= 48:                                   # 49 x 48 > 2304 nodes: refused, the caller keeps such cells on the host
+    if W >= 49 and H >= 48 and not tiled:                     # 49 x 48 > 2304 nodes: refused by the one-workgroup kernel (the tiled solver takes any size)
         big = api._rects(np.array([(0, 0, 49, 48)], np.int32))
         b2 = api.Batch(pr.e, big, big)
         assert b2.max_cell_nodes == 49 * 48
@@ -1069,14 +1074,16 @@ def _random_cell_payloads(rng, shapes, dyadic):
     return pays
 
 
-def _solve_cells_on_device(pr, shapes, pays, tiled=False):
+def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False):
     """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel."""
     H, W = pr.H, pr.W
     rects, x, y, rowh = [], 0, 0, 0
     for (w, h) in shapes:
         if x + w > W:
             x, y, rowh = 0, y + rowh, 0
-        assert y + h <= H, "cells do not fit the image"
+        if y + h > H:                          # (the solvers only look at the payload: cells may overlap in the image)
+            x, y, rowh = 0, 0, 0
+        assert w <= W and h <= H, "a cell does not fit the image"
         rects.append((x, y, w, h))
         x += w
         rowh = max(rowh, h)
@@ -1091,6 +1098,8 @@ def _solve_cells_on_device(pr, shapes, pays, tiled=False):
     dp.upload(pay)
     if tiled:
         ws = api.DeviceBuffer(pr.e, batch.tiled_workspace_bytes())
+        if poison:
+            ws.fill(0xA5); dm.fill(0x5A); ds.fill(0x7F)
         batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
         ws.free()
     else:
@@ -1170,6 +1179,70 @@ def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40, tiled=False):
         assert np.array_equal(dev_src, canonical), f"cell {i} ({w}x{h}): device {dev_src.astype(int)} canonical {canonical.astype(int)}"
         assert abs(flows[i] - best) <= 1e-9 * max(1.0, np.abs(tr).sum()), (flows[i], best)
     return len(shapes)
+
+
+def case_tiled_maxflow_large_cells(pr, seed=11, shapes=None):
+    """les_hip_batch_solve_graphs_tiled on cells of SEVERAL tiles -- wide, tall, one-row, one-column, just over one tile, many tiles --
+    against networkx (dyadic capacities: the canonical cut node for node, equal flow; float capacities: a minimum cut, flow to 1e-6) and
+    against the host solver (identical masks on the dyadic cells).  The workspace is poisoned first: nothing may depend on its contents,
+    and a second solve on the same workspace must return the same bytes (bit-reproducible).  -> (cells, nodes, tie nodes)"""
+    from localexpstereo_amd import gc as lgc
+    rng = np.random.default_rng(seed)
+    if shapes is None:
+        shapes = [(150, 130), (65, 31), (31, 65), (pr.W, 1), (1, min(pr.H, 300)), (129, 129), (64, 30), (200, 45)]
+    shapes = [(min(w, pr.W), min(h, pr.H)) for (w, h) in shapes]
+    total_nodes = ties = 0
+    for dyadic in (True, False):
+        pays = _random_cell_payloads(rng, shapes, dyadic)
+        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=True, poison=True)
+        off2, status2, masks2, flows2 = _solve_cells_on_device(pr, shapes, pays, tiled=True)
+        assert not status.any() and not status2.any()
+        assert np.array_equal(masks, masks2), "two solves of the same lock-step differ"
+        for i, ((w, h), p) in enumerate(zip(shapes, pays)):
+            ref_flow, ref_src = _grid_graph_reference(p, w, h)
+            dev_src = masks[off[i]: off[i] + w * h] != 0
+            scale = max(1.0, np.abs(p[:, 0]).astype(np.float64).sum())
+            total_nodes += w * h
+            if dyadic:
+                assert np.array_equal(dev_src, ref_src), f"cell {i} ({w}x{h}): {int((dev_src != ref_src).sum())} nodes differ from the canonical minimum cut"
+                assert abs(flows[i] - ref_flow) <= 1e-9 * scale, (flows[i], ref_flow)
+                hm = np.zeros(w * h, np.uint8)
+                lgc.solve_prebuilt(api._rects(np.array([(0, 0, w, h)], np.int32)), np.ascontiguousarray(p.reshape(-1), np.float32), np.array([0], np.int64), hm, nthreads=1)
+                assert np.array_equal(dev_src, hm != 0), f"cell {i}: differs from the host solver"
+            else:
+                assert abs(flows[i] - ref_flow) <= 1e-6 * scale, (flows[i], ref_flow)
+                cap_dev = _cut_capacity(p, w, h, dev_src)
+                assert abs(cap_dev - ref_flow) <= 1e-6 * scale, f"cell {i}: the device mask is not a minimum cut ({cap_dev} vs {ref_flow})"
+                ties += int((dev_src != ref_src).sum())
+    return 2 * len(shapes), total_nodes, ties
+
+
+def case_tiled_maxflow_hard_cells(pr):
+    """The two committed 129 x 129 crops of real coarse-layer lock-steps (tests/golden/hard_cells.npz: 89 % and 20 % of the nodes switch) through
+    the tiled device solver: masks node for node equal to the host solver's (liblocalexp_host.so), flows equal to 1e-6.  -> nodes that switch"""
+    import os
+    from localexpstereo_amd import gc as lgc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_cells.npz"))
+    shapes, pays = [], []
+    for k in z.files:
+        h, w = z[k].shape[:2]
+        shapes.append((w, h))
+        pays.append(np.ascontiguousarray(z[k].reshape(-1, 5), np.float32))
+    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=True)
+    assert not status.any()
+    switched = 0
+    for i, ((w, h), p) in enumerate(zip(shapes, pays)):
+        hm, hf = np.zeros(w * h, np.uint8), np.zeros(1)
+        lgc.solve_prebuilt(api._rects(np.array([(0, 0, w, h)], np.int32)), np.ascontiguousarray(p.reshape(-1)), np.array([0], np.int64), hm, nthreads=1, flows_out=hf)
+        dev = masks[off[i]: off[i] + w * h] != 0
+        assert np.array_equal(dev, hm != 0), f"cell {i}: {int((dev != (hm != 0)).sum())} nodes differ from the host cut"
+        # (terminals of 1e6 -- invalid labels -- sit next to capacities below 1: a float excess of 0.01 absorbed by such a sink arc is below its ulp;
+        # the bound is the one of the one-workgroup kernel's test, relative to the terminal capacities)
+        tsum = float(np.abs(p[:, 0]).astype(np.float64).sum())
+        assert abs(flows[i] - hf[0]) <= 1e-6 * tsum + 1e-5 * abs(hf[0]) + 1e-5, (flows[i], hf[0], tsum)
+        assert 0 < dev.mean() < 1
+        switched += int(dev.sum())
+    return switched
 
 
 def case_exchange_pack_unpack(pr, seed=2):

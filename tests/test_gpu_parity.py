@@ -395,6 +395,20 @@ def test_gpu_device_maxflow_against_independent_checkers(mid):
     print(f"device max-flow vs brute force: {n} cells of at most 4 x 4 nodes, canonical cut reproduced exactly")
 
 
+def test_gpu_tiled_device_maxflow(mid):
+    """les_hip_batch_solve_graphs_tiled (cells of any size, the coarse layers' cuts): the same independent checkers as the one-workgroup kernel,
+    cells of several tiles against networkx and the host solver, bit-reproducible masks, and the committed hard cells against the host solver."""
+    pc.case_device_maxflow_edge_cells(mid, seed=8, tiled=True)
+    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(mid, seed=5, ncells=30, max_side=45, tiled=True)
+    assert diff <= 2e-4 * nodes
+    pc.case_device_maxflow_vs_brute_force(mid, seed=9, ncells=40, tiled=True)
+    cells, nodes, ties = pc.case_tiled_maxflow_large_cells(mid)
+    print(f"tiled device max-flow vs networkx: {cells} cells of several tiles, {nodes} nodes, {ties} nodes on ties in the float-capacity cells")
+    assert ties <= 2e-4 * nodes
+    sw = pc.case_tiled_maxflow_hard_cells(mid)
+    print(f"tiled device max-flow on tests/golden/hard_cells.npz: masks equal to the host solver's, {sw} nodes switch")
+
+
 def test_gpu_exchange_pack_unpack(mid):
     assert pc.case_exchange_pack_unpack(mid) > 0
 

@@ -216,6 +216,23 @@ def test_sim_device_maxflow_edge_cells(cones):
     pc.case_device_maxflow_edge_cells(cones)
 
 
+def test_sim_tiled_device_maxflow(sim_lib, oracle_mod):
+    """The region-parallel device max-flow for cells of any size (csrc/les_maxflow_tiled.h): awkward shapes against the host solver,
+    small cells against networkx and exhaustive enumeration, cells of several tiles against networkx and the host solver, and the two
+    committed crops of real hard lock-steps against the host solver."""
+    pr = pc.synth_pair(sim_lib, 140, 210, 4)
+    try:
+        pc.case_device_maxflow_edge_cells(pr, tiled=True)
+        cells, nodes, diff = pc.case_device_maxflow_vs_networkx(pr, seed=5, ncells=6, max_side=24, tiled=True)
+        assert diff <= 2e-4 * nodes + 2
+        pc.case_device_maxflow_vs_brute_force(pr, seed=9, ncells=10, tiled=True)
+        cells, nodes, ties = pc.case_tiled_maxflow_large_cells(pr, shapes=[(100, 70), (65, 31), (210, 1), (1, 140), (31, 65)])
+        assert ties <= 2e-4 * nodes + 2
+        assert pc.case_tiled_maxflow_hard_cells(pr) > 0
+    finally:
+        pr.close()
+
+
 def test_sim_device_maxflow_against_independent_checkers(cones):
     """The same kernel source against networkx and brute force (no product code as the checker); the full-size version runs on the GPU."""
     cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24)
