@@ -285,8 +285,10 @@ def main():
 
     # ---- sub-records: the other two workloads of SURVEY.md 8(d) on the same context
     if world == 1 and args.sub_steps > 0 and args.workload == "h1":
+        sub_steps_by_name = {}
         for name in ("h2", "h3", "h3b"):
             st, ev, bpe, bt, ds, _ = make_workload(name)
+            sub_steps_by_name[name] = st
             el, km = measure(st, args.sub_steps, 2)
             ab = ev * bpe + float(P) * 48.0
             result["h3_batched" if name == "h3b" else name] = {
@@ -336,12 +338,19 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import e2e_bench
                 rec = {}
-                for dual in (0, 1):
-                    r = e2e_bench.run(dual=dual, quiet=True)
-                    rec["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "seconds_reference_clock", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
+                # two scenes: "objects" (nine small objects over a background plane: the easy one for the cuts) and "three_surfaces" (the C++ host demo's
+                # scene, host/DemoScene.h: three large slanted surfaces, proposals flip most of a coarse cell at once -- the hard one), one and two views each
+                for scene in ("objects", "three_surfaces"):
+                    rec[scene] = {}
+                    for dual in (0, 1):
+                        r = e2e_bench.run(dual=dual, quiet=True, scene=scene)
+                        rec[scene]["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "seconds_reference_clock", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
+                rec["single"], rec["dual"] = rec["objects"]["single"], rec["objects"]["dual"]           # (the keys of rounds 3-4: the "objects" scene)
+                rec["all_under_10_s"] = all(rec[sc][v]["seconds_optimiser"] < 10.0 for sc in ("objects", "three_surfaces") for v in ("single", "dual"))
                 from localexpstereo_amd.gc import cpu_budget
                 rec["host_cpus"] = cpu_budget()
-                rec["note"] = ("synthetic pair at the Adirondack-H shape (the data set is not in the container); MidV3 defaults: layers 14/43/129, 2 PatchMatch + 5 graph-cut iterations; "
+                rec["note"] = ("synthetic pairs at the Adirondack-H shape (the data set is not in the container); MidV3 defaults: layers 14/43/129, 2 PatchMatch + 5 graph-cut iterations; "
+                               "every cut on the GPU since round 5 (finest layer: one workgroup per cell in LDS; coarse layers: the tiled solver, gc_seconds.tiled_*); "
                                "seconds_optimiser counts from the top of run() (layers, job tables, host energy context, label initialisation included), seconds_reference_clock from where the "
                                "reference starts its timer (after initCurrentFast, LES/FastGCStereo.h:141); both exclude the evaluator")
                 result["e2e"] = rec
@@ -364,10 +373,16 @@ def main():
             if rank == 0:
                 result["e2e_sharded"] = {"error": "timeout: the sharded end-to-end leg did not finish (a rank failed or a collective hung); headline measured before it"}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+                os._exit(0)                                      # (the headline line is out: the driver's parse succeeds, the error is in the record)
+            os._exit(3)                                          # every other rank: a hung collective is a failure, not a clean exit
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            del batch, out, vol, e                               # the headline's buffers (1.5 GB volume + output) make room
+            # the headline's context and buffers make room (1.5 GB volume + its tiled copy + output): the batch and the context are released
+            # explicitly -- `step` (a closure) still refers to them, and a live context must not outlive the volume it points into
+            torch.cuda.synchronize(dev)
+            batch.destroy()
+            e.close()
+            del step, batch, out, vol, e
             torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import e2e_bench
@@ -424,6 +439,16 @@ def main():
         s1 = time.perf_counter()
         got = out[:ns].cpu().numpy()
         err = float(np.max(np.abs(got.astype(np.float64) - ref)))
+        # north_star states the tolerance as RELATIVE (1e-4); the kernel's error is absolute (a fixed-point step that scales with th_col - vmin), so the
+        # relative error is largest on the smallest costs: reported here for the costs below 1 % of th_col (none on a U[0,1) volume after a 441-pixel average:
+        # the count says so) and, as the floor of the claim, the smallest cost above which every evaluation of the sample is within 1e-4 relative
+        small = ref < 0.01 * 0.5
+        rel_all = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref.astype(np.float64)), 1e-30)
+        bad = rel_all > 1e-4
+        rel_floor = float(ref[bad].max()) if bad.any() else 0.0
+        rel_small = float(rel_all[small].max()) if small.any() else None
+        n_small = int(small.sum())
+        del rel_all, bad, small
         result["cpu_baseline"] = {
             "value": round(ns * P / (c1 - c0) / 1e6, 2),
             "unit": "Mcost-evals/s",
@@ -433,6 +458,9 @@ def main():
                       f"OpenMP over hypotheses, double-precision guided filter as the reference default)",
             "single_thread_value": round(P / (s1 - s0) / 1e6, 2),
             "gpu_vs_oracle_max_abs_err_on_sample": err,
+            "gpu_vs_oracle_max_rel_err_on_costs_below_1pct_of_th": rel_small,
+            "costs_below_1pct_of_th_in_sample": n_small,
+            "smallest_cost_with_rel_err_above_1e-4": rel_floor,          # 0.0: every evaluation of the sample is within 1e-4 relative
         }
         del ref, got
         # ---- the same for the other two workloads of SURVEY 8(d) (bounded samples: a few CPU-seconds each)
@@ -441,13 +469,23 @@ def main():
                 n2 = D                                                      # the whole H2 workload: ~1 s on 16 cores
                 pl2 = synth.slanted_planes(D, H, W, D - 1, seed=7 + rank)[:n2]
                 c0 = time.perf_counter()
-                o.aggregate_planes(pl2, nthreads=cores)
+                ref2 = o.aggregate_planes(pl2, nthreads=cores)
                 c1 = time.perf_counter()
                 result["cpu_baseline"]["h2"] = {"value": round(n2 * P / (c1 - c0) / 1e6, 2), "unit": "Mcost-evals/s", "cores": cores,
                                                 "sample": f"the {n2} slanted planes of H2 ({n2 * P / 1e6:.0f} M evals, {c1 - c0:.2f} s, OpenMP over hypotheses)"}
+                # the GPU's H2 pass against these slabs: the only place where the tiled-copy gather (steep planes, role A's KIND 5) meets the oracle at configs[2]'s size
+                sub_steps_by_name["h2"]()
+                torch.cuda.synchronize(dev)
+                got2 = out[:n2].cpu().numpy()
+                d2 = np.abs(got2.astype(np.float64) - ref2)
+                result["h2"]["gpu_vs_oracle_max_abs_err"] = float(d2.max())
+                result["h2"]["gpu_vs_oracle_max_rel_err"] = float((d2 / np.maximum(np.abs(ref2), 1e-30)).max())
+                result["h2"]["oracle_slabs_compared"] = int(n2)
+                result["h2"]["steep_planes_in_sample"] = int((np.abs(pl2[:, 0]) >= 0.05).sum())
+                del ref2, got2, d2
                 from localexpstereo_amd import pm
                 rng3 = np.random.default_rng(7 + rank)
-                ev3, t3, nl3 = 0, 0.0, 0
+                ev3, t3, nl3, err3, px3 = 0, 0.0, 0, 0.0, 0
                 for unit, slots in zip((int(W * 0.01), int(W * 0.03), int(W * 0.09)), (9, 3, 3)):
                     units_, shared, filt, sets = pm.layer_geometry(W, H, 20, unit)
                     for cells in sets:                                      # every disjoint set of each layer, one of its proposal slots
@@ -456,13 +494,23 @@ def main():
                         cx, cy = shared[cells]["x"] + shared[cells]["w"] / 2, shared[cells]["y"] + shared[cells]["h"] / 2
                         pl[:, 2] = rng3.uniform(0.2, 0.8, len(cells)) * (D - 1) - pl[:, 0] * cx - pl[:, 1] * cy
                         c0 = time.perf_counter()
-                        o.unary_batch(filt[cells], shared[cells], pl, mode=0, check=True, nthreads=cores)
+                        ref3 = o.unary_batch(filt[cells], shared[cells], pl, mode=0, check=True, nthreads=cores)
                         t3 += time.perf_counter() - c0
+                        got3 = e.unary_batch(filt[cells], shared[cells], pl, mode=0, check=True)      # the same lock-step on the GPU (march kernel, cell geometry)
+                        w3 = ~np.isnan(ref3)
+                        assert np.array_equal(w3, ~np.isnan(got3)), "H3: the written pixels differ from the oracle's"
+                        assert np.array_equal(ref3[w3] == 1e6, got3[w3] == 1e6), "H3: invalid-label sentinels differ from the oracle's"
+                        v3 = w3 & (ref3 != 1e6)
+                        err3 = max(err3, float(np.abs(got3[v3].astype(np.float64) - ref3[v3]).max())) if v3.any() else err3
+                        px3 += int(v3.sum())
                         ev3 += int(sum(int(f["w"]) * int(f["h"]) for f in filt[cells]))
                         nl3 += 1
                 result["cpu_baseline"]["h3"] = {"value": round(ev3 / t3 / 1e6, 2), "unit": "Mcost-evals/s (filter-domain)", "cores": cores,
                                                 "sample": f"{nl3} of the 240 lock-steps of H3: every disjoint set of each layer, one proposal slot, one plane per cell ({ev3 / 1e6:.0f} M "
                                                           f"filter-domain evals, {t3:.2f} s, OpenMP over cells as the reference does)"}
+                result["h3"]["gpu_vs_oracle_max_abs_err"] = err3
+                result["h3"]["oracle_locksteps_compared"] = nl3
+                result["h3"]["consumed_pixels_compared"] = px3
             except Exception as ex:                  # never lose the headline line to a sub-record
                 result["cpu_baseline"]["h2_h3_error"] = repr(ex)
     if rank == 0:

@@ -50,9 +50,10 @@ typedef struct {
     int device;                   /* HIP device ordinal                                                */
     int volumes_on_device;        /* != 0: volL/volR are device pointers owned by the caller (shared, not
                                      copied -- like the ref-counted cv::Mat headers, :20-21).  Their
-                                     contents must not change while the context exists: the cost range
+                                     contents must not change behind the context's back: the cost range
                                      of the fixed-point kernel and the tiled copy that steep planes
-                                     gather from (les_hip_tiled_volume_bytes) are taken at creation   */
+                                     gather from (les_hip_tiled_volume_bytes) are taken at creation --
+                                     after refilling a volume in place call les_hip_refresh_volume    */
 } les_hip_params;
 
 /* replaces: CostVolumeEnergy::CostVolumeEnergy (LES/CostVolumeEnergy.h:16-43) including the two
@@ -61,6 +62,13 @@ typedef struct {
  * or device when volumes_on_device).  Either view may be NULL if its mode is never used. */
 int les_hip_create(les_hip_ctx** out, const les_hip_params* params, const uint8_t* imL, const uint8_t* imR,
                    const float* volL, const float* volR);
+
+/* After the caller has overwritten the cost volume of view `mode` in place (volumes_on_device; same shape): re-derives what the context
+ * keeps of it -- the cost range that fixes the fixed-point scales of the march kernel, the finite-ness test, the tiled copy that steep
+ * planes gather from.  The guide statistics (LES/GuidedFilter.h:58-102) depend on the images only and stay.  No reference counterpart:
+ * CostVolumeEnergy shares the caller's cv::Mat and derives nothing from it (LES/CostVolumeEnergy.h:20-21).  Synchronises the stream; must
+ * not run concurrently with evaluations on the same context. */
+int les_hip_refresh_volume(les_hip_ctx* ctx, int mode);
 
 /* replaces: NaiveStereoEnergy::NaiveStereoEnergy (LES/StereoEnergy.h:638-689) -- the image-based matching cost of the
  * MiddV2 configuration (LES/main.cpp:86-121, PMStereoBase.h:37): no cost volume; the raw cost of a plane is the truncated

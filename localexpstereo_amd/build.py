@@ -46,6 +46,23 @@ def build_hip(force=False, verbose=False):
     return HIP_SO
 
 
+PLAIN_SO = os.path.join(CSRC, "libles_plain.so")
+PLAIN_FLAGS = ["-DLES_MARCH_SCAN_PLAIN", "-DLES_MARCH_STATS_PLAIN", "-DLES_SIMT_PLAIN"]
+
+
+def build_hip_plain(force=False):
+    """hipcc -> localexpstereo_amd/csrc/libles_plain.so: the SAME sources with every inline-assembly path of the march kernel replaced by
+    plain C++ (the DPP scan, the tied-destination statistics loads with hand-kept vmcnt, the SDWA / cvt / med3 / mad64 primitives).  Test
+    infrastructure: the GPU tests run the product and this build on the same inputs and require bit-identical outputs (the CPU simulator
+    cannot see the assembly).  Never loaded by the package."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "localexp_hip.h")]
+    if not force and _newer(PLAIN_SO, srcs):
+        return PLAIN_SO
+    cmd = [_hipcc()] + HIPCC_FLAGS + PLAIN_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", PLAIN_SO] + HIPCC_LIBS
+    subprocess.check_call(cmd, cwd=CSRC)
+    return PLAIN_SO
+
+
 def build_host(force=False):
     exe = os.path.join(HOST, "les_host_demo")
     srcs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".h", ".cpp"))] if os.path.isdir(HOST) else []

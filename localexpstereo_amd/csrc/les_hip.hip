@@ -44,11 +44,11 @@ int fail(int code, const char* fmt, ...)
 
 // One line on stderr, once per context and reason, when work that the march kernel could have served goes to the 2.2x slower strip
 // kernel (a perf cliff nobody would otherwise see; les_hip_batch_kernel_kind reports the same fact per batch).  LES_HIP_QUIET=1 silences it.
-enum FallbackReason { FB_RADIUS = 0, FB_NONFINITE, FB_RANGE, FB_THRESHOLD, FB_IMAGE_SIZE, FB_GEOMETRY, FB_PATCHES, FB_COUNT };
-void note_fallback(unsigned& seen, FallbackReason r, const char* fmt, ...)
+enum FallbackReason { FB_RADIUS = 0, FB_NONFINITE, FB_RANGE, FB_THRESHOLD, FB_IMAGE_SIZE, FB_GEOMETRY, FB_PATCHES, FB_GUIDE, FB_COUNT };
+void note_fallback(std::atomic<unsigned>& seen, FallbackReason r, const char* fmt, ...)
 {
-    if (seen & (1u << r)) return;
-    seen |= 1u << r;
+    // (contexts are shared by concurrent host threads -- the re-entrant per-call operator, the two views: fetch_or decides who reports)
+    if (seen.fetch_or(1u << r, std::memory_order_relaxed) & (1u << r)) return;
     static const bool quiet = [] { const char* e = getenv("LES_HIP_QUIET"); return e && atoi(e) != 0; }();
     if (quiet) return;
     char buf[512];
@@ -170,6 +170,7 @@ struct ViewData {
     float* mstats = nullptr;
     float* vol_t = nullptr;              // the volume once more, tiled [H][ceil(W/8)][D][8]: the taps of steep planes (les_march.h, role A's KIND 5); null when not built
     bool march_ok = false;               // volume finite, range condition met, tables built
+    unsigned dmax_bits = 0;              // largest diagonal entry of the guide's inverse covariance (float bits): fixes the scale of a, b
     les::MarchView mv = {};
 };
 
@@ -181,7 +182,7 @@ struct les_hip_ctx {
     const StripEntry* strip;
     const MarchEntry* march = nullptr;   // null: radius not instantiated (or LES_HIP_KERNEL=strip)
     int ncu = 256;                       // compute units of the device (job cutting of the march kernel)
-    unsigned fallback_seen = 0;          // reasons already reported by note_fallback
+    std::atomic<unsigned> fallback_seen{0};   // reasons already reported by note_fallback
     hipStream_t stream;
     les::Geom geom;
     ViewData v[2];
@@ -357,7 +358,7 @@ bool build_march_jobs(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_
         return true;
     }
     // Cut: geometry (wide jobs, one per workgroup / narrow jobs, two per workgroup) and rows per job.  A workgroup fills a CU
-    // (12 waves, 130 KB LDS) and runs one 7-row block per ~3.4 us tick with a 2-tick pipeline fill and 4R halo rows per job, so
+    // (12 waves, ~155 KB LDS) and runs one block of BY rows (3 .. 7 by radius; 7 at radius 10) per ~2.3-2.7 us tick with a 2-tick pipeline fill and 4R halo rows per job, so
     // the launch time is about rounds(workgroups / CUs) x ticks(rows per job): pick the cut that minimises it.  (Layer-1/2 sets
     // have only 5..50 cells: whole cells would leave most CUs idle -- measured 13 and 8 G evaluations/s against 55 at layer 0.)
     const int ncu = c->ncu;
@@ -517,9 +518,9 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
         note_fallback(c->fallback_seen, FB_RANGE, "view %d: costs reach %g below the truncation threshold %g (more than 8 x the threshold)", m, range, (double)th);
         return LES_HIP_OK;
     }
-    // tables
-    unsigned dbits = 0;
-    {
+    // tables (d_hs == nullptr: les_hip_refresh_volume -- the guide has not changed, its tables and the bound on the inverse covariance are kept)
+    unsigned dbits = v.dmax_bits;
+    if (d_hs) {
         struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } dm;
         HIPCHECK(hipMalloc(&dm.p, sizeof(unsigned)));
         unsigned* d_dmax = static_cast<unsigned*>(dm.p);
@@ -530,10 +531,11 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(&dbits, d_dmax, sizeof(unsigned), hipMemcpyDeviceToHost, cur_stream(c)));
         HIPCHECK(hipStreamSynchronize(cur_stream(c)));
+        v.dmax_bits = dbits;
     }
     float dmax;
     memcpy(&dmax, &dbits, sizeof dmax);
-    if (!(dmax > 0.0f) || !(dmax < INFINITY)) return LES_HIP_OK;
+    if (!(dmax > 0.0f) || !(dmax < INFINITY)) { note_fallback(c->fallback_seen, FB_GUIDE, "view %d: the inverse covariance of the guide is not positive and finite (largest diagonal entry %g)", m, (double)dmax); return LES_HIP_OK; }
     const int K = 2 * c->R + 1;
     const double Ba = 0.5 * range * std::sqrt((double)dmax), Bb = range + 1.5 * Ba;
     const double scale = 1073741824.0 / ((double)K * Bb * 1.25);    // horizontal box sums of the quantised a, b stay below 2^30
@@ -561,7 +563,11 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
         const unsigned long long nt = (unsigned long long)H * (unsigned long long)((W + 7) / 8) * 8ull * (unsigned long long)c->p.D;
         if (!(e && atoi(e) == 0) && nt < (1ull << 30)) {
             if (v.vol_t) { (void)hipFree(v.vol_t); v.vol_t = nullptr; }
-            if (hipMalloc((void**)&v.vol_t, nt * sizeof(float)) == hipSuccess) {
+            // the copy must not be what later makes a scratch, batch or graph allocation fail: it is only taken when it leaves at least as much
+            // memory free again as it uses, and 4 GB on top
+            size_t mem_free = 0, mem_total = 0;
+            const bool room = hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free >= 2 * nt * sizeof(float) + (4ull << 30);
+            if (room && hipMalloc((void**)&v.vol_t, nt * sizeof(float)) == hipSuccess) {
                 hipLaunchKernelGGL(les::les_tile_volume_kernel, dim3((unsigned)(((W + 7) / 8 * 8 + 63) / 64), (unsigned)H), dim3(256), 0, cur_stream(c), v.vol, v.vol_t, c->p.D, H, W);
                 HIPCHECK(hipGetLastError());
                 mv.vol_t = v.vol_t;
@@ -760,10 +766,27 @@ int les_hip_synchronize(les_hip_ctx* c)
     return LES_HIP_OK;
 }
 
+int les_hip_refresh_volume(les_hip_ctx* c, int mode)
+{
+    if (!c) return fail(LES_HIP_ERR_ARG, "null argument");
+    if (mode < 0 || mode > 1 || !c->v[mode].vol) return fail(LES_HIP_ERR_ARG, "view %d has no cost volume", mode);
+    HIPCHECK(hipSetDevice(c->p.device));
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
+    if (!c->march || !c->v[mode].mstats) return LES_HIP_OK;          // strip kernel only: it keeps nothing derived from the volume
+    const int rc = build_march_view(c, mode, nullptr);             // cost range -> fixed-point scales, tiled copy rebuilt; the guide's tables stay
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(cur_stream(c)));
+    return LES_HIP_OK;
+}
+
 int les_hip_batch_create(les_hip_ctx* c, int n, const les_hip_rect* frs, const les_hip_rect* trs, int out_slabs, les_hip_batch** out)
 {
     if (!c || !out || n < 0 || (n > 0 && (!frs || !trs))) return fail(LES_HIP_ERR_ARG, "null argument");
     if (out_slabs < 0) return fail(LES_HIP_ERR_ARG, "out_slabs must be 0 (one map) or the number of consecutive calls that share a slab");
+    // (since round 4 out_slabs = k means "call i writes slab i / k"; before, any non-zero value meant k = 1.  A caller that still passes another
+    // non-zero constant for "one slab per call" would get overlapping writes: only a k that divides n is a well-formed request)
+    if (out_slabs > 1 && n % out_slabs != 0) return fail(LES_HIP_ERR_ARG, "out_slabs = %d does not divide the %d calls of the batch (slab i / out_slabs holds out_slabs consecutive calls; pass 1 for one slab per call)", out_slabs, n);
     *out = nullptr;
     std::vector<les::Job> jobs;
     int rc = build_jobs(c, n, frs, trs, out_slabs, jobs);
@@ -1151,8 +1174,11 @@ int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, con
     a.ncells = b->n;
     a.K = 8; a.S = 12;                                     // short sweeps, a dozen of them between exact relabellings (measured: K = 8 / 16 / 32 / 64 -> 4.5 / 5.2 / 6.8 / 9.7 ms on a hard layer-1 lock-step)
     a.max_launches = 2000;
-    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_K")) a.K = std::max(1, atoi(ev));
-    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_S")) a.S = std::max(1, atoi(ev));
+    a.K2 = a.K; a.S2 = a.S;
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_K")) a.K = a.K2 = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_S")) a.S = a.S2 = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_K2")) a.K2 = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_TILED_S2")) a.S2 = std::max(1, atoi(ev));
     if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) a.max_launches = std::max(1, atoi(ev));      // tests of the callers' host fall-back
     a.masks = d_masks;
     a.status = d_status;

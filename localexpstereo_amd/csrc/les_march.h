@@ -11,7 +11,8 @@
 // multiplies, three-operand integer adds, DPP, bit-field extracts -- takes ~4.2, an SDWA byte operand is free on top of that, an
 // LDS ds_write_b128 costs ~13.7 CU cycles and a ds_read_b128 4.1, a wave issues at most one instruction per ~4 cycles, a taken
 // branch costs ~26, and the arbiter prefers the oldest wave.  So the kernel minimises instruction COUNT: all four box-filter passes
-// are EXACT 32-BIT INTEGER sums (round 4: no 64-bit or fp64 accumulation anywhere in the loops), computed by three wave-specialised
+// are EXACT INTEGER sums (round 4: 32-bit everywhere except the four stage-2 vertical sums of role D, which are exact 64-bit integers by one
+// v_mad_i64_i32 each -- acc64_add_i32; no fp64 anywhere in the loops), computed by three wave-specialised
 // roles (A, C, D below; the prefix passes B1 / B2 run on the waves of role A) that work on consecutive row blocks at the same time:
 //
 //   A  (lane = image column of a job, marching down the rows; NJ jobs per workgroup)
@@ -34,7 +35,7 @@
 // (2^-25 u8), the fp32 3x3 algebra (shared with les_strip_kernel), the stage-2 quantisation (resolution ~1e-6 of |a|max before a
 // 441-pixel average), the 2^4 rounding of the stage-2 window sums (2^-30 of their full scale) and the fp32 combination.
 //
-// The kernel is only launched when the host has established its preconditions (les_hip.hip: march_usable): a finite volume,
+// The kernel is only launched when the host has established its preconditions (les_hip.hip: build_march_view per context, build_march_jobs per batch): a finite volume,
 // th_col - vmin <= 8 |th_col|, and every target at least 2R away from clip borders that are not image borders (so that every
 // consumed stage-1 window is a true covariance window and the bound on |a| holds).  Everything else runs les_strip_kernel.
 #pragma once
@@ -144,7 +145,7 @@ struct MarchCfg {
 //   role D                                   block k-3 : box sums from T2, vertical sums, output
 // and ONE workgroup barrier per block ("tick").  Every role issues the global loads of its next block before it waits at
 // the barrier, so memory latency is covered by the other two roles' work; role A / D keep their rings in registers, role C
-// has no state and can hold the 12 statistics words of all BY rows in flight.  The prefix sums are wave-local (each wave
+// has no state and can hold the statistics words (9 per pixel: the 36-byte record) of all BY rows in flight.  The prefix sums are wave-local (each wave
 // prefixes the 64 columns it wrote, no cross-wave synchronisation): a window that crosses a wave boundary adds the total of
 // the left neighbour's tile (its last prefix element).
 // ---------------------------------------------------------------------------------------------------
@@ -252,13 +253,17 @@ typedef float mstat_tail;                       // {M2}
 typedef mstat4 mstat_tail;                      // {M2, mu0, mu1, mu2}
 #endif
 struct MarchStatRow { mstat4 a, b; mstat_tail c; };
-#if defined(LES_SIM)
-struct MarchStatDesc { const char* base; };
-__device__ inline MarchStatDesc march_stats_desc(const float* base, uint32_t) { return MarchStatDesc{(const char*)base}; }
+#if defined(LES_SIM) || defined(LES_MARCH_STATS_PLAIN)
+// Plain C++ loads (the simulator, and the -DLES_MARCH_STATS_PLAIN check build whose outputs the GPU tests compare bit for bit with the
+// product's): a range-checked record read -- offsets beyond the table read 0, as the buffer descriptor does -- and no hand-kept waits.
+struct MarchStatDesc { const char* base; uint32_t bytes; };
+__device__ inline MarchStatDesc march_stats_desc(const float* base, uint32_t bytes) { return MarchStatDesc{(const char*)base, bytes}; }
 __device__ inline void march_stats_load(MarchStatRow& r, const MarchStatDesc& d, uint32_t voff, uint32_t soff)
 {
-    const char* q = d.base + (size_t)voff + (size_t)soff;          // 36-byte records: not 16-byte aligned
-    memcpy(&r.a, q, 16); memcpy(&r.b, q + 16, 16); memcpy(&r.c, q + 32, sizeof r.c);
+    const unsigned long long o = (unsigned long long)voff + (unsigned long long)soff;
+    float w[8 + sizeof(mstat_tail) / 4];
+    for (unsigned i = 0; i < sizeof w / 4; i++) w[i] = (o + 4ull * i + 4 <= d.bytes) ? *reinterpret_cast<const float*>(d.base + o + 4ull * i) : 0.0f;   // 36-byte records: dword aligned only
+    memcpy(&r.a, w, 16); memcpy(&r.b, w + 4, 16); memcpy(&r.c, w + 8, sizeof r.c);
 }
 template <int N>
 __device__ inline void march_stats_wait(MarchStatRow& r) { (void)r; }

@@ -115,7 +115,8 @@ struct MtArgs {
     char* ws;                        // workspace (mt_layout)
     long long nodes;                 // total node count of the lock-step
     int ncells;
-    int K, S;                        // inner iterations per discharge sweep; sweeps between exact relabellings
+    int K, S;                        // inner iterations per discharge sweep; sweeps between exact relabellings -- in the first round (dense: every wave has work)
+    int K2, S2;                      // ... and in the later rounds (a few active nodes per tile: an iteration is cheap, a launch is not)
     int max_launches;                // a cell that needs more reports status 1 (cut on the host)
     uint8_t* masks;
     int* status;
@@ -140,6 +141,8 @@ les_maxflow_tiled_kernel(MtArgs a)
     const int tid = (int)threadIdx.x;
     // (written by the last tile of the previous launch: plain loads see them across the kernel boundary)
     const int phase = ctl->phase, launch = ctl->launches, parity = ctl->parity;
+    const bool first_round = ctl->rounds <= 1;
+    const int Kit = first_round ? a.K : a.K2, Ssw = first_round ? a.S : a.S2;
     if (phase == kMtDone) return;
 
     int* hg = reinterpret_cast<int*>(base);                                 // heights / distances, halo-pitched: (th + 2) x (tw + 2)
@@ -406,7 +409,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             __syncthreads();
             // ---- K synchronous iterations: pushes | barrier | receive + relabel | barrier.  All LDS reads of a step are issued together and
             // unconditionally (a chain of conditional reads costs a round trip each); a wave none of whose lanes has work skips the step.
-            for (int it = 0; it < a.K; it++) {
+            for (int it = 0; it < Kit; it++) {
                 const int fl = 8 + it % 3;
                 if (tid == 0) sflag[8 + (it + 1) % 3] = 0;
                 bool act = false;
@@ -579,7 +582,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             int next = phase, par = parity, sweeps = ctl->sweeps, rounds = ctl->rounds;
             if (phase == kMtRelabel0) { next = ctl->ntiles > 1 ? kMtRelabel : (active ? kMtDischarge : kMtFinal); par ^= 1; sweeps = 0; rounds++; }
             else if (phase == kMtRelabel) next = changed ? kMtRelabel : (active ? kMtDischarge : kMtFinal);
-            else if (phase == kMtDischarge) { par ^= 1; sweeps++; next = (!active || sweeps >= a.S) ? kMtRelabel0 : kMtDischarge; }
+            else if (phase == kMtDischarge) { par ^= 1; sweeps++; next = (!active || sweeps >= Ssw) ? kMtRelabel0 : kMtDischarge; }
             else next = kMtDone;
             if (next == kMtDone) {
                 a.status[t.cell] = 0;

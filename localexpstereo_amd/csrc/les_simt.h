@@ -164,12 +164,25 @@ __device__ __forceinline__ void quad_allgather(T v, T out[4])
 #define LES_MARCH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ int readfirstlane_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // floor(x + 0.5) in one instruction (saturating): round-half-up keeps the quantisation of a, b unbiased
+#if defined(LES_SIMT_PLAIN)
+// -DLES_SIMT_PLAIN (the check build the GPU tests compare bit for bit with the product, tests/test_gpu_parity.py): the arithmetic primitives below
+// as plain C++ -- the definitions the simulator uses -- instead of inline assembly
+__device__ __forceinline__ int cvt_rpi_i32(float x)
+{
+    if (!(x == x)) return 0;
+    const float f = floorf(x + 0.5f);
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int)0x80000000;
+    return (int)f;
+}
+#else
 __device__ __forceinline__ int cvt_rpi_i32(float x)
 {
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+#endif
 template <int N>
 __device__ __forceinline__ int dpp_row_shr(int v)
 {
@@ -187,6 +200,15 @@ __device__ __forceinline__ int readlane_i32(int v, int l) { return __builtin_amd
 //   mul24_sbyte<B>(g, v)   sign-extended byte B of g times the low 24 bits of v        (v_mul_i32_i24_sdwa)
 //   cvt_f32_sbyte<B>(g)    float of the sign-extended byte B of g                       (v_cvt_f32_i32_sdwa)
 //   min_f32_finite(a, b)   one v_min_f32 (fminf() adds a canonicalising v_max_f32 in IEEE mode; the operands here are finite)
+#if defined(LES_SIMT_PLAIN)
+template <int B>
+__device__ __forceinline__ int mul24_sbyte(uint32_t g, int v) { return (((int)(g << (24 - 8 * B))) >> 24) * v; }
+template <int B>
+__device__ __forceinline__ float cvt_f32_sbyte(uint32_t g) { return (float)(((int)(g << (24 - 8 * B))) >> 24); }
+__device__ __forceinline__ float min_f32_finite(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float med3_f32(float x, float lo, float hi) { return !(x > lo) ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ void acc64_add_i32(long long& acc, int d) { acc += (long long)d; }
+#else
 template <int B>
 __device__ __forceinline__ int mul24_sbyte(uint32_t g, int v)
 {
@@ -225,6 +247,7 @@ __device__ __forceinline__ void acc64_add_i32(long long& acc, int d)
 {
     asm("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(d) : "vcc");
 }
+#endif
 // Raw buffer access (march kernel, round 4): address = descriptor base + per-lane byte offset (VGPR) + wave-uniform byte offset (SGPR),
 // i.e. a row of an image costs NO scalar address arithmetic (the global_load `saddr` form needs a 64-bit scalar add per row and
 // access); out-of-range offsets read 0.  num_records is in bytes (stride 0).

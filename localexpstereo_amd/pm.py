@@ -67,6 +67,7 @@ class _Shard:
         tgt = units if target_is_unit else shared
         self.n = len(self.own)
         self.regions = np.ascontiguousarray(tgt[self.own])
+        self.batch_filter = np.ascontiguousarray(filt[self.own])
         self.batch = api.Batch(e, filt[self.own], tgt[self.own])
         self.batch.set_units(units[self.own])
         self.rng = torch.from_numpy(seeds[self.own].view(np.int64).copy()).to(dev)
@@ -364,7 +365,7 @@ class PMRunner:
             pin = (lambda t: t.pin_memory()) if r0.device.type == "cuda" else (lambda t: t)
             n = max([1] + [sum(r.shards[li][si].graph_nodes for r in runners) for li in range(len(r0.shards)) for si in range(len(r0.shards[li]))])
             r0._joint = dict(payload=torch.empty(n * 5, dtype=torch.float32, device=r0.device), payload_host=pin(torch.empty(n * 5, dtype=torch.float32)),
-                             masks=torch.empty(n, dtype=torch.uint8, device=r0.device), masks_host=pin(torch.zeros(n, dtype=torch.uint8)))
+                             masks=torch.empty(n, dtype=torch.uint8, device=r0.device), masks_host=pin(torch.zeros(n, dtype=torch.uint8)), batches={})
         J = r0._joint
         for li in range(len(r0.shards)):
             for si in range(len(r0.shards[li])):
@@ -389,12 +390,42 @@ class PMRunner:
                             sh.batch.expansion_graph(sh.planes.data_ptr(), r.labels.data_ptr(), r.cur.data_ptr(), r.prop.data_ptr(),
                                                      J["payload"].data_ptr() + 20 * int(base[v]), mode=r.mode, lambda_=p["lambda_"], th_smooth=p["th_smooth"],
                                                      omega=p["omega"], epsilon=p["epsilon"])
-                        r0._sync()
-                        J["payload_host"][: total * 5].copy_(J["payload"][: total * 5])
-                        t1 = time.perf_counter()
-                        lgc.solve_prebuilt(regions, J["payload_host"].numpy()[: total * 5], offsets, J["masks_host"].numpy()[:total], nthreads=nthreads)
-                        t2 = time.perf_counter()
-                        J["masks"][:total].copy_(J["masks_host"][:total])
+                        # device cuts: ONE solve over the cells of all views -- a joint batch (the views' target rects one after the other) has
+                        # exactly the node offsets of the concatenated payload, so the single-batch entry points serve it unchanged
+                        on_dev = False
+                        ncell = sum(sh.n for sh in shs)
+                        small = max([0] + [sh.batch.max_cell_nodes for sh in shs if sh.n]) <= api.Batch.MAXFLOW_MAX_NODES
+                        if ncell and (r0.device_cuts == "all" or (r0.device_cuts == "fine" and small)):
+                            jb = J["batches"].get((li, si))
+                            if jb is None:
+                                fr = np.concatenate([sh.batch_filter for sh in shs])
+                                jb = J["batches"][(li, si)] = api.Batch(r0.e, fr, regions)
+                                assert jb.graph_nodes() == total and np.array_equal(jb.graph_offsets(), offsets)
+                            if J.get("status") is None or J["status"].numel() < ncell:
+                                J["status"] = torch.zeros(max(ncell, 1024), dtype=torch.int32, device=r0.device)
+                            st = J["status"][:ncell]
+                            if small:
+                                jb.solve_graphs(J["payload"].data_ptr(), J["masks"].data_ptr(), st.data_ptr())
+                            else:
+                                nb = jb.tiled_workspace_bytes()
+                                if J.get("ws") is None or J["ws"].numel() < nb + 256:
+                                    J["ws"] = torch.empty(nb + 256, dtype=torch.uint8, device=r0.device)
+                                wp = (J["ws"].data_ptr() + 255) & ~255
+                                nl = jb.solve_graphs_tiled(J["payload"].data_ptr(), J["masks"].data_ptr(), st.data_ptr(), wp, J["ws"].numel() - (wp - J["ws"].data_ptr()))
+                                r0.gc_seconds["tiled_launches"] = r0.gc_seconds.get("tiled_launches", 0) + nl
+                                r0.gc_seconds["tiled_locksteps"] = r0.gc_seconds.get("tiled_locksteps", 0) + 1
+                            on_dev = not bool(st.any().item())
+                            if on_dev:
+                                r0.gc_seconds["cells_cut_on_device"] = r0.gc_seconds.get("cells_cut_on_device", 0) + ncell
+                        if on_dev:
+                            t1 = t2 = time.perf_counter()
+                        else:
+                            r0._sync()
+                            J["payload_host"][: total * 5].copy_(J["payload"][: total * 5])
+                            t1 = time.perf_counter()
+                            lgc.solve_prebuilt(regions, J["payload_host"].numpy()[: total * 5], offsets, J["masks_host"].numpy()[:total], nthreads=nthreads)
+                            t2 = time.perf_counter()
+                            J["masks"][:total].copy_(J["masks_host"][:total])
                         for v, (r, sh) in enumerate(zip(runners, shs)):
                             if sh.n:
                                 sh.batch.apply_masks(sh.planes.data_ptr(), J["masks"].data_ptr() + int(base[v]), r.cur.data_ptr(), r.prop.data_ptr(), r.labels.data_ptr())
@@ -424,6 +455,10 @@ class PMRunner:
         return self.labels[..., 0] * xs + self.labels[..., 1] * ys + self.labels[..., 2]
 
     def close(self):
+        if getattr(self, "_joint", None) is not None:
+            for jb in self._joint["batches"].values():
+                jb.destroy()
+            self._joint = None
         for sh in [s_ for layer in self.shards for s_ in layer] + [self.init]:
             sh.batch.destroy()
             if sh.xchg is not None:

@@ -30,12 +30,22 @@ from localexpstereo_amd.synth import make_scene, make_scene_three_surfaces, ad_v
 def scene_inputs(scene, H, W, D, dev):
     """(imL, imR, gt, volL as a host array): "objects" = synth.make_scene + absolute-difference volume (nine small objects), "three_surfaces" = the
     C++ host demo's scene (DemoScene.h; large slanted surfaces: the hard one for the cuts)."""
+    key = (scene, H, W, D)
+    if _scene_cache.get("key") == key:                 # (one entry: bench.py runs one view and two views on the same scene back to back)
+        return _scene_cache["val"]
     if scene == "three_surfaces":
-        return make_scene_three_surfaces(H, W, D)
-    if scene != "objects":
+        val = make_scene_three_surfaces(H, W, D)
+    elif scene == "objects":
+        imL, imR, gt = make_scene(H, W, D)
+        val = (imL, imR, gt, ad_volume(imL, imR, D, dev).cpu().numpy())        # host arrays = what the .acrt reader hands over
+    else:
         raise ValueError(f"unknown scene {scene!r}")
-    imL, imR, gt = make_scene(H, W, D)
-    return imL, imR, gt, ad_volume(imL, imR, D, dev).cpu().numpy()        # host arrays = what the .acrt reader hands over
+    _scene_cache.clear()
+    _scene_cache.update(key=key, val=val)
+    return val
+
+
+_scene_cache = {}
 
 
 def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0, smooth_weight=0.5, host_threads=0, quiet=False, scene="objects", device_cuts=None):

@@ -143,7 +143,7 @@ class Cell:
         return inner_cost + int(its_tile.max()), int((its_tile > 0).sum())
 
 
-def solve(p5, tsy, tsx, K, S, region_relabel, verbose=False):
+def solve(p5, tsy, tsx, K, S, region_relabel, verbose=False, K2=None, S2=None):
     c = Cell(p5, tsy, tsx)
     launches, cost = 0, 0
     rounds = 0
@@ -158,8 +158,9 @@ def solve(p5, tsy, tsx, K, S, region_relabel, verbose=False):
             print(f"    round {rounds}: relabel launches {l} (cost {cst}), active {int(act.sum())}, excess {float(c.ex[act].sum()):.4f}")
         if not act.any():
             break
-        for s in range(S):
-            cs, nt = c.discharge_sweep(K, region_relabel)
+        Kr, Sr = (K, S) if rounds == 1 or K2 is None else (K2, S2)
+        for s in range(Sr):
+            cs, nt = c.discharge_sweep(Kr, region_relabel)
             launches += 1; cost += cs
             act = (c.ex > 0) & (c.hgt < c.BIG)
             if verbose:
@@ -178,6 +179,8 @@ def main():
     ap.add_argument("--tile", type=int, nargs=2, default=[32, 64])
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--s", type=int, default=8, help="discharge sweeps between global relabellings")
+    ap.add_argument("--k2", type=int, default=None, help="inner iterations per sweep after the first round")
+    ap.add_argument("--s2", type=int, default=None)
     ap.add_argument("--cells", type=int, default=0)
     ap.add_argument("--no-region-relabel", action="store_true")
     ap.add_argument("-v", action="store_true")
@@ -192,7 +195,7 @@ def main():
             w, h = int(reg[i]["w"]), int(reg[i]["h"])
             p = pay[off[i] * 5:(off[i] + w * h) * 5].reshape(h, w, 5).copy()
             t0 = time.perf_counter()
-            mask, launches, cost, rounds = solve(p, args.tile[0], args.tile[1], args.k, args.s, not args.no_region_relabel, args.v)
+            mask, launches, cost, rounds = solve(p, args.tile[0], args.tile[1], args.k, args.s, not args.no_region_relabel, args.v, args.k2, args.s2 or args.s)
             t1 = time.perf_counter()
             r1 = np.zeros(1, dtype=api.RECT_DT); r1["w"] = w; r1["h"] = h
             ref = np.zeros(w * h, np.uint8)
