@@ -325,7 +325,58 @@ def main():
                 "steps": args.sub_steps, "kernel": "march" if b8.kernel_kind(0) == 1 else "strip", "workgroups_per_launch": b8.num_jobs,
                 "algorithmic_GBps": round((ev8 * 8.0 + float(H8) * W8 * 48.0) / (km8 * 1e-3) / 1e9, 2),
             }
-            del b8, e8, vol8
+            # the slanted-plane pass (H2) on the same shard: 64 planes with slopes in +-1/2, centre disparity inside the shard's range -- steep planes
+            # take their taps from the tiled copy of the shard (1.5 GB more per rank)
+            pl8s = torch.from_numpy(synth.slanted_planes(D8, H8, W8, D8 - 1, seed=7)).to(dev)
+            el8s, km8s = measure(lambda: b8.run(pl8s.data_ptr(), out8.data_ptr(), mode=0, check=False, planes_on_device=True), args.sub_steps, 2)
+            result["n8_rank_shape_h2"] = {
+                "workload": f"H2 on the shard one rank holds at N = 8: {D8} slanted planes (slopes +-1/2) x {W8}x{H8}",
+                "ms_per_step": round(el8s / args.sub_steps * 1e3, 4), "value": round(ev8 * args.sub_steps / el8s / 1e6, 2), "unit": "Mcost-evals/s",
+                "steps": args.sub_steps, "algorithmic_GBps": round((ev8 * 12.0 + float(H8) * W8 * 48.0) / (km8s * 1e-3) / 1e9, 2),
+                "tiled_copy_bytes": e8.tiled_volume_bytes(0),
+            }
+            b8.destroy(); e8.close()
+            del b8, e8, vol8, pl8s
+            # ---- configs[4] itself on ONE GPU (3000 x 2000 x 512: 12.3 GB, 3.07e9 floats -- beyond 32-bit element offsets): 64 slanted planes whose
+            # disparity stays inside the range over the image ("tame": what the short gather needs at this size), taps from the tiled copy (12.3 GB more; round 5:
+            # the kernel's descriptor starts at the first row a job gathers, so the copy may have any size) against taps from [D][H][W]
+            try:
+                free_b, _ = torch.cuda.mem_get_info()
+                D4 = 512
+                if free_b > 60 * 2**30:
+                    vol4 = torch.empty((D4, H8, W8), device=dev, dtype=torch.float32)
+                    for d0 in range(0, D4, 64):
+                        vol4[d0:d0 + 64].uniform_(0.0, 1.0, generator=gen)
+                    rng4 = np.random.default_rng(11)
+                    pl4 = np.zeros((64, 4), np.float32)
+                    pl4[:, 0] = rng4.uniform(-0.06, 0.06, 64) * np.where(np.arange(64) % 2, 1.0, 0.3)     # |a| up to 0.06: 180 slices across the image
+                    pl4[:, 1] = rng4.uniform(-0.03, 0.03, 64)
+                    pl4[:, 2] = 256.0 - pl4[:, 0] * (W8 / 2) - pl4[:, 1] * (H8 / 2) + rng4.uniform(-20, 20, 64)
+                    rec4 = {"workload": f"configs[4] on one GPU: 64 slanted planes (|a| <= 0.06, disparity inside [0, 511] over the image) x {W8}x{H8}, volume {W8}x{H8}x{D4} (12.3 GB)"}
+                    full4 = [(0, 0, W8, H8)] * 64
+                    d_pl4 = torch.from_numpy(pl4).to(dev)
+                    outs4 = {}
+                    for tag, env in (("tiled", None), ("planar", "0")):
+                        if env is None:
+                            os.environ.pop("LES_HIP_TILED", None)
+                        else:
+                            os.environ["LES_HIP_TILED"] = env
+                        e4 = api.HipCostVolumeEnergy(synth.make_guide(H8, W8, 1234), None, vol4.data_ptr(), None, windR=20, eps=1e-4, th_col=0.5, max_disp=D4 - 1,
+                                                     device=dev_index, volumes_on_device=True, shape=(D4, H8, W8))
+                        e4.set_stream(stream.cuda_stream)
+                        b4 = api.Batch(e4, full4, full4, out_slabs=True)
+                        el4, km4 = measure(lambda: b4.run(d_pl4.data_ptr(), out8.data_ptr(), mode=0, check=False, planes_on_device=True), max(2, args.sub_steps // 4), 1)
+                        rec4[tag] = {"ms_per_step": round(km4, 4), "algorithmic_GBps": round((64.0 * H8 * W8 * 12.0 + float(H8) * W8 * 48.0) / (km4 * 1e-3) / 1e9, 2),
+                                     "tiled_copy_bytes": e4.tiled_volume_bytes(0), "kernel": "march" if b4.kernel_kind(0) == 1 else "strip"}
+                        outs4[tag] = out8[:8].clone()
+                        b4.destroy(); e4.close()
+                    os.environ.pop("LES_HIP_TILED", None)
+                    rec4["tiled_equals_planar_bit_for_bit"] = bool(torch.equal(outs4["tiled"], outs4["planar"]))
+                    result["config4_h2_one_gpu"] = rec4
+                    del vol4, outs4
+                    torch.cuda.empty_cache()
+            except Exception as ex:
+                result["config4_h2_one_gpu"] = {"error": repr(ex)}
         except Exception as ex:                      # never lose the headline line to a sub-record
             result["n8_rank_shape"] = {"error": repr(ex)}
         if saved is not None:
@@ -405,6 +456,8 @@ def main():
                 "seconds_optimiser_max": max(r["seconds_optimiser"] for r in allrec),
                 "bytes_exchanged_per_rank": [r["bytes_exchanged"] for r in allrec],
                 "all_gathers_per_rank": [r["all_gathers"] for r in allrec],
+                "exchange_seconds_per_rank": [r.get("exchange_seconds") for r in allrec],     # device time in pack -> all-gather -> unpack (events around each exchange)
+                "tiled_cut_seconds_per_rank": [round(sum(v for k, v in r.get("gc_seconds", {}).items() if k.startswith("tiled_seconds")), 3) for r in allrec],
                 "host_cut_seconds_per_rank": [r["host_cut_seconds"] for r in allrec],
                 "bad_all_last": next((r["bad_all_last"] for r in allrec if r["bad_all_last"] is not None), None),
                 "host_cpus_shared_by_all_ranks": os.cpu_count(),

@@ -72,7 +72,7 @@ def build_host(force=False):
     if not force and _newer(exe, srcs + [HIP_SO]):
         return exe
     cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), main, "-o", exe,
-           "-L", CSRC, "-llocalexp_hip", "-Wl,-rpath," + CSRC]
+           "-L", CSRC, "-llocalexp_hip", "-Wl,-rpath," + CSRC, "-ldl"]
     subprocess.check_call(cmd, cwd=HOST)
     return exe
 

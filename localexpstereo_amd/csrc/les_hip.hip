@@ -556,12 +556,13 @@ int build_march_view(les_hip_ctx* c, int m, const double* d_hs)
     mv.raw_off = nullptr;
     mv.vol_t = nullptr;
     // The tiled copy for the taps of planes that are steep along x (a second resident copy of the volume: 1.5 GB more at 1500 x 1000 x 256, of
-    // 288 GB).  Optional: LES_HIP_TILED=0 turns it off, a failing allocation or a copy of 2^30 floats or more (32-bit tap offsets) leaves it out
+    // 288 GB).  Optional: LES_HIP_TILED=0 turns it off, a failing allocation or too little free memory (below) leaves it out
     // -- such planes then gather from [D][H][W] as every other plane does (same values, more HBM traffic).
     if (!c->naive && v.vol) {
         const char* e = getenv("LES_HIP_TILED");
         const unsigned long long nt = (unsigned long long)H * (unsigned long long)((W + 7) / 8) * 8ull * (unsigned long long)c->p.D;
-        if (!(e && atoi(e) == 0) && nt < (1ull << 30)) {
+        // (any size since round 5: the kernel's descriptor starts at the first row a job gathers; one image row of tiles must stay below 2^31 bytes)
+        if (!(e && atoi(e) == 0) && (unsigned long long)((W + 7) / 8) * (unsigned long long)c->p.D * 32ull < (1ull << 31)) {
             if (v.vol_t) { (void)hipFree(v.vol_t); v.vol_t = nullptr; }
             // the copy must not be what later makes a scratch, batch or graph allocation fail: it is only taken when it leaves at least as much
             // memory free again as it uses, and 4 GB on top

@@ -445,8 +445,14 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         int slice_lo = 0;
         const bool tame = !fronto && !view.raw_off && march_plane_short_gather(g, plane, job, R, &slice_lo);
         const uint32_t W8 = ((uint32_t)g.W + 7u) >> 3;
-        // (tiled taps: 32-bit byte offsets from the base of the copy -- the whole copy below 2^30 floats)
-        const bool tiled = tame && view.vol_t && fabsf(plane.x) >= (NJ == 1 ? LES_TILED_MIN_SLOPE_WIDE : LES_TILED_MIN_SLOPE) && (unsigned long long)g.H * W8 * 8ull * (unsigned long long)g.D < (1ull << 30);
+        // (tiled taps: 32-bit byte offsets from the tiles of the first image row the job gathers -- round 5: the descriptor starts at that row, so the
+        //  copy may be of any size (configs[4]: 12.3 GB); what has to stay below 2^32 bytes is the job's own span of rows, (th + 4R + padding) x W8 x D x 32)
+        const uint32_t trowB = W8 * (uint32_t)g.D * 32u;                  // bytes of one image row of tiles
+        const int trow_lo = max(job.ty0 - 2 * R, job.cy0);
+        const int trow_hi = min(job.ty0 - 2 * R + (nblk + 2) * BY, job.cy1);          // one past the last row a (clamped) address can name
+        const unsigned long long tspanB = (unsigned long long)max(trow_hi - trow_lo, 1) * (unsigned long long)trowB;
+        const bool tiled = tame && view.vol_t && fabsf(plane.x) >= (NJ == 1 ? LES_TILED_MIN_SLOPE_WIDE : LES_TILED_MIN_SLOPE) && tspanB < 0xfffffff0ull &&
+                           (unsigned long long)W8 * (unsigned long long)g.D * 32ull < (1ull << 31);
         // Columns outside the clip contribute count 0: their factor is 0 and their addend the bare 1.5 * 2^23 (per-lane constants, so
         // the column half of the clip test costs nothing per row; the row half is one v_and with a scalar mask)
         const float spj = !col_in ? 0.0f : (inv_job ? 0.0f : view.sp);
@@ -481,15 +487,15 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
         const float* v0base = view.vol + (size_t)i0s;
         if constexpr (KIND == 3) v0base = view.vol + view.raw_off[job.plane_idx] - job.cx0;
         if constexpr (KIND == 4) v0base = view.vol + (size_t)slice_lo * (size_t)HWu;          // the lowest slice the job touches: every tap lies within 2^30 bytes of it
-        if constexpr (KIND == 5) v0base = view.vol_t;
+        if constexpr (KIND == 5) v0base = view.vol_t + (size_t)trow_lo * (size_t)(trowB >> 2);      // the tiles of the first row this job gathers
         // (KIND 4: masked rows beyond the march compute addresses from a disparity outside the tame range -- the descriptor must end where
         //  the volume ends, so that whatever passes its range check is inside the allocation)
         const unsigned long long rest4 = (unsigned long long)(g.D - slice_lo) * (unsigned long long)imgB;
-        const uint32_t tiledB = (uint32_t)g.H * W8 * 32u * (uint32_t)g.D;                // bytes of the tiled copy (KIND 5 only runs when this is below 2^32)
+        const unsigned long long trestB = (unsigned long long)(g.H - trow_lo) * (unsigned long long)trowB;      // from there to the end of the copy
+        const uint32_t tiledB = (uint32_t)(trestB < 0xfffffffcull ? trestB : 0xfffffffcull);   // (whatever passes the range check lies inside the allocation)
         const BufRsrc rs_v0 = make_buf(v0base, KIND == 3 ? 0xfffffffcu : (KIND == 4 ? (uint32_t)(rest4 < 0xfffffffcull ? rest4 : 0xfffffffcull) : (KIND == 5 ? tiledB : imgB)));
         // KIND 5: byte offset of (slice 0, image row 0, this lane's column) in the tiled copy, bytes per image row of tiles, the slice the range starts at
         const uint32_t tcol = (((uint32_t)sx >> 3) * (uint32_t)g.D * 8u + ((uint32_t)sx & 7u)) * 4u;
-        const uint32_t trowB = W8 * (uint32_t)g.D * 32u;
         const int dsub = g.D0 - slice_lo;                                 // KIND 4: slice index relative to the descriptor base
         const BufRsrc rs_v1 = make_buf(view.vol + (size_t)i1s, imgB);
         auto prep = [&](int b) __attribute__((always_inline)) {
@@ -500,7 +506,7 @@ les_march_kernel(Geom g, MarchView view, const Job* __restrict__ jobs, const flo
             rowbits_nx = ballot_low(t < Ttot && gy >= job.cy0 && gy < job.cy1, BY);
             if constexpr (KIND == 3) nx_rowraw = (sy - job.cy0) * fw * 4;
             else nx_dbase = plane.y * (float)sy + plane.z;              // b*y + c, LES/CostVolumeEnergy.h:73
-            if constexpr (KIND == 5) nx_rowT = (int)((uint32_t)sy * trowB);
+            if constexpr (KIND == 5) nx_rowT = (int)((uint32_t)(sy - trow_lo) * trowB);          // (sy >= max(ty0 - 2R, cy0) = trow_lo)
         };
         auto issue_row = [&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;

@@ -7,8 +7,10 @@
 //                                              threads like the reference loop and (b) device-resident,
 //                                              and checks that both reduce the energy and reach the
 //                                              ground truth (needs an MI355X)
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -268,6 +270,73 @@ static int cmd_full(int argc, char** argv)
     return fail;
 }
 
+// The mode north_star's sentence is about: the reference's UNCHANGED loop (LES/FastGCStereo.h:30-63) -- OpenMP threads, one cell per thread, each
+// calling StereoEnergy::ComputeUnaryPotential per proposal -- with the HIP operator installed through the seam (setStereoEnergy), at full size.
+// Every call crosses PCIe twice (plane in, target tile out) and synchronises its own stream; the graph cuts are the host's, as in the reference.
+// Prints calls, calls/s, the summed thread time inside the operator and the wall-clock of the PatchMatch and graph-cut iterations.
+struct TimedHipEnergy : HipCostVolumeEnergy {
+    using HipCostVolumeEnergy::HipCostVolumeEnergy;
+    mutable std::atomic<long long> calls{0}, nanos{0}, pixels{0};
+    void ComputeUnaryPotential(const Rect& filterRect, const Rect& targetRect, float* costs, int row_stride, const Plane& plane, Reusable& reusable,
+                               int mode = 0) const override
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        HipCostVolumeEnergy::ComputeUnaryPotential(filterRect, targetRect, costs, row_stride, plane, reusable, mode);
+        nanos += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        calls++;
+        pixels += (long long)filterRect.width * filterRect.height;
+    }
+};
+static int cmd_percall(int argc, char** argv)
+{
+    const int W = argc > 2 ? atoi(argv[2]) : 1436, H = argc > 3 ? atoi(argv[3]) : 992, D = argc > 4 ? atoi(argv[4]) : 256;
+    const int iters = argc > 5 ? atoi(argv[5]) : 5, pm = argc > 6 ? atoi(argv[6]) : 2;
+    const int threads = argc > 7 ? atoi(argv[7]) : std::min(16, omp_get_max_threads());
+    omp_set_num_threads(threads);
+    Scene s = make_scene(W, H, D);
+    Parameters param(1.0f, 20, "GF", 1e-4f);
+    param.th_col = 0.5f;
+    const float maxdisp = (float)D - 1;
+    auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
+    st->setSeed(7);
+    auto energy = std::make_unique<TimedHipEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp);
+    TimedHipEnergy* te = energy.get();
+    st->setStereoEnergy(std::move(energy));
+    st->addLayer(std::max(2, int(W * 0.01)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});   // LES/main.cpp:391-397
+    st->addLayer(std::max(4, int(W * 0.03)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    st->addLayer(std::max(8, int(W * 0.09)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
+    auto lap = [&](const char* what, const std::chrono::steady_clock::time_point& t0, long long c0, long long n0) {
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const long long c = te->calls - c0, n = te->nanos - n0;
+        printf("percall %-22s %7.3f s   %8lld operator calls   %9.0f calls/s   %6.1f us per call (thread time; %.2f thread-seconds = %.0f %% of %d threads)\n", what, sec, c,
+               c / std::max(sec, 1e-9), c ? n * 1e-3 / c : 0.0, n * 1e-9, 100.0 * n * 1e-9 / std::max(sec * threads, 1e-9), threads);
+        return sec;
+    };
+    double total = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    long long c0 = te->calls, n0 = te->nanos;
+    st->initCurrentFast(0);
+    total += lap("initCurrentFast", t0, c0, n0);
+    for (int it = 0; it < pm; it++) {
+        t0 = std::chrono::steady_clock::now(); c0 = te->calls; n0 = te->nanos;
+        for (size_t li = 0; li < st->layers().layers.size(); li++) st->localExpansionMovesForLayer((int)li, 0, it, false);
+        char name[64]; snprintf(name, sizeof name, "PatchMatch iteration %d", it);
+        total += lap(name, t0, c0, n0);
+    }
+    for (int it = 0; it < iters; it++) {
+        t0 = std::chrono::steady_clock::now(); c0 = te->calls; n0 = te->nanos;
+        for (size_t li = 0; li < st->layers().layers.size(); li++) st->localExpansionMovesForLayer((int)li, 0, it, true);
+        char name[64]; snprintf(name, sizeof name, "graph-cut iteration %d", it);
+        total += lap(name, t0, c0, n0);
+    }
+    const double bad = bad_pixels(st->computeDisparities(0), s, 1.0f), e = st->totalEnergy(0);
+    printf("percall %dx%dx%d  pm %d + gc %d, %d OpenMP threads: %.3f s   %lld operator calls (%.1f M filter-domain pixels)   E=%.1f  bad1.0=%.2f%%\n", W, H, D, pm, iters, threads,
+           total, (long long)te->calls, te->pixels * 1e-6, e, bad);
+    const int fail = bad > 10.0 ? 1 : 0;
+    printf(fail ? "les_host_demo: FAILED\n" : "les_host_demo: OK\n");
+    return fail;
+}
+
 // The C++ driver on a scene written by tools/dump_scene.py (the synthetic Adirondack-shape pair of tools/e2e_bench.py, left volume as the device
 // ingest leaves it): the same data, parameters and layers as the Python driver's end-to-end run, one view.
 static int cmd_scene(int argc, char** argv)
@@ -324,14 +393,31 @@ static int cmd_ranks(int argc, char** argv)
 {
     const int W = argc > 2 ? atoi(argv[2]) : 240, H = argc > 3 ? atoi(argv[3]) : 160, D = argc > 4 ? atoi(argv[4]) : 32;
     const int world = argc > 5 ? atoi(argv[5]) : 2;
+    // "nccl": the real transport -- one GPU, one host thread and one ncclComm_t per rank (ncclCommInitAll; RCCL resolved with dlopen as the library
+    // does), the exchange through les_hip_exchange_tiles on each rank's stream.  Needs `world` visible GPUs (RCCL refuses duplicate devices).
+    const bool use_nccl = argc > 6 && !strcmp(argv[6], "nccl");
+    std::vector<void*> comms((size_t)world, nullptr);
+    int (*comm_destroy)(void*) = nullptr;
+    if (use_nccl) {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h && getenv("LES_RCCL_LIB")) h = dlopen(getenv("LES_RCCL_LIB"), RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { printf("FAIL: librccl.so not found (LES_RCCL_LIB=path selects one)\n"); return 1; }
+        auto init_all = reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(h, "ncclCommInitAll"));
+        comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+        std::vector<int> devs((size_t)world);
+        for (int r = 0; r < world; r++) devs[(size_t)r] = r;
+        const int rc = init_all ? init_all(comms.data(), world, devs.data()) : -1;
+        if (rc != 0) { printf("FAIL: ncclCommInitAll over %d devices returned %d\n", world, rc); return 1; }
+    }
     Scene s = make_scene(W, H, D);
     Parameters param(1.0f, 20, "GF", 1e-4f);
     param.th_col = 0.5f;
     const float maxdisp = (float)D - 1;
-    auto build = [&]() {
+    auto build = [&](int device = 0) {
         auto st = std::make_unique<PMStereo>(W, H, param, maxdisp);
         st->setSeed(7);
-        st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp));
+        st->setStereoEnergy(std::make_unique<HipCostVolumeEnergy>(s.im.data(), s.im.data(), W, H, s.vol.data(), s.vol.data(), D, param, maxdisp, 0.0f, device));
         st->addLayer(std::max(2, int(W * 0.04)), {{LES_HIP_PROPOSE_EXPANSION, 1}, {LES_HIP_PROPOSE_RANSAC, 1}, {LES_HIP_PROPOSE_RANDOM, 7}});
         st->addLayer(std::max(4, int(W * 0.12)), {{LES_HIP_PROPOSE_EXPANSION, 2}, {LES_HIP_PROPOSE_RANSAC, 1}});
         return st;
@@ -351,10 +437,11 @@ static int cmd_ranks(int argc, char** argv)
     std::vector<std::thread> threads;
     for (int r = 0; r < world; r++)
         threads.emplace_back([&, r] {
-            auto st = build();
+            auto st = build(use_nccl ? r : 0);
             st->rank = r; st->world = world;
             les_hip_ctx* c = static_cast<const HipCostVolumeEnergy&>(st->getEnergyInstance()).handle();
-            st->gatherFn = [&loop, c, world](int rank, const float* d_send, float* d_recv, long long slot) {
+            if (use_nccl) st->ncclComm = comms[(size_t)r];
+            else st->gatherFn = [&loop, c, world](int rank, const float* d_send, float* d_recv, long long slot) {
                 loop.slots[(size_t)rank].resize((size_t)slot);
                 les_hip_memcpy_d2h(c, loop.slots[(size_t)rank].data(), d_send, sizeof(float) * (size_t)slot);
                 loop.barrier();
@@ -366,6 +453,8 @@ static int cmd_ranks(int argc, char** argv)
             ranks[(size_t)r] = std::move(st);
         });
     for (auto& t : threads) t.join();
+    if (use_nccl && comm_destroy) for (void* cm : comms) if (cm) comm_destroy(cm);
+    if (use_nccl) printf("transport: RCCL (ncclCommInitAll over %d GPUs, les_hip_exchange_tiles)\n", world);
     int fail = 0;
     for (int r = 0; r < world; r++) {
         if (!okv[(size_t)r]) { printf("FAIL: runDevice (rank %d of %d)\n", r, world); fail = 1; continue; }
@@ -412,6 +501,14 @@ int main(int argc, char** argv)
         }
     }
     if (argc >= 2 && !strcmp(argv[1], "scene")) return cmd_scene(argc, argv);
+    if (argc >= 2 && !strcmp(argv[1], "percall")) {
+        try {
+            return cmd_percall(argc, argv);
+        } catch (const std::exception& e) {
+            printf("les_host_demo: %s\n", e.what());
+            return 3;
+        }
+    }
     if (argc >= 2 && !strcmp(argv[1], "full")) {
         try {
             return cmd_full(argc, argv);
@@ -420,6 +517,6 @@ int main(int argc, char** argv)
             return 3;
         }
     }
-    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters] | full [W H D iters pmInit] | ranks [W H D world]\n");
+    fprintf(stderr, "usage: les_host_demo layers W H windR unit | run [W H D iters] | full [W H D iters pmInit coarse] | percall [W H D iters pmInit threads] | scene dir [iters pmInit] | ranks [W H D world]\n");
     return 2;
 }

@@ -108,6 +108,7 @@ class PMRunner:
                 self.init = _Shard(self, units, shared, fr, np.arange(len(units)), seeds_for(len(units), seed + 777), target_is_unit=True)
         self.bytes_exchanged = 0
         self.exchanges = 0                       # all-gathers issued
+        self._xevents = []
 
     # -- exchange: one all-gather of the updated tiles of a set (labels 16 B/px + cost 4 B/px).  Pack and unpack are kernels of the
     # library on the runner's stream; with the nccl backend the collective is enqueued on the same stream by torch, so nothing here
@@ -124,6 +125,10 @@ class PMRunner:
             n = max(n, x.slot_floats, self.init.xchg.slot_floats if getattr(self, "init", None) is not None and self.init.xchg else 0)
             self._xbuf = (torch.zeros(n, dtype=torch.float32, device=self.device), torch.zeros(n * self.world, dtype=torch.float32, device=self.device))
         send, recv = self._xbuf[0][: x.slot_floats], self._xbuf[1][: x.slot_floats * self.world]
+        ev = None
+        if self.device.type == "cuda":           # device time of pack -> all-gather -> unpack on this rank's stream (summed by exchange_seconds())
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self.device))
         x.pack(self.labels.data_ptr(), self.cur.data_ptr(), send.data_ptr())
         if self.device.type != "cuda":
             self._sync()
@@ -137,6 +142,17 @@ class PMRunner:
         self.bytes_exchanged += recv.numel() * 4
         self.exchanges += 1
         x.unpack(recv.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr())
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self._xevents.append(ev)
+
+    def exchange_seconds(self):
+        """Device seconds this rank's stream spent in the tile exchanges so far (pack -> all-gather -> unpack, events around each): what separates the
+        collective's share from the cuts' in a multi-GPU run.  Synchronises."""
+        if self.device.type != "cuda" or not self._xevents:
+            return 0.0
+        torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in self._xevents) * 1e-3
 
     def _sync(self):
         self.e.synchronize()

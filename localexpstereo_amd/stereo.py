@@ -221,6 +221,7 @@ class FastGCStereo:
         self.seconds_reference_clock = self.seconds - self.init_seconds
         self.bytes_exchanged = sum(r.bytes_exchanged for r in runners.values())
         self.all_gathers = sum(r.exchanges for r in runners.values())
+        self.exchange_seconds = sum(r.exchange_seconds() for r in runners.values())     # device time inside pack -> all-gather -> unpack on this rank
         for r in runners.values():
             r.close()
         if g is not None:

@@ -758,26 +758,98 @@ def test_adirondack_shape_midv3_end_to_end(dual, scene):
 
 
 def test_two_ranks_rccl_equal_one_rank(tmp_path):
-    """SURVEY.md 8(e) on hardware: pm.PMRunner with backend nccl (= RCCL) and the HIP build on 2 GPUs reproduces the 1-rank labels
-    and costs bit for bit.  Needs 2 visible GPUs (the round-end GPU box has one: the test then skips; it runs on the 8-GPU node)."""
+    """SURVEY.md 8(e) on hardware, everything a first multi-GPU box should validate at once (needs >= 2 visible GPUs; the round-end GPU box has one:
+    the test then skips):
+      (a) pm.PMRunner with backend nccl (= RCCL over xGMI) and the HIP build on 2 GPUs: PatchMatch iterations AND a graph-cut iteration with every
+          cut on the ranks' own GPUs reproduce the 1-rank labels and costs bit for bit;
+      (b) the two-view run with the view split (stereo.FastGCStereo.run: one rank group per view, per-set all-gathers inside a group, one broadcast
+          per view, post-processing replicated) on 2 -- and, with 4 GPUs, 4 -- ranks reproduces the 1-rank labelling and raw labelling bit for bit;
+      (c) the C++ host: `les_host_demo ranks ... nccl` = PMStereo::runDevice with rank / world and a real ncclComm_t per rank (ncclCommInitAll, one
+          host thread and one GPU per rank, les_hip_exchange_tiles) instead of the loop-back transport: every rank bit-equal to the single-rank run."""
     import subprocess
     import sys
     import torch
-    if torch.cuda.device_count() < 2:
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
         pytest.skip("needs 2 GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    worker = os.path.join(root, "tests", "dist_worker.py")
-    outs = []
-    for world in (1, 2):
-        out = str(tmp_path / f"w{world}.npz")
-        args = [out, "hip", "200", "260", "24", "1", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LES_HIP_QUIET="1")
+
+    def launch(worker, world, args, port):
         cmd = ([sys.executable, worker] if world == 1 else
                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                "--master-port", "29531", worker]) + args
-        subprocess.run(cmd, check=True, timeout=900, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-        outs.append(np.load(out))
-    assert int(outs[1]["bytes_exchanged"]) > 0
-    assert outs[0]["labels"].tobytes() == outs[1]["labels"].tobytes() and outs[0]["cur"].tobytes() == outs[1]["cur"].tobytes()
+                "--master-port", str(port), worker]) + args
+        subprocess.run(cmd, check=True, timeout=900, cwd=root, env=env)
+    # (a)
+    worker = os.path.join(root, "tests", "dist_worker.py")
+    for gc_iters in ("0", "1"):
+        outs = []
+        for world in (1, 2):
+            out = str(tmp_path / f"a{gc_iters}_w{world}.npz")
+            launch(worker, world, [out, "hip", "200", "260", "24", "1", gc_iters], 29531)
+            outs.append(np.load(out))
+        assert int(outs[1]["bytes_exchanged"]) > 0
+        assert outs[0]["labels"].tobytes() == outs[1]["labels"].tobytes() and outs[0]["cur"].tobytes() == outs[1]["cur"].tobytes(), f"gc_iters={gc_iters}"
+    # (b)
+    worker = os.path.join(root, "tests", "dist_worker_dual.py")
+    ref = None
+    for world in [1, 2] + ([4] if ngpu >= 4 else []):
+        out = str(tmp_path / f"b_w{world}.npz")
+        launch(worker, world, [out, "hip", "200", "260", "24", "1", "1"], 29541 + world)
+        z = np.load(out)
+        if ref is None:
+            ref = z
+        else:
+            assert ref["raw"].tobytes() == z["raw"].tobytes() and ref["lab"].tobytes() == z["lab"].tobytes(), f"two views, world {world}"
+    # (c)
+    demo = os.path.join(root, "localexpstereo_amd", "host", "les_host_demo")
+    if os.path.exists(demo):
+        r = subprocess.run([demo, "ranks", "240", "160", "32", "2", "nccl"], capture_output=True, text=True, timeout=900, env=env)
+        print(r.stdout[-3000:], r.stderr[-2000:])
+        assert r.returncode == 0 and "les_host_demo: OK" in r.stdout
+
+
+def test_config4_size_steep_planes_tiled_taps_equal_planar_taps(monkeypatch):
+    """BASELINE configs[4] shape on one GPU (3000 x 2000 x 512: beyond 32-bit element offsets): steep planes whose disparity stays inside the range
+    take their taps from the tiled copy of the volume (12.3 GB; the kernel's descriptor starts at the first row a job gathers -- round 5), and the
+    aggregated costs are bit-identical to the taps from [D][H][W] (context created with LES_HIP_TILED=0)."""
+    import torch
+    from localexpstereo_amd import api, synth
+    H, W, D = 2000, 3000, 512
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip("not enough free HBM")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    vol = torch.empty((D, H, W), device="cuda", dtype=torch.float32)
+    for d0 in range(0, D, 64):
+        vol[d0:d0 + 64].uniform_(0.0, 1.0, generator=gen)
+    guide = synth.make_guide(H, W, 99)
+    rng = np.random.default_rng(3)
+    n = 12
+    planes = np.zeros((n, 4), np.float32)
+    planes[:, 0] = rng.uniform(0.03, 0.07, n) * np.where(np.arange(n) % 2, 1.0, -1.0)
+    planes[:, 1] = rng.uniform(-0.004, 0.004, n)
+    planes[:, 2] = 256.0 - planes[:, 0] * (W / 2) - planes[:, 1] * (H / 2)
+    full = [(0, 0, W, H)] * n
+    outs = {}
+    for tag in ("tiled", "planar"):
+        if tag == "planar":
+            monkeypatch.setenv("LES_HIP_TILED", "0")
+        else:
+            monkeypatch.delenv("LES_HIP_TILED", raising=False)
+        e = api.HipCostVolumeEnergy(guide, None, vol.data_ptr(), None, volumes_on_device=True, shape=(D, H, W), max_disp=D - 1)
+        assert (e.tiled_volume_bytes(0) > 0) == (tag == "tiled")
+        b = api.Batch(e, full, full, out_slabs=True)
+        assert b.kernel_kind(0) == 1
+        out = torch.zeros((n, H, W), device="cuda", dtype=torch.float32)
+        b.run(planes, out.data_ptr(), mode=0, check=True)
+        e.synchronize()
+        outs[tag] = out
+        b.destroy(); e.close()
+    assert torch.equal(outs["tiled"], outs["planar"])
+    v = outs["tiled"][outs["tiled"] != 1e6]
+    assert 0.2 < float(v.mean()) < 0.5                       # (U[0,1) costs truncated at 0.5 and averaged)
 
 
 def test_max_size_volume_32bit_offsets(oracle_mod):

@@ -96,7 +96,7 @@ def run_sharded(rank, world, device, width=1436, height=992, ndisp=256, iteratio
     t_total = time.perf_counter() - t1
     bad = [r.get("all") for r in st.log if r.get("all") is not None]
     return dict(seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), bytes_exchanged=int(st.bytes_exchanged),
-                all_gathers=int(st.all_gathers), host_cut_seconds=round(float(st.gc_seconds.get("host_cuts", st.gc_seconds.get("cuts", 0.0))), 3),
+                all_gathers=int(st.all_gathers), exchange_seconds=round(float(getattr(st, "exchange_seconds", 0.0)), 4), host_cut_seconds=round(float(st.gc_seconds.get("host_cuts", st.gc_seconds.get("cuts", 0.0))), 3),
                 gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, bad_all_last=(round(bad[-1], 3) if bad else None))
 
 
