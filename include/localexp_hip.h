@@ -208,10 +208,12 @@ int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, con
  * les_hip_batch_solve_graphs; same cut (SINK side = the nodes that can still reach the sink).  Bit-reproducible from run to run.
  * d_workspace: caller-owned device scratch of at least les_hip_batch_tiled_workspace_bytes(batch) bytes, 256-byte aligned, not
  * shared between host threads that call concurrently (109 bytes per graph node + 64 per cell).  The call synchronises the calling
- * thread's stream (it reads "cells done" between groups of launches); launches_out (or NULL): launches enqueued. */
+ * thread's stream (between groups of launches it looks at a host-mapped "cells done" word the kernel adds to: no copy); launches_out
+ * (or NULL): launches enqueued; unsolved_out (or NULL): cells that hit the launch limit (their d_status is non-zero) -- callers that
+ * only need "all solved?" read it instead of copying d_status back. */
 long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs_tiled(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
-                                     double* d_flows, void* d_workspace, long long workspace_bytes, int* launches_out);
+                                     double* d_flows, void* d_workspace, long long workspace_bytes, int* launches_out, int* unsolved_out);
 
 /* replaces: the mask updates after a graph cut -- subProposalCost.copyTo(subCurrentCost, updateMask);
  * subCurrentLabeling.setTo(label, updateMask) (LES/FastGCStereo.h:61-62) -- for all cells of the batch.  d_masks: one

@@ -81,7 +81,7 @@ def load(path=None):
         "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
         "les_hip_refresh_volume": (ci, [vp, ci]),
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
-        "les_hip_batch_solve_graphs_tiled": (ci, [vp, vp, vp, vp, vp, vp, vp, C.c_longlong, C.POINTER(ci)]),
+        "les_hip_batch_solve_graphs_tiled": (ci, [vp, vp, vp, vp, vp, vp, vp, C.c_longlong, C.POINTER(ci), C.POINTER(ci)]),
         "les_hip_batch_tiled_workspace_bytes": (C.c_longlong, [vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_calib_copy_wide": (ci, [vp, vp, C.c_size_t, ci, vp]),
@@ -315,11 +315,12 @@ class Batch:
     def solve_graphs_tiled(self, payload_dev, masks_dev, status_dev, workspace_dev, workspace_bytes, flows_dev=None):
         """The same for cells of any size (the coarse layers): region-parallel push-relabel over tiles of the cells, graphs resident in
         device memory (csrc/les_maxflow_tiled.h).  workspace: 256-byte aligned device scratch of tiled_workspace_bytes().  Synchronises
-        the calling thread's stream.  -> launches enqueued."""
-        n = C.c_int(0)
+        the calling thread's stream.  -> launches enqueued; self.tiled_unsolved = cells that hit the launch limit (0: every cell was cut)."""
+        n, u = C.c_int(0), C.c_int(0)
         self.e._chk(self.e.L.les_hip_batch_solve_graphs_tiled(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
                                                               C.c_void_p(int(flows_dev)) if flows_dev else None, C.c_void_p(int(workspace_dev)),
-                                                              C.c_longlong(int(workspace_bytes)), C.byref(n)))
+                                                              C.c_longlong(int(workspace_bytes)), C.byref(n), C.byref(u)))
+        self.tiled_unsolved = u.value
         return n.value
 
     def apply_masks(self, planes_dev, masks_dev, cur_dev, prop_dev, labels_dev):

@@ -1138,12 +1138,23 @@ long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* b)
     return (long long)les::mt_layout(std::max<long long>(1, b->graph_nodes), std::max(1, b->n)).total;
 }
 
+namespace {
+// Two host-mapped words per calling thread (pinned, fine-grained: the kernel adds to them with system-scope atomics, the host reads them after
+// synchronising its stream -- the progress check of a lock-step costs no copy).  Allocated on the thread's first call; freed at process exit.
+struct MtHostFlags {
+    int* h = nullptr; int* d = nullptr; int device = -1;
+    ~MtHostFlags() { if (h) (void)hipHostFree(h); }
+};
+thread_local MtHostFlags tl_mt_flags;
+}  // namespace
+
 int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows,
-                                     void* d_workspace, long long workspace_bytes, int* launches_out)
+                                     void* d_workspace, long long workspace_bytes, int* launches_out, int* unsolved_out)
 {
     if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !d_payload || !d_masks || !d_status || !d_workspace) return fail(LES_HIP_ERR_ARG, "null argument");
     if (launches_out) *launches_out = 0;
+    if (unsolved_out) *unsolved_out = 0;
     if (b->n == 0) return LES_HIP_OK;
     if (workspace_bytes < les_hip_batch_tiled_workspace_bytes(b))
         return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs_tiled: workspace of %lld bytes, %lld needed (les_hip_batch_tiled_workspace_bytes)", workspace_bytes,
@@ -1184,7 +1195,22 @@ int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, con
     a.masks = d_masks;
     a.status = d_status;
     a.flows = d_flows;
-    hipLaunchKernelGGL(les::les_maxflow_tiled_init_kernel, dim3((b->n + 255) / 256), dim3(256), 0, st, a.ws, a.nodes, a.ncells, b->d_mt_tiles_per_cell, d_status, d_flows);
+    MtHostFlags& hf = tl_mt_flags;
+    if (!hf.h || hf.device != c->p.device) {
+        if (hf.h) { (void)hipHostFree(hf.h); hf.h = nullptr; }
+#if defined(LES_SIM)
+        HIPCHECK(hipHostMalloc((void**)&hf.h, 64, 0));
+        hf.d = hf.h;
+#else
+        HIPCHECK(hipHostMalloc((void**)&hf.h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHECK(hipHostGetDevicePointer((void**)&hf.d, hf.h, 0));
+#endif
+        hf.device = c->p.device;
+    }
+    volatile int* flags = hf.h;
+    flags[0] = 0; flags[1] = 0;                             // (the previous call on this thread has synchronised: nothing in flight writes them)
+    a.host_flags = hf.d;
+    hipLaunchKernelGGL(les::les_maxflow_tiled_init_kernel, dim3((b->n + 255) / 256), dim3(256), 0, st, a.ws, a.nodes, a.ncells, b->d_mt_tiles_per_cell, d_status, d_flows, a.host_flags);
     HIPCHECK(hipGetLastError());
     // Launches are enqueued in groups; after each group the host reads "cells done" (the only synchronisation).  Launches that come
     // after the last cell finished return at once.
@@ -1194,14 +1220,14 @@ int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, con
             hipLaunchKernelGGL(les::les_maxflow_tiled_kernel, dim3(std::max(1, b->mt_ntiles)), dim3(les::kMtThreads), les::kMtLdsBytes, st, a);
         total += group;
         HIPCHECK(hipGetLastError());
-        les::MtHeader hdr;
-        HIPCHECK(hipMemcpyAsync(&hdr, d_workspace, sizeof(hdr), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
-        if (hdr.cells_done >= b->n) break;
-        if (total >= a.max_launches + group) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: %d of %d cells still open after %d launches", b->n - hdr.cells_done, b->n, total);
+        const int done = flags[0];
+        if (done >= b->n) break;
+        if (total >= a.max_launches + group) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: %d of %d cells still open after %d launches", b->n - done, b->n, total);
         group = 16;
     }
     if (launches_out) *launches_out = total;
+    if (unsolved_out) *unsolved_out = flags[1];
     return LES_HIP_OK;
 }
 

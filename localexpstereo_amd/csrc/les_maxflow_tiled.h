@@ -54,7 +54,7 @@ struct MtCtl {                                                                //
     int parity, sweeps, launches, rounds;
     int ntiles, pad[7];
 };
-struct MtHeader { int cells_done, launches, pad[14]; };                       // 64 B at the start of the workspace
+struct MtHeader { int cells_done, cells_failed, pad[14]; };                   // 64 B at the start of the workspace (device-side copy of the two counters)
 
 // workspace carve-up for `nodes` graph nodes and `cells` cells (all regions 256-byte aligned)
 struct MtLayout {
@@ -83,6 +83,7 @@ __device__ inline int mt_atomic_or(int* p, int v) { return __atomic_fetch_or(p, 
 __device__ inline int mt_load(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 __device__ inline void mt_store(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 __device__ inline void mt_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+__device__ inline void mt_host_add(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 __device__ inline void mt_atomic_add_f64(double* p, double v)
 {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
@@ -104,6 +105,7 @@ __device__ __forceinline__ int mt_atomic_or(int* p, int v) { return __hip_atomic
 __device__ __forceinline__ int mt_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mt_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mt_fence() { __threadfence(); }
+__device__ __forceinline__ void mt_host_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }   // (fine-grained host memory)
 __device__ __forceinline__ void mt_atomic_add_f64(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
@@ -121,6 +123,7 @@ struct MtArgs {
     uint8_t* masks;
     int* status;
     double* flows;                   // optional
+    int* host_flags;                 // host-mapped (pinned) words the host reads after a stream synchronisation, no copy: [0] cells finished, [1] of them: gave up
 };
 
 // grid = tiles of the lock-step; block = kMtThreads; dynamic LDS = kMtLdsBytes
@@ -587,9 +590,13 @@ les_maxflow_tiled_kernel(MtArgs a)
             if (next == kMtDone) {
                 a.status[t.cell] = 0;
                 mt_atomic_add(&hdr->cells_done, 1);
+                mt_host_add(a.host_flags, 1);
             } else if (launch + 1 >= a.max_launches) {
                 next = kMtDone;                                          // gives up: status stays 1, the caller cuts the cell on the host
                 mt_atomic_add(&hdr->cells_done, 1);
+                mt_atomic_add(&hdr->cells_failed, 1);
+                mt_host_add(a.host_flags + 1, 1);
+                mt_host_add(a.host_flags, 1);
             }
             ctl->parity = par; ctl->sweeps = sweeps; ctl->rounds = rounds;
             mt_store(&ctl->changed, 0);
@@ -603,13 +610,13 @@ les_maxflow_tiled_kernel(MtArgs a)
 
 // sets up the per-cell control words of a lock-step: grid = ceil(cells / 256), block = 256
 __global__ void les_maxflow_tiled_init_kernel(char* ws, long long nodes, int ncells, const int* __restrict__ tiles_per_cell, int* __restrict__ status,
-                                              double* __restrict__ flows)
+                                              double* __restrict__ flows, int* __restrict__ host_flags)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const MtLayout L = mt_layout(nodes, ncells);
     if (i == 0) {
         MtHeader* h = reinterpret_cast<MtHeader*>(ws);
-        h->cells_done = 0; h->launches = 0;
+        h->cells_done = 0; h->cells_failed = 0;
     }
     if (i >= ncells) return;
     MtCtl* c = reinterpret_cast<MtCtl*>(ws + L.ctl) + i;
@@ -622,6 +629,7 @@ __global__ void les_maxflow_tiled_init_kernel(char* ws, long long nodes, int nce
         c->phase = kMtDone;
         status[i] = 0;
         mt_atomic_add(&reinterpret_cast<MtHeader*>(ws)->cells_done, 1);
+        mt_host_add(host_flags, 1);
     }
 }
 

@@ -347,11 +347,12 @@ public:
                                                 tiled_cap = need;
                                                 chk(les_hip_malloc(ctx, &d_tiled, (size_t)need));
                                             }
-                                            int launches = 0;
-                                            if (ok) chk(les_hip_batch_solve_graphs_tiled(ctx, sb.b, d_payload, d_masks, d_status, nullptr, d_tiled, tiled_cap, &launches));
+                                            int launches = 0, unsolved = 0;
+                                            if (ok) chk(les_hip_batch_solve_graphs_tiled(ctx, sb.b, d_payload, d_masks, d_status, nullptr, d_tiled, tiled_cap, &launches, &unsolved));
                                             gcTiledLaunches += launches;
+                                            status.assign((size_t)sb.n, unsolved ? 1 : 0);       // (reported through a host-mapped word: no copy of d_status)
                                         }
-                                        if (ok) chk(les_hip_memcpy_d2h(ctx, status.data(), d_status, sizeof(int) * (size_t)sb.n));
+                                        if (ok && fitsLds) chk(les_hip_memcpy_d2h(ctx, status.data(), d_status, sizeof(int) * (size_t)sb.n));
                                         cutOnDevice = ok && std::all_of(status.begin(), status.end(), [](int v) { return v == 0; });
                                     }
                                     if (cutOnDevice) {

@@ -322,7 +322,8 @@ class PMRunner:
                                         self.gc_seconds["tiled_launches"] = self.gc_seconds.get("tiled_launches", 0) + nl
                                         self.gc_seconds["tiled_locksteps"] = self.gc_seconds.get("tiled_locksteps", 0) + 1
                                         self.gc_seconds[f"tiled_seconds_layer{li}"] = self.gc_seconds.get(f"tiled_seconds_layer{li}", 0.0) + time.perf_counter() - tl0
-                                    on_dev = not bool(st.any().item())          # (the only synchronisation of the lock-step)
+                                    # (the only synchronisation of the lock-step; the tiled solver reports "cells that gave up" through a host-mapped word: no copy)
+                                    on_dev = (sh.batch.tiled_unsolved == 0) if not small else not bool(st.any().item())
                                     if on_dev:
                                         self.gc_seconds["cells_cut_on_device"] = self.gc_seconds.get("cells_cut_on_device", 0) + sh.n
                                 if on_dev:
@@ -430,7 +431,7 @@ class PMRunner:
                                 nl = jb.solve_graphs_tiled(J["payload"].data_ptr(), J["masks"].data_ptr(), st.data_ptr(), wp, J["ws"].numel() - (wp - J["ws"].data_ptr()))
                                 r0.gc_seconds["tiled_launches"] = r0.gc_seconds.get("tiled_launches", 0) + nl
                                 r0.gc_seconds["tiled_locksteps"] = r0.gc_seconds.get("tiled_locksteps", 0) + 1
-                            on_dev = not bool(st.any().item())
+                            on_dev = (jb.tiled_unsolved == 0) if not small else not bool(st.any().item())
                             if on_dev:
                                 r0.gc_seconds["cells_cut_on_device"] = r0.gc_seconds.get("cells_cut_on_device", 0) + ncell
                         if on_dev:

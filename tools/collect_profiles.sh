@@ -6,7 +6,7 @@
 # is what bench.py quotes as roofline.traffic.  Usage: bash tools/collect_profiles.sh [tag]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-round4}
+TAG=${1:-round5}
 O=gpurun_out/prof; mkdir -p $O
 B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0 --e2e 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --steps 100 --warmup 5 --cpu-planes 0 --sub-steps 0 --e2e 0 > $O/stats.log 2>&1     # enough launches that the cold first ones do not weigh on the average
@@ -26,7 +26,15 @@ rocprofv3 --kernel-trace --stats -d $O/h3 -- python bench.py --workload h3 --ste
 python tools/prof_summary.py $O/h3 --md > $O/${TAG}_h3_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/e2e -- python tools/e2e_bench.py > $O/e2e.log 2>&1
 python tools/prof_summary.py $O/e2e --md > $O/${TAG}_e2e_kernel_stats.md
-rm -rf $O/h3 $O/e2e
+# round 5: the hard scene (every cut on the GPU: the coarse layers by les_maxflow_tiled_kernel; __amd_rocclr_copyBuffer calls = what still crosses PCIe),
+# and the launches of the tiled solver on dumped lock-steps (per-launch durations in sequence: RELABEL0 / RELABEL / DISCHARGE phases)
+rocprofv3 --kernel-trace --stats -d $O/e2e_ts -- python tools/e2e_bench.py --scene three_surfaces > $O/e2e_ts.log 2>&1
+python tools/prof_summary.py $O/e2e_ts --md > $O/${TAG}_e2e_three_surfaces_kernel_stats.md
+if ls tools/_samples/ts1/*.npz > /dev/null 2>&1; then
+  rocprofv3 --kernel-trace --output-format csv -d $O/mf -- python tools/tiled_cut_replay.py tools/_samples/ts1/*.npz tools/_samples/obj/*.npz --reps 1 > $O/${TAG}_tiled_replay.log 2>&1
+  python tools/trace_summary.py $O/mf tiled_kernel --seq 160 > $O/${TAG}_tiled_maxflow_trace.md
+fi
+rm -rf $O/h3 $O/e2e $O/e2e_ts $O/mf
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/cal_FETCH_SIZE $O/cal_WRITE_SIZE $O/pmc_sq $O/pmc_lds
 python - "$O" "$TAG" <<'PY'
 import json, re, sys, os
