@@ -164,6 +164,26 @@ def one_case(rng, lib, stats):
             stats["cut_diff"] = stats.get("cut_diff", 0) + ndiff
             for b_ in (dm, ds, df):
                 b_.free()
+        # ... and the tiled solver (cells of any size: csrc/les_maxflow_tiled.h) on every lock-step with a defined cut, against the host solver
+        if k > 0 and nn > 0 and np.isfinite(got).all():
+            dm2, ds2, ws = api.DeviceBuffer(e, nn), api.DeviceBuffer(e, 4 * k), api.DeviceBuffer(e, batch.tiled_workspace_bytes())
+            ws.fill(0xA5)
+            batch.solve_graphs_tiled(bufs[4].ptr, dm2.ptr, ds2.ptr, ws.ptr, ws.nbytes)
+            e.synchronize()
+            if batch.tiled_unsolved or ds2.download((k,), np.int32).any():
+                raise AssertionError(f"tiled device max-flow hit its launch limit ({W}x{H}, {k} cells)")
+            dev2 = dm2.download((nn,), np.uint8)
+            host2 = np.zeros(nn, np.uint8)
+            lgc.solve_prebuilt(trs, got, off, host2)
+            nd2 = int(((dev2 != 0) != (host2 != 0)).sum())
+            if nd2 > max(2, 2e-5 * nn):
+                raise AssertionError(f"tiled device cut differs from the host cut in {nd2} of {nn} nodes ({W}x{H}, {k} cells, lambda {lam})")
+            stats["tiled_cuts"] = stats.get("tiled_cuts", 0) + 1
+            stats["tiled_nodes"] = stats.get("tiled_nodes", 0) + nn
+            stats["tiled_diff"] = stats.get("tiled_diff", 0) + nd2
+            stats["tiled_multi"] = stats.get("tiled_multi", 0) + (1 if batch.max_cell_nodes > 1920 else 0)
+            for b_ in (dm2, ds2, ws):
+                b_.free()
         batch.destroy()
         for b in bufs:
             b.free()
@@ -206,7 +226,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
-          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut), {stats.get('naive', 0)} image-based energies ({stats.get('naive_march', 0)} of them on the march kernel), {stats.get('march', 0)} configurations on the march kernel, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut; {stats.get('tiled_cuts', 0)} cut by the tiled solver, {stats.get('tiled_multi', 0)} of them with cells of several tiles: {stats.get('tiled_diff', 0)} of {stats.get('tiled_nodes', 0)} nodes differ), {stats.get('naive', 0)} image-based energies ({stats.get('naive_march', 0)} of them on the march kernel), {stats.get('march', 0)} configurations on the march kernel, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
