@@ -1056,10 +1056,10 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->maxflow_lds_ready) {
             HIPCHECK(hipSetDevice(c->p.device));
-            hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)les::mf_lds_bytes(les::kMfMaxNodes));
             if (arc == hipSuccess)
-                arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                arc = hipFuncSetAttribute(reinterpret_cast<const void*>(les::les_maxflow_kernel<5, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)les::mf_lds_bytes(les::kMfMaxNodes));
             if (arc != hipSuccess) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs: device max-flow unavailable on device %d (hipFuncSetAttribute max dynamic LDS: %s); cut on the host",
                                                c->p.device, hipGetErrorString(arc));
@@ -1070,10 +1070,10 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     const les::GraphCellMf* cells = reinterpret_cast<const les::GraphCellMf*>(b->d_targets);
     int max_iter = les::kMfMaxIter;
     if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) max_iter = std::max(0, atoi(ev));      // tests of the callers' host fall-back
-    if (maxn <= 4 * les::kMfThreads)
-        hipLaunchKernelGGL(les::les_maxflow_kernel<4>, dim3(b->n), dim3(les::kMfThreads), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+    if (maxn <= 2048)
+        hipLaunchKernelGGL((les::les_maxflow_kernel<2, 1024>), dim3(b->n), dim3(1024), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     else
-        hipLaunchKernelGGL(les::les_maxflow_kernel<5>, dim3(b->n), dim3(les::kMfThreads), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL((les::les_maxflow_kernel<5, 512>), dim3(b->n), dim3(512), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }

@@ -43,7 +43,7 @@ __host__ __device__ inline size_t mf_lds_bytes(int nodes)
 {
     const size_t n = (size_t)((nodes + 7) / 8) * 8;
     const size_t bytes = n * (8 * 4 + 4 + 4 + 4 + 2) + 64;
-    return bytes < 4160 ? 4160 : bytes;                    // (the final reduction borrows kMfThreads doubles)
+    return bytes < 8256 ? 8256 : bytes;                    // (the final reduction borrows one double per thread: up to 1024)
 }
 
 struct GraphCellMf { int x, y, w, h; };                   // same layout as GraphCell (les_pairwise.h)
@@ -53,9 +53,12 @@ struct GraphCellMf { int x, y, w, h; };                   // same layout as Grap
 __host__ __device__ inline int mf_dx(int k) { return (int)((0x02201102u >> (4 * k)) & 0xfu) - 1; }      // +1 -1  0  0 -1 +1 +1 -1
 __host__ __device__ inline int mf_dy(int k) { return (int)((0x02020211u >> (4 * k)) & 0xfu) - 1; }      //  0  0 +1 -1 +1 -1 +1 -1
 
-// grid = cells; block = kMfThreads; dynamic LDS = mf_lds_bytes(max nodes of the launch); NPT * kMfThreads >= nodes of every cell
-template <int kMfNodesPerThread>
-__global__ void __launch_bounds__(kMfThreads, 4)     // 4 waves per SIMD: two 8-wave workgroups per CU -> at most 128 VGPRs
+// grid = cells; block = THREADS; dynamic LDS = mf_lds_bytes(max nodes of the launch); NPT * THREADS >= nodes of every cell.
+// Two shapes (round 5): <2, 1024> for cells of up to 2048 nodes -- sixteen waves with two node slots each: what an iteration costs is the instruction
+// stream of its slowest wave (one wave issues an instruction per ~4.2 cycles whatever the others do), and two slots are half the stream of four; 64 VGPRs,
+// two workgroups per CU as before -- and <5, 512> (128 VGPRs) for the cells between 2049 and 2304 nodes, where three slots of 1024 threads spill.
+template <int kMfNodesPerThread, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 128)
 les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __restrict__ offsets, const float* __restrict__ payload,
                    int nmax_padded, int max_iter, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows)
 {
@@ -81,18 +84,18 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     if (N <= 0) { if (tid == 0) { status[blockIdx.x] = 0; if (flows) flows[blockIdx.x] = 0.0; } return; }
     const int BIG = N + 2;                                 // "cannot reach the sink" (fits uint16: N <= 2304)
 
-    // ---- own nodes: v = tid + j * kMfThreads
+    // ---- own nodes: v = tid + j * THREADS
     int vx[kMfNodesPerThread], vy[kMfNodesPerThread];
 #pragma unroll
     for (int j = 0; j < kMfNodesPerThread; j++) {
-        const int v = tid + j * kMfThreads;
+        const int v = tid + j * THREADS;
         vy[j] = v < N ? v / W : -1;
         vx[j] = v < N ? v - vy[j] * W : 0;
     }
     double t_in = 0.0;                                     // sink capacity of the own nodes at load time (for the flow value)
 #pragma unroll
     for (int j = 0; j < kMfNodesPerThread; j++) {
-        const int v = tid + j * kMfThreads;
+        const int v = tid + j * THREADS;
         if (v >= N) continue;
         const float tr = p5[5 * v];
         const int x = vx[j], y = vy[j];
@@ -118,7 +121,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         int* dist = reinterpret_cast<int*>(sentA);
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            const int v = tid + j * THREADS;
             d[j] = (v < N && ex[v] < 0.0f) ? 1 : BIG;
             if (v < N) dist[v] = d[j];
         }
@@ -135,7 +138,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             bool changed = false;
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
+                const int v = tid + j * THREADS;
                 if (v >= N) continue;
                 float rk[8];
 #pragma unroll
@@ -156,7 +159,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         }
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            const int v = tid + j * THREADS;
             if (v >= N) continue;
             const int dd = d[j] > BIG ? BIG : d[j];
             const int hh = (int)hgt[v];
@@ -173,7 +176,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         bool act = false;
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            const int v = tid + j * THREADS;
             if (v < N && ex[v] > 0.0f && (int)hgt[v] < BIG) act = true;
         }
         if (act) flag[0] = 1;
@@ -204,7 +207,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
                 for (int jj = 0; jj < JB; jj++) {
                     const int j = j0 + jj;
                     if (j >= kMfNodesPerThread) continue;
-                    const int v = tid + j * kMfThreads;
+                    const int v = tid + j * THREADS;
                     const bool in = v < N;
                     const int vs = in ? v : 0;
                     ev[jj] = ex[vs]; ra[jj] = r[kp * NP + vs]; rb[jj] = r[(kp + 1) * NP + vs]; hv[jj] = (int)hgt[vs];
@@ -217,7 +220,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
                 for (int jj = 0; jj < JB; jj++) {
                     const int j = j0 + jj;
                     if (j >= kMfNodesPerThread) continue;
-                    const int v = tid + j * kMfThreads;
+                    const int v = tid + j * THREADS;
                     if (v >= N) continue;
                     float e0 = ev[jj], da = 0.0f, db = 0.0f;
                     if (e0 > 0.0f && hv[jj] < BIG) {
@@ -234,14 +237,14 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
             float ga[kMfNodesPerThread], gb[kMfNodesPerThread];
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
+                const int v = tid + j * THREADS;
                 const int uax = vx[j] - dxa, uay = vy[j] - dya, ubx = vx[j] - dxb, uby = vy[j] - dyb;   // the nodes that push towards v
                 ga[j] = (v < N && uax >= 0 && uax < W && uay >= 0 && uay < H) ? sentA[v - offa] : 0.0f;
                 gb[j] = (v < N && ubx >= 0 && ubx < W && uby >= 0 && uby < H) ? sentB[v - offb] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < kMfNodesPerThread; j++) {
-                const int v = tid + j * kMfThreads;
+                const int v = tid + j * THREADS;
                 if (ga[j] > 0.0f) r[(kp ^ 1) * NP + v] += ga[j];
                 if (gb[j] > 0.0f) r[((kp + 1) ^ 1) * NP + v] += gb[j];
                 if (ga[j] > 0.0f || gb[j] > 0.0f) ex[v] += ga[j] + gb[j];     // (a sink arc absorbs what it can right here)
@@ -252,7 +255,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         int hn[kMfNodesPerThread];
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            const int v = tid + j * THREADS;
             hn[j] = -1;
             if (v >= N) continue;
             const int hv = (int)hgt[v];
@@ -270,7 +273,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kMfNodesPerThread; j++) {
-            const int v = tid + j * kMfThreads;
+            const int v = tid + j * THREADS;
             if (v < N && hn[j] >= 0) hgt[v] = (uint16_t)hn[j];
         }
         note_active();                                                       // (own nodes only: their excess and new heights)
@@ -283,7 +286,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     double t_out = 0.0;
 #pragma unroll
     for (int j = 0; j < kMfNodesPerThread; j++) {
-        const int v = tid + j * kMfThreads;
+        const int v = tid + j * THREADS;
         if (v >= N) continue;
         m[v] = (int)hgt[v] >= BIG ? 255 : 0;
         const float xv = ex[v];
@@ -294,7 +297,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
     double* red = reinterpret_cast<double*>(r);
     red[tid] = t_in - t_out;
     __syncthreads();
-    for (int s2 = kMfThreads / 2; s2 > 0; s2 >>= 1) {
+    for (int s2 = THREADS / 2; s2 > 0; s2 >>= 1) {
         if (tid < s2) red[tid] += red[tid + s2];
         __syncthreads();
     }

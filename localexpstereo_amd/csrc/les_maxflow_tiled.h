@@ -36,8 +36,8 @@
 
 namespace les {
 
-constexpr int kMtThreads = 512;
-constexpr int kMtNpt = 4;                                  // nodes per thread
+constexpr int kMtThreads = 1024;
+constexpr int kMtNpt = 2;                                  // nodes per thread
 constexpr int kMtMaxTileNodes = 1920;                      // tw * th
 constexpr int kMtMaxSide = 64;                             // tw, th <= 64
 constexpr int kMtMaxHalo = kMtMaxTileNodes + 2 * (kMtMaxSide + kMtMaxTileNodes / kMtMaxSide) + 4;    // (tw + 2) * (th + 2) <= 2112
@@ -127,7 +127,7 @@ struct MtArgs {
 };
 
 // grid = tiles of the lock-step; block = kMtThreads; dynamic LDS = kMtLdsBytes
-__global__ void __launch_bounds__(kMtThreads, 4)          // two 8-wave workgroups per CU -> at most 128 VGPRs
+__global__ void __launch_bounds__(kMtThreads, 8)          // two 16-wave workgroups per CU (eight waves per SIMD) -> at most 64 VGPRs
 les_maxflow_tiled_kernel(MtArgs a)
 {
 #if defined(LES_SIM)
