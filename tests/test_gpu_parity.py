@@ -87,7 +87,8 @@ def test_gpu_wta(mid):
 
 
 def test_gpu_other_radii(oracle_mod):
-    # guided-filter radius = windR / 2: every radius instantiated in csrc/les_hip.hip (1..10, 12, 15)
+    # guided-filter radius = windR / 2: the strip kernel is instantiated for radii 1 .. 10, 12, 15 (csrc/les_hip.hip: kStrip), the march kernel for 4 .. 10
+    # (kMarch); every radius below runs on whichever serves it and is compared with the oracle
     for windR, eps, th in ((2, 1e-2, 0.5), (4, 1e-3, 0.8), (6, 1e-4, 0.5), (8, 1e-4, 0.5), (10, 1e-4, 0.5), (12, 1e-4, 0.3),
                            (14, 1e-4, 0.5), (15, 1e-4, 0.5), (16, 1e-5, 1.5), (18, 1e-4, 0.5), (20, 1e-4, 0.5), (24, 1e-4, 0.5), (30, 1e-3, 0.5)):
         pr = pc.synth_pair(None, 90, 130, 10, windR=windR, eps=eps, th_col=th)
