@@ -1140,10 +1140,11 @@ long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* b)
 
 namespace {
 // Two host-mapped words per calling thread (pinned, fine-grained: the kernel adds to them with system-scope atomics, the host reads them after
-// synchronising its stream -- the progress check of a lock-step costs no copy).  Allocated on the thread's first call; freed at process exit.
+// synchronising its stream -- the progress check of a lock-step costs no copy).  Allocated on the thread's first call.
 struct MtHostFlags {
     int* h = nullptr; int* d = nullptr; int device = -1;
-    ~MtHostFlags() { if (h) (void)hipHostFree(h); }
+    // (no destructor: a thread's -- in particular the main thread's -- thread_local objects are destroyed when the HIP runtime may already be gone;
+    //  64 pinned bytes per thread that ever cut are returned with the process)
 };
 thread_local MtHostFlags tl_mt_flags;
 }  // namespace

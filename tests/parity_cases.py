@@ -1245,6 +1245,44 @@ def case_tiled_maxflow_hard_cells(pr):
     return switched
 
 
+def case_refresh_volume(lib, H=90, W=130, D=10):
+    """les_hip_refresh_volume: a context created on a DEVICE-resident volume keeps things derived from it (the cost range that fixes the march kernel's fixed-point
+    scales, the tiled copy steep planes gather from).  After the caller refills the volume in place -- here with costs of another range, [-1, 2) instead of [0, 1) -- and
+    calls refresh, the context must produce exactly what a context created on the new volume produces (bit for bit; fronto-parallel, slanted and steep planes)."""
+    imL = synth.make_guide(H, W, 1234)
+    volA = synth.make_volume(D, H, W, 42)
+    volB = (synth.make_volume(D, H, W, 43) * np.float32(3.0) - np.float32(1.0)).astype(np.float32)
+    planes = np.concatenate([synth.fronto_planes(D)[:4], synth.slanted_planes(6, H, W, D - 1, seed=7), random_planes(4, D, H, W, 3, slant=0.04)]).astype(np.float32)
+    n = len(planes)
+    full = api._rects(np.array([(0, 0, W, H)] * n, np.int32))
+
+    def run(e):
+        b = api.Batch(e, full, full, out_slabs=True)
+        assert b.kernel_kind(0) == 1
+        out = api.DeviceBuffer(e, n * H * W * 4)
+        b.run(planes, out.ptr, mode=0, check=True)
+        e.synchronize()
+        got = out.download((n, H, W), np.float32)
+        out.free(); b.destroy()
+        return got
+    helper = api.HipCostVolumeEnergy(imL, None, volA, None, windR=20, eps=1e-4, th_col=0.5, lib=lib)       # (owns nothing of interest: device allocations go through a context)
+    dv = api.DeviceBuffer(helper, D * H * W * 4)
+    dv.upload(volA)
+    e = api.HipCostVolumeEnergy(imL, None, dv.ptr, None, windR=20, eps=1e-4, th_col=0.5, volumes_on_device=True, shape=(D, H, W), lib=lib)
+    a_dev = run(e)
+    a_ref = run(helper)
+    assert np.array_equal(a_dev.view(np.uint32), a_ref.view(np.uint32))
+    dv.upload(volB)                                            # the caller refills its volume in place ...
+    e.refresh_volume(0)                                        # ... and says so
+    b_dev = run(e)
+    fresh = api.HipCostVolumeEnergy(imL, None, volB, None, windR=20, eps=1e-4, th_col=0.5, lib=lib)
+    b_ref = run(fresh)
+    assert np.array_equal(b_dev.view(np.uint32), b_ref.view(np.uint32)), f"{int((b_dev.view(np.uint32) != b_ref.view(np.uint32)).sum())} values differ after the refresh"
+    assert not np.array_equal(a_dev, b_dev)
+    fresh.close(); e.close(); dv.free(); helper.close()
+    return n
+
+
 def case_relative_error_floor(lib, th_col, H=240, W=320, D=32):
     """north_star states the tolerance as 1e-4 RELATIVE; the march kernel's error is ABSOLUTE (fixed-point steps that scale with th_col - vmin), so the
     relative claim has a floor: the cost below which 1e-4 relative is not met.  An absolute-difference style volume -- min(1, 0.12 |d - gt|) * 2 th_col, exact zeros where

@@ -409,6 +409,12 @@ def test_gpu_relative_tolerance_and_its_floor(oracle_mod, th_col):
     assert r["max_abs_err_on_exact_zeros"] <= 5.3e-6 * max(1.0, th_col)
 
 
+def test_gpu_refresh_volume(oracle_mod):
+    """les_hip_refresh_volume after an in-place refill of a device-resident volume (another cost range: other fixed-point scales, the tiled copy rebuilt)
+    == a context created on the new volume, bit for bit."""
+    assert pc.case_refresh_volume(None, H=200, W=300, D=24) > 0
+
+
 def test_gpu_plain_build_is_bit_identical_to_the_product(oracle_mod):
     """What the CPU simulator cannot see: the inline-assembly paths of the march kernel.  libles_plain.so (build.build_hip_plain: the same sources with
     the assembly replaced by plain C++) must reproduce the product's outputs bit for bit."""

@@ -216,6 +216,11 @@ def test_sim_device_maxflow_edge_cells(cones):
     pc.case_device_maxflow_edge_cells(cones)
 
 
+def test_sim_refresh_volume(sim_lib, oracle_mod):
+    """les_hip_refresh_volume after an in-place refill of a device-resident volume == a context created on the new volume."""
+    assert pc.case_refresh_volume(sim_lib) > 0
+
+
 def test_sim_tiled_device_maxflow(sim_lib, oracle_mod):
     """The region-parallel device max-flow for cells of any size (csrc/les_maxflow_tiled.h): awkward shapes against the host solver,
     small cells against networkx and exhaustive enumeration, cells of several tiles against networkx and the host solver, and the two
