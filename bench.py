@@ -395,7 +395,7 @@ def main():
                     rec[scene] = {}
                     for dual in (0, 1):
                         r = e2e_bench.run(dual=dual, quiet=True, scene=scene)
-                        rec[scene]["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "seconds_reference_clock", "gc_seconds", "shape", "iterations", "pm_iterations") if k in r}
+                        rec[scene]["dual" if dual else "single"] = {k: r[k] for k in ("seconds_total_including_ingest", "seconds_optimiser", "seconds_reference_clock", "gc_seconds", "tiled_locksteps", "shape", "iterations", "pm_iterations") if k in r}
                 rec["single"], rec["dual"] = rec["objects"]["single"], rec["objects"]["dual"]           # (the keys of rounds 3-4: the "objects" scene)
                 rec["all_under_10_s"] = all(rec[sc][v]["seconds_optimiser"] < 10.0 for sc in ("objects", "three_surfaces") for v in ("single", "dual"))
                 from localexpstereo_amd.gc import cpu_budget

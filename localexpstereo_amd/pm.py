@@ -239,6 +239,7 @@ class PMRunner:
         pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
         self._prop_host = pin(torch.empty((self.H, self.W), dtype=torch.float32))
         self.gc_max_gap = 0.0
+        self.tiled_lockstep_ms = {}              # layer -> [(ms, launches)] of every lock-step the tiled solver cut (per view: a runner is a view)
         self.gc_seconds = {"device": 0.0, "host_cuts": 0.0, "h2d": 0.0}
         self.gc_seconds.update({f"host_cuts_layer{li}": 0.0 for li in range(len(self.shards))})
 
@@ -322,6 +323,7 @@ class PMRunner:
                                         self.gc_seconds["tiled_launches"] = self.gc_seconds.get("tiled_launches", 0) + nl
                                         self.gc_seconds["tiled_locksteps"] = self.gc_seconds.get("tiled_locksteps", 0) + 1
                                         self.gc_seconds[f"tiled_seconds_layer{li}"] = self.gc_seconds.get(f"tiled_seconds_layer{li}", 0.0) + time.perf_counter() - tl0
+                                        self.tiled_lockstep_ms.setdefault(li, []).append((1e3 * (time.perf_counter() - tl0), nl))      # (wall of the solve call, launches enqueued)
                                     # (the only synchronisation of the lock-step; the tiled solver reports "cells that gave up" through a host-mapped word: no copy)
                                     on_dev = (sh.batch.tiled_unsolved == 0) if not small else not bool(st.any().item())
                                     if on_dev:

@@ -222,6 +222,14 @@ class FastGCStereo:
         self.bytes_exchanged = sum(r.bytes_exchanged for r in runners.values())
         self.all_gathers = sum(r.exchanges for r in runners.values())
         self.exchange_seconds = sum(r.exchange_seconds() for r in runners.values())     # device time inside pack -> all-gather -> unpack on this rank
+        # per view and layer: how long the lock-steps cut by the tiled solver took (p50 / p90 / max ms, launches)
+        self.tiled_lockstep_stats = {}
+        for m, r in runners.items():
+            for li, rows in getattr(r, "tiled_lockstep_ms", {}).items():
+                a = np.array(rows, np.float64)
+                self.tiled_lockstep_stats[f"view{m}_layer{li}"] = dict(locksteps=len(a), ms_p50=round(float(np.percentile(a[:, 0], 50)), 2), ms_p90=round(float(np.percentile(a[:, 0], 90)), 2),
+                                                                       ms_max=round(float(a[:, 0].max()), 2), ms_sum=round(float(a[:, 0].sum()), 1), launches_p50=int(np.percentile(a[:, 1], 50)),
+                                                                       launches_max=int(a[:, 1].max()))
         for r in runners.values():
             r.close()
         if g is not None:

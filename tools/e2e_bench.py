@@ -77,7 +77,7 @@ def run(width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, dual=0
     rows = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in st.log]
     return dict(scene=scene, shape=[W, H, D], iterations=iterations, pm_iterations=pm_iterations, dual=bool(dual), host_cores=os.cpu_count(),
                 seconds_total_including_ingest=round(t_total, 3), seconds_optimiser=round(st.seconds, 3), seconds_reference_clock=round(getattr(st, "seconds_reference_clock", st.seconds), 3), seconds_evaluation=round(st.eval_seconds, 3), scene_seconds=round(t_scene, 2),
-                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, cgroup_cpu=cpu, host_threads=host_threads, log=rows)
+                gc_seconds={k: round(v, 3) for k, v in st.gc_seconds.items()}, tiled_locksteps=getattr(st, "tiled_lockstep_stats", {}), cgroup_cpu=cpu, host_threads=host_threads, log=rows)
 
 
 def run_sharded(rank, world, device, width=1436, height=992, ndisp=256, iterations=5, pm_iterations=2, smooth_weight=0.5, scene="objects"):
