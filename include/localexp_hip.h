@@ -199,6 +199,11 @@ int les_hip_batch_expansion_graph(les_hip_ctx* ctx, const les_hip_batch* batch, 
 long long les_hip_batch_max_cell_nodes(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
                                double* d_flows);
+/* The same with a running count: *d_unsolved_total (a device int the caller zeroed) += 1 for every cell that hits the iteration limit.  A caller
+ * that enqueues the lock-steps of a whole disjoint set without synchronising reads this ONE word at the end of the set instead of n status words
+ * per lock-step (and repeats the set the slow way in the -- so far unobserved -- case that it is not zero). */
+int les_hip_batch_solve_graphs_counted(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
+                                       double* d_flows, int* d_unsolved_total);
 
 /* The same replacement (LES/FastGCStereo.h:553-559 on the graph of :411-551) for cells of ANY size -- the coarse layers, whose cells
  * (129 x 129 ... 404 x 387 nodes at the Adirondack shape) do not fit a workgroup's LDS: the graphs stay in device memory, a cell is
@@ -214,6 +219,21 @@ int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, con
 long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs_tiled(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
                                      double* d_flows, void* d_workspace, long long workspace_bytes, int* launches_out, int* unsolved_out);
+/* Hand-over (round 6): a lock-step lasts as long as its slowest cell, and the launches are at their worst on the tail of a hard cell.  After
+ * 28 launches, as soon as at most 8 cells of at most 400 000 nodes in total are still open, their residual graphs (8 residual capacities +
+ * the excess per node) go to host-mapped memory and the host cores -- idle during device cuts -- finish each with a search from the
+ * remaining excess nodes (host/ResidualCut.h; one thread per cell).  The residual graph of a feasible preflow has the minimum cuts of the
+ * graph it came from, so masks, status and flows mean what they mean without it.  LES_HIP_MAXFLOW_HANDOVER=0 switches it off.
+ * The _stats form reports what happened (the plain form = the _stats form without the report). */
+typedef struct les_hip_tiled_stats {
+    int launches;            /* launches of les_maxflow_tiled_kernel enqueued */
+    int unsolved;            /* cells that hit the launch limit (d_status non-zero) */
+    int handed_cells;        /* cells finished by the host cores from their residual graphs */
+    long long handed_nodes;  /* ... and their graph nodes (36 bytes each crossed PCIe, 1 byte came back) */
+    double host_ms;          /* wall-clock of the host cores' part */
+} les_hip_tiled_stats;
+int les_hip_batch_solve_graphs_tiled_stats(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
+                                           double* d_flows, void* d_workspace, long long workspace_bytes, les_hip_tiled_stats* stats);
 
 /* replaces: the mask updates after a graph cut -- subProposalCost.copyTo(subCurrentCost, updateMask);
  * subCurrentLabeling.setTo(label, updateMask) (LES/FastGCStereo.h:61-62) -- for all cells of the batch.  d_masks: one

@@ -60,6 +60,15 @@ int les_gc_expansion_moves_prebuilt(les_gc_ctx* ctx, int mode, int n, const les_
 int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* payload, const long long* offsets, int nthreads,
                           unsigned char* masks, double* flows);
 
+/* The same cut continued from a RESIDUAL graph (the state in which the tiled device max-flow hands straggler cells over,
+ * include/localexp_hip.h: les_hip_batch_solve_graphs_tiled; host/ResidualCut.h): rc8 = 8 residual capacities per node towards
+ * E W S N SW NE SE NW, ex = one float per node (> 0 excess, < 0 remaining sink capacity), cell i at node offsets[i].  The
+ * residual graph of any feasible preflow has the minimum cuts of the original graph, so the masks are those of
+ * les_gc_solve_prebuilt on the payload the preflow started from (LES/FastGCStereo.h:553-559).  solver: 0 = search from the
+ * excess nodes with the push-relabel continuation, 1 = push-relabel only.  flows (may be NULL): the flow routed HERE. */
+int les_gc_solve_residual(int n, const les_hip_rect* regions, const float* rc8, const float* ex, const long long* offsets, int nthreads,
+                          int solver, unsigned char* masks, double* flows);
+
 /* Host construction of the same payload from the context's current solution (the code path of
  * les_gc_expansion_moves up to the max-flow): the parity reference of the device construction. */
 int les_gc_build_graphs(les_gc_ctx* ctx, int mode, int n, const les_hip_rect* regions, const les_hip_plane* planes,

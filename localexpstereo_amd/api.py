@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_set_thread_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_refresh_volume", "les_hip_batch_solve_graphs", "les_hip_batch_solve_graphs_tiled", "les_hip_batch_tiled_workspace_bytes", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_refresh_volume", "les_hip_batch_solve_graphs", "les_hip_batch_solve_graphs_counted", "les_hip_batch_solve_graphs_tiled", "les_hip_batch_solve_graphs_tiled_stats", "les_hip_batch_tiled_workspace_bytes", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width", "les_hip_tiled_volume_bytes",
     "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_exchange_create", "les_hip_exchange_destroy", "les_hip_exchange_slot_floats",
@@ -32,6 +32,11 @@ PROPOSE_EXPANSION, PROPOSE_RANDOM, PROPOSE_RANSAC, PROPOSE_INIT = 0, 1, 2, 3
 
 class LesHipError(RuntimeError):
     pass
+
+
+class TiledStats(C.Structure):
+    """les_hip_tiled_stats (include/localexp_hip.h)."""
+    _fields_ = [("launches", C.c_int), ("unsolved", C.c_int), ("handed_cells", C.c_int), ("handed_nodes", C.c_longlong), ("host_ms", C.c_double)]
 
 
 class Params(C.Structure):
@@ -81,7 +86,9 @@ def load(path=None):
         "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
         "les_hip_refresh_volume": (ci, [vp, ci]),
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
+        "les_hip_batch_solve_graphs_counted": (ci, [vp, vp, vp, vp, vp, vp, vp]),
         "les_hip_batch_solve_graphs_tiled": (ci, [vp, vp, vp, vp, vp, vp, vp, C.c_longlong, C.POINTER(ci), C.POINTER(ci)]),
+        "les_hip_batch_solve_graphs_tiled_stats": (ci, [vp, vp, vp, vp, vp, vp, vp, C.c_longlong, C.POINTER(TiledStats)]),
         "les_hip_batch_tiled_workspace_bytes": (C.c_longlong, [vp]),
         "les_hip_calib_copy": (ci, [vp, vp, C.c_size_t, ci, vp]),
         "les_hip_calib_copy_wide": (ci, [vp, vp, C.c_size_t, ci, vp]),
@@ -301,12 +308,13 @@ class Batch:
     def max_cell_nodes(self):
         return int(self.e.L.les_hip_batch_max_cell_nodes(self.h))
 
-    def solve_graphs(self, payload_dev, masks_dev, status_dev, flows_dev=None):
+    def solve_graphs(self, payload_dev, masks_dev, status_dev, flows_dev=None, unsolved_total_dev=None):
         """Max-flow + segment read-out of every cell's expansion graph on the device (LES/FastGCStereo.h:553-559); cells of at most
         MAXFLOW_MAX_NODES nodes.  masks (uint8 per node), status (int32 per cell: 0 solved, 1 = cut it on the host), flows (float64 per
-        cell, optional) are device pointers."""
-        self.e._chk(self.e.L.les_hip_batch_solve_graphs(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
-                                                        C.c_void_p(int(flows_dev)) if flows_dev else None))
+        cell, optional) are device pointers; unsolved_total (optional): a device int that grows by one per cell that hit the iteration limit."""
+        self.e._chk(self.e.L.les_hip_batch_solve_graphs_counted(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
+                                                                C.c_void_p(int(flows_dev)) if flows_dev else None,
+                                                                C.c_void_p(int(unsolved_total_dev)) if unsolved_total_dev else None))
 
     def tiled_workspace_bytes(self):
         """Device scratch les_hip_batch_solve_graphs_tiled needs for this batch (109 bytes per graph node)."""
@@ -315,13 +323,15 @@ class Batch:
     def solve_graphs_tiled(self, payload_dev, masks_dev, status_dev, workspace_dev, workspace_bytes, flows_dev=None):
         """The same for cells of any size (the coarse layers): region-parallel push-relabel over tiles of the cells, graphs resident in
         device memory (csrc/les_maxflow_tiled.h).  workspace: 256-byte aligned device scratch of tiled_workspace_bytes().  Synchronises
-        the calling thread's stream.  -> launches enqueued; self.tiled_unsolved = cells that hit the launch limit (0: every cell was cut)."""
-        n, u = C.c_int(0), C.c_int(0)
-        self.e._chk(self.e.L.les_hip_batch_solve_graphs_tiled(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
-                                                              C.c_void_p(int(flows_dev)) if flows_dev else None, C.c_void_p(int(workspace_dev)),
-                                                              C.c_longlong(int(workspace_bytes)), C.byref(n), C.byref(u)))
-        self.tiled_unsolved = u.value
-        return n.value
+        the calling thread's stream.  -> launches enqueued; self.tiled_unsolved = cells that hit the launch limit (0: every cell was cut);
+        self.tiled_stats = the call's les_hip_tiled_stats (cells / nodes the host cores finished from their residual graphs, their milliseconds)."""
+        st = TiledStats()
+        self.e._chk(self.e.L.les_hip_batch_solve_graphs_tiled_stats(self.e.h, self.h, C.c_void_p(int(payload_dev)), C.c_void_p(int(masks_dev)), C.c_void_p(int(status_dev)),
+                                                                    C.c_void_p(int(flows_dev)) if flows_dev else None, C.c_void_p(int(workspace_dev)),
+                                                                    C.c_longlong(int(workspace_bytes)), C.byref(st)))
+        self.tiled_unsolved = st.unsolved
+        self.tiled_stats = dict(launches=st.launches, unsolved=st.unsolved, handed_cells=st.handed_cells, handed_nodes=st.handed_nodes, host_ms=st.host_ms)
+        return st.launches
 
     def apply_masks(self, planes_dev, masks_dev, cur_dev, prop_dev, labels_dev):
         """Mask updates of a lock-step on the device (LES/FastGCStereo.h:61-62); masks in graph-node order."""

@@ -17,7 +17,7 @@ HOST = os.path.join(_HERE, "host")
 HIP_SO = os.path.join(CSRC, "liblocalexp_hip.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-HIPCC_LIBS = ["-ldl"]      # dlopen of librccl at run time (les_hip_exchange_tiles): no link-time dependency on RCCL
+HIPCC_LIBS = ["-ldl", "-lpthread"]      # dlopen of librccl at run time (les_hip_exchange_tiles): no link-time dependency on RCCL
 
 
 def _newer(target, sources):
@@ -37,6 +37,7 @@ def _hipcc():
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("les_hip.hip", "les_kernels.h", "les_march.h", "les_march_lab.h", "les_propose.h", "les_post.h", "les_pairwise.h", "les_maxflow.h", "les_maxflow_tiled.h", "les_simt.h")]
     srcs.append(os.path.join(ROOT, "include", "localexp_hip.h"))
+    srcs += [os.path.join(HOST, f) for f in ("ResidualCut.h", "GridMaxFlow.h", "GridPushRelabel.h", "BandPool.h")]      # the host cores' finisher of the tiled max-flow
     if not force and _newer(HIP_SO, srcs):
         return HIP_SO
     cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", HIP_SO] + HIPCC_LIBS

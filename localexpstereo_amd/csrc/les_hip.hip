@@ -13,8 +13,11 @@
 #include "les_maxflow.h"
 #include "les_maxflow_tiled.h"
 
+#include "../host/ResidualCut.h"      // the host cores' finisher of the tiled max-flow (plain C++: search trees / push-relabel on a residual graph)
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <mutex>
 #if !defined(LES_SIM)
@@ -157,6 +160,8 @@ const MarchEntry* find_march(int R, int wide = 1)
 
 constexpr long long kRawPatchCapFloats = 1ll << 30;   // 4 GB of raw-cost patches per batch and view (image-based energy on the march kernel)
 constexpr int kRansacMaxSam = 500;   // RansacProposer default MAX_SAM, LES/Proposer.h:265
+constexpr int kRansacChunks = 5;
+constexpr int kRansacChunkEnds[kRansacChunks] = {16, 64, 128, 256, kRansacMaxSam};   // the candidates are evaluated in chunks that end here (les_propose.h)
 
 struct ViewData {
     float* vol = nullptr;
@@ -175,6 +180,9 @@ struct ViewData {
 };
 
 }  // namespace
+
+struct MtHost;
+namespace { void mt_host_free(MtHost* m); }
 
 struct les_hip_ctx {
     les_hip_params p;
@@ -202,6 +210,7 @@ struct les_hip_ctx {
     bool maxflow_lds_ready = false;      // the per-device dynamic-LDS opt-in of les_maxflow_kernel has been made on this context's device
     bool maxflow_tiled_lds_ready = false;   // ... and of les_maxflow_tiled_kernel
     std::vector<les_hip_scratch*> own_scratch;   // scratch objects created behind les_hip_unary_one (one per calling thread), freed with the context
+    std::vector<MtHost*> mt_idle; // host-mapped flag words + hand-over staging of the tiled max-flow: one per CONCURRENT caller, reused, freed with the context
 };
 
 struct les_hip_batch {
@@ -225,7 +234,7 @@ struct les_hip_batch {
     // cell geometry for the proposers / WTA
     les::Rect4* d_units = nullptr;
     les::WtaJob* d_targets = nullptr;
-    les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // RANSAC proposer scratch
+    les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};   // RANSAC proposer scratch
     int wta_chunks = 1;                  // blocks per target rect in the WTA kernel
     // expansion-graph payload layout (les_hip_batch_expansion_graph): node offset of every target, total node count
     std::vector<long long> graph_off;
@@ -628,6 +637,74 @@ float naive_alpha(const les_hip_ctx* c) { return c->naive_alpha; }
 
 }  // namespace
 
+// Host side of one tiled solve in flight: the host-mapped words the kernels report through (pinned, fine-grained: the kernel adds to them with
+// system-scope atomics, the host reads them after synchronising its stream -- the progress check of a lock-step costs no copy) and the pinned
+// staging of the hand-over (les_maxflow_tiled.h: residual graphs out, masks and flow values back).  A context keeps a pool of them: a call
+// takes one, returns it at the end; they are freed with the context (round 5 kept two words per host THREAD for ever).
+struct MtHost {
+    int* h_flags = nullptr; int* d_flags = nullptr;                    // [0] cells finished, [1] of them: gave up, [2] cells handed over, [3] their nodes
+    char* h_stage = nullptr; char* d_stage = nullptr;                  // rc8 [cap_nodes][8] floats | ex [cap_nodes] floats | masks [cap_nodes] bytes | list [cap_cells] | flows [cap_cells]
+    long long cap_nodes = 0;
+    int cap_cells = 0;
+    size_t off_ex() const { return (size_t)cap_nodes * 32; }
+    size_t off_masks() const { return (size_t)cap_nodes * 36; }
+    size_t off_list() const { return ((size_t)cap_nodes * 37 + 255) & ~(size_t)255; }
+    size_t off_flows() const { return off_list() + (size_t)cap_cells * sizeof(les::MtHandCell); }
+    size_t bytes() const { return off_flows() + (size_t)cap_cells * sizeof(double); }
+};
+namespace {
+void mt_host_free(MtHost* m)
+{
+    if (!m) return;
+    if (m->h_flags) (void)hipHostFree(m->h_flags);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
+    delete m;
+}
+int mt_host_map(void** h, void** d, size_t bytes)
+{
+#if defined(LES_SIM)
+    HIPCHECK(hipHostMalloc(h, bytes, 0));
+    *d = *h;
+#else
+    HIPCHECK(hipHostMalloc(h, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHECK(hipHostGetDevicePointer(d, *h, 0));
+#endif
+    return LES_HIP_OK;
+}
+int mt_host_acquire(les_hip_ctx* c, MtHost** out)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->mt_idle.empty()) { *out = c->mt_idle.back(); c->mt_idle.pop_back(); return LES_HIP_OK; }
+    }
+    MtHost* m = new MtHost();
+    const int rc = mt_host_map((void**)&m->h_flags, (void**)&m->d_flags, 64);
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return LES_HIP_OK;
+}
+void mt_host_release(les_hip_ctx* c, MtHost* m)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->mt_idle.push_back(m);
+}
+// staging for `nodes` graph nodes (37 bytes each) of `cells` cells, grown on demand
+int mt_host_stage(MtHost* m, long long nodes, int cells)
+{
+    if (m->cap_nodes >= nodes && m->cap_cells >= cells) return LES_HIP_OK;
+    if (m->h_stage) { (void)hipHostFree(m->h_stage); m->h_stage = nullptr; }
+    m->cap_nodes = std::max(m->cap_nodes, (nodes + 4095) & ~4095ll);
+    m->cap_cells = std::max(m->cap_cells, (cells + 15) & ~15);
+    const int rc = mt_host_map((void**)&m->h_stage, (void**)&m->d_stage, m->bytes());
+    if (rc) { m->cap_nodes = 0; m->cap_cells = 0; return rc; }
+    return LES_HIP_OK;
+}
+struct MtHostLease {                       // returns the MtHost to the pool on every exit path
+    les_hip_ctx* c; MtHost* m;
+    ~MtHostLease() { if (m) mt_host_release(c, m); }
+};
+}  // namespace
+
 extern "C" {
 
 const char* les_hip_last_error(void) { return g_err.c_str(); }
@@ -737,6 +814,8 @@ void les_hip_destroy(les_hip_ctx* c)
     }
     for (les_hip_scratch* sc : c->own_scratch) les_hip_scratch_destroy(sc);
     c->own_scratch.clear();
+    for (MtHost* m : c->mt_idle) mt_host_free(m);
+    c->mt_idle.clear();
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_wta) (void)hipFree(c->d_wta);
@@ -892,6 +971,7 @@ void les_hip_batch_destroy(les_hip_batch* b)
     if (b->rs.noi) (void)hipFree(b->rs.noi);
     if (b->rs.no) (void)hipFree(b->rs.no);
     if (b->rs.refit) (void)hipFree(b->rs.refit);
+    if (b->rs.cell) (void)hipFree(b->rs.cell);
     delete b;
 }
 
@@ -916,6 +996,7 @@ int les_hip_batch_set_units(les_hip_ctx* c, les_hip_batch* b, const les_hip_rect
         HIPCHECK(hipMalloc((void**)&b->rs.noi, n * S * sizeof(int)));
         HIPCHECK(hipMalloc((void**)&b->rs.no, n * S * sizeof(int)));
         HIPCHECK(hipMalloc((void**)&b->rs.refit, n * S * 3 * sizeof(float)));
+        HIPCHECK(hipMalloc((void**)&b->rs.cell, n * sizeof(les::RansacCell)));
     }
     if (b->rs.disp) HIPCHECK(hipFree(b->rs.disp));
     b->rs.disp = nullptr;
@@ -945,9 +1026,15 @@ int les_hip_batch_propose(les_hip_ctx* c, const les_hip_batch* b, int kind, int 
     case LES_HIP_PROPOSE_RANSAC:
         // RansacProposer(K, MAX_SAM = 500, conf = 0.95), threshold 1.0 (LES/Proposer.h:265,305)
         hipLaunchKernelGGL(les::les_ransac_snapshot_kernel, dim3(n), dim3(256), 0, cur_stream(c), b->d_units, lab, W, b->rs);
-        hipLaunchKernelGGL(les::les_ransac_draw_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, b->rs, n, kRansacMaxSam);
-        hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (kRansacMaxSam + 15) / 16), dim3(64), 0, cur_stream(c), b->d_units, b->rs, kRansacMaxSam, 1.0f);
-        hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f);
+        // the reference's adaptive schedule (:193, :229-236): candidates in chunks, a cell whose loop has ended ignores the later launches
+        // (no host round trip: the launches of dead chunks return at once)
+        hipLaunchKernelGGL(les::les_ransac_begin_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, b->rs, n, kRansacMaxSam, kRansacChunkEnds[0]);
+        for (int k = 0, j0 = 0; k < kRansacChunks; k++) {
+            const int j1 = kRansacChunkEnds[k], j2 = k + 1 < kRansacChunks ? kRansacChunkEnds[k + 1] : kRansacMaxSam;
+            hipLaunchKernelGGL(les::les_ransac_eval_kernel, dim3(n, (j1 - j0 + 15) / 16), dim3(64), 0, cur_stream(c), b->d_units, b->rs, kRansacMaxSam, 1.0f, j0, j1);
+            hipLaunchKernelGGL(les::les_ransac_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, cur_stream(c), b->d_units, rng, pl, b->rs, n, kRansacMaxSam, 0.95f, j0, j1, j2);
+            j0 = j1;
+        }
         break;
     case LES_HIP_PROPOSE_INIT:
         hipLaunchKernelGGL(les::les_init_labels_kernel, dim3(n), dim3(64), 0, cur_stream(c), b->d_units, lab, W, rng, pl, mind, maxd);
@@ -1040,6 +1127,12 @@ long long les_hip_batch_max_cell_nodes(const les_hip_batch* b)
 
 int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows)
 {
+    return les_hip_batch_solve_graphs_counted(c, b, d_payload, d_masks, d_status, d_flows, nullptr);
+}
+
+int les_hip_batch_solve_graphs_counted(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows,
+                                       int* d_unsolved_total)
+{
     if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !d_payload || !d_masks || !d_status) return fail(LES_HIP_ERR_ARG, "null argument");
     if (b->n == 0) return LES_HIP_OK;
@@ -1071,9 +1164,9 @@ int les_hip_batch_solve_graphs(les_hip_ctx* c, const les_hip_batch* b, const flo
     int max_iter = les::kMfMaxIter;
     if (const char* ev = getenv("LES_HIP_MAXFLOW_MAX_ITER")) max_iter = std::max(0, atoi(ev));      // tests of the callers' host fall-back
     if (maxn <= 2048)
-        hipLaunchKernelGGL((les::les_maxflow_kernel<2, 1024>), dim3(b->n), dim3(1024), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL((les::les_maxflow_kernel<2, 1024>), dim3(b->n), dim3(1024), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows, d_unsolved_total);
     else
-        hipLaunchKernelGGL((les::les_maxflow_kernel<5, 512>), dim3(b->n), dim3(512), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows);
+        hipLaunchKernelGGL((les::les_maxflow_kernel<5, 512>), dim3(b->n), dim3(512), lds, cur_stream(c), cells, b->d_graph_off, d_payload, np, max_iter, d_masks, d_status, d_flows, d_unsolved_total);
     HIPCHECK(hipGetLastError());
     return LES_HIP_OK;
 }
@@ -1138,24 +1231,29 @@ long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* b)
     return (long long)les::mt_layout(std::max<long long>(1, b->graph_nodes), std::max(1, b->n)).total;
 }
 
-namespace {
-// Two host-mapped words per calling thread (pinned, fine-grained: the kernel adds to them with system-scope atomics, the host reads them after
-// synchronising its stream -- the progress check of a lock-step costs no copy).  Allocated on the thread's first call.
-struct MtHostFlags {
-    int* h = nullptr; int* d = nullptr; int device = -1;
-    // (no destructor: a thread's -- in particular the main thread's -- thread_local objects are destroyed when the HIP runtime may already be gone;
-    //  64 pinned bytes per thread that ever cut are returned with the process)
-};
-thread_local MtHostFlags tl_mt_flags;
-}  // namespace
-
 int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows,
                                      void* d_workspace, long long workspace_bytes, int* launches_out, int* unsolved_out)
 {
+    les_hip_tiled_stats st;
+    const int rc = les_hip_batch_solve_graphs_tiled_stats(c, b, d_payload, d_masks, d_status, d_flows, d_workspace, workspace_bytes, &st);
+    if (launches_out) *launches_out = st.launches;
+    if (unsolved_out) *unsolved_out = st.unsolved;
+    return rc;
+}
+
+int les_hip_batch_solve_graphs_tiled_stats(les_hip_ctx* c, const les_hip_batch* b, const float* d_payload, unsigned char* d_masks, int* d_status, double* d_flows,
+                                           void* d_workspace, long long workspace_bytes, les_hip_tiled_stats* stats)
+{
+    int launches_tmp = 0, unsolved_tmp = 0, handed_tmp = 0;
+    int *launches_out = &launches_tmp, *unsolved_out = &unsolved_tmp, *handed_out = &handed_tmp;
+    long long handed_nodes = 0;
+    double host_ms = 0.0;
+    struct Report {                                       // fills *stats on every exit path
+        les_hip_tiled_stats* s; int *l, *u, *h; long long* hn; double* ms;
+        ~Report() { if (s) { s->launches = *l; s->unsolved = *u; s->handed_cells = *h; s->handed_nodes = *hn; s->host_ms = *ms; } }
+    } report{stats, launches_out, unsolved_out, handed_out, &handed_nodes, &host_ms};
     if (c) (void)hipSetDevice(c->p.device);                 // HIP's current device is per host thread
     if (!c || !b || !d_payload || !d_masks || !d_status || !d_workspace) return fail(LES_HIP_ERR_ARG, "null argument");
-    if (launches_out) *launches_out = 0;
-    if (unsolved_out) *unsolved_out = 0;
     if (b->n == 0) return LES_HIP_OK;
     if (workspace_bytes < les_hip_batch_tiled_workspace_bytes(b))
         return fail(LES_HIP_ERR_ARG, "les_hip_batch_solve_graphs_tiled: workspace of %lld bytes, %lld needed (les_hip_batch_tiled_workspace_bytes)", workspace_bytes,
@@ -1196,39 +1294,108 @@ int les_hip_batch_solve_graphs_tiled(les_hip_ctx* c, const les_hip_batch* b, con
     a.masks = d_masks;
     a.status = d_status;
     a.flows = d_flows;
-    MtHostFlags& hf = tl_mt_flags;
-    if (!hf.h || hf.device != c->p.device) {
-        if (hf.h) { (void)hipHostFree(hf.h); hf.h = nullptr; }
-#if defined(LES_SIM)
-        HIPCHECK(hipHostMalloc((void**)&hf.h, 64, 0));
-        hf.d = hf.h;
-#else
-        HIPCHECK(hipHostMalloc((void**)&hf.h, 64, hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCHECK(hipHostGetDevicePointer((void**)&hf.d, hf.h, 0));
-#endif
-        hf.device = c->p.device;
-    }
-    volatile int* flags = hf.h;
-    flags[0] = 0; flags[1] = 0;                             // (the previous call on this thread has synchronised: nothing in flight writes them)
-    a.host_flags = hf.d;
+    MtHostLease lease{c, nullptr};
+    rc = mt_host_acquire(c, &lease.m);
+    if (rc) return rc;
+    MtHost& hf = *lease.m;
+    volatile int* flags = hf.h_flags;
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;   // (nothing in flight writes them: the previous user of this MtHost has synchronised)
+    a.host_flags = hf.d_flags;
     hipLaunchKernelGGL(les::les_maxflow_tiled_init_kernel, dim3((b->n + 255) / 256), dim3(256), 0, st, a.ws, a.nodes, a.ncells, b->d_mt_tiles_per_cell, d_status, d_flows, a.host_flags);
     HIPCHECK(hipGetLastError());
+    if (b->mt_ntiles == 0) {                                // every target rect is empty: the init kernel has closed all cells
+        HIPCHECK(hipStreamSynchronize(st));
+        return LES_HIP_OK;
+    }
+    // Hand-over policy (les_maxflow_tiled.h, host/ResidualCut.h): after `hand_after` launches, as soon as at most `hand_cells` cells of at most
+    // `hand_nodes` nodes in total are still open, the host cores finish them from their residual graphs.  LES_HIP_MAXFLOW_HANDOVER=0 switches it off
+    // (every cell is then cut by launches alone, as in round 5); ..._AFTER / _CELLS / _NODES override the thresholds (A/B measurements).
+    // A lock-step that is still running after `hand_all_after` launches hands over whatever is open (the launches would go on for hundreds more: the
+    // status-1 exit of round 5 at 2 000 launches remains for a hand-over that is switched off).
+    int hand_after = 28, hand_cells = 8, hand_all_after = 300;
+    long long hand_nodes = 400000;
+    bool hand = true;
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_HANDOVER")) hand = atoi(ev) != 0;
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_HANDOVER_AFTER")) hand_after = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_HANDOVER_CELLS")) hand_cells = std::max(1, atoi(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_HANDOVER_NODES")) hand_nodes = std::max(1ll, atoll(ev));
+    if (const char* ev = getenv("LES_HIP_MAXFLOW_HANDOVER_ALL_AFTER")) hand_all_after = std::max(1, atoi(ev));
     // Launches are enqueued in groups; after each group the host reads "cells done" (the only synchronisation).  Launches that come
     // after the last cell finished return at once.
-    int total = 0, group = 12;
+    int total = 0, group = 12, handed = 0;
     for (;;) {
         for (int i = 0; i < group; i++)
-            hipLaunchKernelGGL(les::les_maxflow_tiled_kernel, dim3(std::max(1, b->mt_ntiles)), dim3(les::kMtThreads), les::kMtLdsBytes, st, a);
+            hipLaunchKernelGGL(les::les_maxflow_tiled_kernel, dim3(b->mt_ntiles), dim3(les::kMtThreads), les::kMtLdsBytes, st, a);
         total += group;
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(st));
         const int done = flags[0];
         if (done >= b->n) break;
+        const bool everything = total >= hand_all_after;
+        if (hand && total >= hand_after && (b->n - done <= hand_cells || everything)) {
+            const int want_cells = everything ? b->n - done : hand_cells;
+            const long long want_nodes = everything ? b->graph_nodes : std::min<long long>(hand_nodes, b->graph_nodes);
+            rc = mt_host_stage(&hf, want_nodes, want_cells);
+            if (rc) return rc;
+            les::MtHandArgs ha;
+            ha.tiles = b->d_mt_tiles; ha.ws = a.ws; ha.nodes = a.nodes; ha.ncells = a.ncells; ha.cells = a.cells;
+            ha.max_cells = want_cells; ha.max_nodes = want_nodes;
+            ha.list = reinterpret_cast<les::MtHandCell*>(hf.d_stage + hf.off_list());
+            ha.rc8 = reinterpret_cast<float*>(hf.d_stage);
+            ha.ex = reinterpret_cast<float*>(hf.d_stage + hf.off_ex());
+            ha.hmasks = reinterpret_cast<const uint8_t*>(hf.d_stage + hf.off_masks());
+            ha.hflows = reinterpret_cast<const double*>(hf.d_stage + hf.off_flows());
+            ha.masks = d_masks; ha.status = d_status; ha.flows = d_flows; ha.host_flags = hf.d_flags;
+            hipLaunchKernelGGL(les::les_maxflow_tiled_collect_kernel, dim3(1), dim3(64), 0, st, ha);
+            hipLaunchKernelGGL(les::les_maxflow_tiled_pack_kernel, dim3(b->mt_ntiles), dim3(les::kMtThreads), 0, st, ha);      // (nothing to pack when the policy said no)
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(st));
+            handed = flags[2];
+            if (handed > 0) {
+                handed_nodes = flags[3];
+                const auto h0 = std::chrono::steady_clock::now();
+                const float* h_rc8 = reinterpret_cast<const float*>(hf.h_stage);
+                const float* h_ex = reinterpret_cast<const float*>(hf.h_stage + hf.off_ex());
+                uint8_t* h_masks = reinterpret_cast<uint8_t*>(hf.h_stage + hf.off_masks());
+                const les::MtHandCell* list = reinterpret_cast<const les::MtHandCell*>(hf.h_stage + hf.off_list());
+                double* hflows = reinterpret_cast<double*>(hf.h_stage + hf.off_flows());
+                const std::vector<les_hip_rect>& tg = b->targets;
+                const char* sev = getenv("LES_HIP_MAXFLOW_HANDOVER_SOLVER");      // 1 (default): FIFO push-relabel; 0: search trees with the push-relabel continuation (measured slower on what is handed over: tools/residual_probe.py)
+                const int solver = sev ? atoi(sev) : 1;
+                if (const char* dump = getenv("LES_HIP_MAXFLOW_HANDOVER_DUMP")) {      // tooling: the residual graphs as handed over (tools/residual_probe.py)
+                    if (FILE* f = fopen(dump, "wb")) {
+                        const long long hn = flags[3];
+                        fwrite(&handed, sizeof(int), 1, f); fwrite(&hn, sizeof(long long), 1, f);
+                        for (int q = 0; q < handed; q++) { const int wh[2] = {tg[(size_t)list[q].cell].w, tg[(size_t)list[q].cell].h}; fwrite(wh, sizeof(int), 2, f); fwrite(&list[q].hoff, sizeof(long long), 1, f); }
+                        fwrite(h_rc8, sizeof(float), (size_t)hn * 8, f); fwrite(h_ex, sizeof(float), (size_t)hn, f);
+                        fclose(f);
+                    }
+                }
+                // one host thread per cell, at most as many as the process may keep busy (a persistent team owned by the calling thread); the large
+                // cells split their phases over row bands as the host cuts do
+                const int team = std::max(1, std::min(handed, les_host::cpuBudget()));
+                std::atomic<int> next{0};
+                les_host::BandPool::mine().run(team, [&](int) {
+                    for (int q = next.fetch_add(1); q < handed; q = next.fetch_add(1)) {
+                        const int cell = list[q].cell;
+                        const int w = tg[(size_t)cell].w, h = tg[(size_t)cell].h;
+                        hflows[q] = les_host::finishResidualCut(h_rc8 + 8 * list[q].hoff, h_ex + list[q].hoff, w, h, h_masks + list[q].hoff, les_host::residualBands(w, h), solver);
+                    }
+                });
+                host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+                hipLaunchKernelGGL(les::les_maxflow_tiled_unpack_kernel, dim3(b->mt_ntiles), dim3(256), 0, st, ha);
+                HIPCHECK(hipGetLastError());
+                // the staging belongs to the next caller as soon as this MtHost is back in the pool: the unpack kernel must have read it
+                HIPCHECK(hipStreamSynchronize(st));
+                if (done + handed >= b->n) break;
+            }
+        }
         if (total >= a.max_launches + group) return fail(LES_HIP_ERR_DEVICE, "les_hip_batch_solve_graphs_tiled: %d of %d cells still open after %d launches", b->n - done, b->n, total);
         group = 16;
     }
-    if (launches_out) *launches_out = total;
-    if (unsolved_out) *unsolved_out = flags[1];
+    *launches_out = total;
+    *unsolved_out = flags[1];
+    *handed_out = handed;
     return LES_HIP_OK;
 }
 

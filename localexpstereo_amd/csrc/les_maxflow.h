@@ -60,7 +60,8 @@ __host__ __device__ inline int mf_dy(int k) { return (int)((0x02020211u >> (4 * 
 template <int kMfNodesPerThread, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS / 128)
 les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __restrict__ offsets, const float* __restrict__ payload,
-                   int nmax_padded, int max_iter, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows)
+                   int nmax_padded, int max_iter, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows,
+                   int* __restrict__ unsolved_total)         // optional: += 1 per cell that hits the iteration limit (callers that check once per several launches)
 {
 #if defined(LES_SIM)
     static thread_local float s_raw[(kMfMaxNodes * 46 + 4160) / 4 + 16];
@@ -308,6 +309,7 @@ les_maxflow_kernel(const GraphCellMf* __restrict__ cells, const long long* __res
 #else
         status[blockIdx.x] = converged ? 0 : 1;
         if (flows) flows[blockIdx.x] = red[0];
+        if (!converged && unsolved_total) atomicAdd(unsolved_total, 1);
 #endif
     }
 }

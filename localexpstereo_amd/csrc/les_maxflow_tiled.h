@@ -25,7 +25,8 @@
 // push keeps a feasible preflow whatever the heights are, and the loop only ends on an EXACT relabelling that finds no excess able
 // to reach the sink -- a maximum preflow, whose sink-side set is unique.  Pushes go downhill (height(v) > height(w)), which is the
 // usual rule under a valid labelling and does not stall under a momentarily invalid one.  Everything is deterministic: a node is
-// the only writer of its residuals, and what it receives it adds in the fixed order of the eight directions (no float atomics).
+// the only writer of its residuals, what it receives it adds in the fixed order of the eight directions, heights are relabelled from a
+// snapshot (stored after a barrier), and the flow value is a sum of 64-bit integers (no float atomics).
 // tools/tiled_pr_probe.py is the numpy model this was designed with (cuts identical to the host solver on dumped lock-steps).
 #pragma once
 
@@ -46,14 +47,20 @@ static_assert(kMtThreads * kMtNpt >= kMtMaxTileNodes, "every node needs an owner
 constexpr size_t kMtLdsBytes = (size_t)kMtMaxHalo * 4 + (size_t)kMtMaxTileNodes * (4 + 8 * 4 + 1) + 64 + 3 * 72 * 4;
 static_assert(2 * kMtLdsBytes <= 160 * 1024, "two workgroups per CU");
 
-enum MtPhase : int { kMtRelabel0 = 0, kMtRelabel = 1, kMtDischarge = 2, kMtFinal = 3, kMtDone = 4 };
+enum MtPhase : int { kMtRelabel0 = 0, kMtRelabel = 1, kMtDischarge = 2, kMtFinal = 3, kMtDone = 4, kMtHandover = 5 };      // (>= kMtDone: the launches leave the cell alone)
+constexpr int kMtFlowShift = 22;                           // flow values are accumulated as 64-bit integers in units of 2^-22 (integer additions commute: the sum over the tiles is the same in any order)
 
 struct MtTile { int cell, x0, y0, tw, th, W, H, pad; long long off, pad2; };   // cell-local rectangle + the cell's size and node offset; 48 B
 struct MtCtl {                                                                // per cell; 64 B
     int phase, arrived, changed, active;
     int parity, sweeps, launches, rounds;
-    int ntiles, pad[7];
+    int ntiles, hand;                 // hand: the cell's slot in the hand-over list (kMtHandover)
+    long long hoff;                   // ... and its node offset in the hand-over staging arrays
+    long long flow_fix;               // sink capacity at load time minus what is left of it, in units of 2^-kMtFlowShift
+    int pad[2];
 };
+static_assert(sizeof(MtCtl) == 64, "one control record per 64 bytes");
+struct MtHandCell { int cell, pad; long long hoff; };                         // one entry of the hand-over list (host-mapped)
 struct MtHeader { int cells_done, cells_failed, pad[14]; };                   // 64 B at the start of the workspace (device-side copy of the two counters)
 
 // workspace carve-up for `nodes` graph nodes and `cells` cells (all regions 256-byte aligned)
@@ -84,17 +91,8 @@ __device__ inline int mt_load(const int* p) { return __atomic_load_n(p, __ATOMIC
 __device__ inline void mt_store(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 __device__ inline void mt_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 __device__ inline void mt_host_add(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-__device__ inline void mt_atomic_add_f64(double* p, double v)
-{
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    unsigned long long old = __atomic_load_n(q, __ATOMIC_RELAXED), nw;
-    do {
-        double d;
-        memcpy(&d, &old, 8);
-        d += v;
-        memcpy(&nw, &d, 8);
-    } while (!__atomic_compare_exchange_n(q, &old, nw, true, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED));
-}
+__device__ inline void mt_atomic_add_i64(long long* p, long long v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+__device__ inline long long mt_load_i64(const long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 #else
 // Keeps the LDS addresses derived from x inside the loop they are used in: hoisted out of the iteration loop (32 of them are loop
 // invariant) they do not fit the 128 registers and come back from scratch memory on every iteration; recomputing one is one v_add.
@@ -106,7 +104,8 @@ __device__ __forceinline__ int mt_load(const int* p) { return __hip_atomic_load(
 __device__ __forceinline__ void mt_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mt_fence() { __threadfence(); }
 __device__ __forceinline__ void mt_host_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }   // (fine-grained host memory)
-__device__ __forceinline__ void mt_atomic_add_f64(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mt_atomic_add_i64(long long* p, long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long mt_load_i64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 struct MtArgs {
@@ -146,7 +145,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     const int phase = ctl->phase, launch = ctl->launches, parity = ctl->parity;
     const bool first_round = ctl->rounds <= 1;
     const int Kit = first_round ? a.K : a.K2, Ssw = first_round ? a.S : a.S2;
-    if (phase == kMtDone) return;
+    if (phase >= kMtDone) return;
 
     int* hg = reinterpret_cast<int*>(base);                                 // heights / distances, halo-pitched: (th + 2) x (tw + 2)
     float* exs = reinterpret_cast<float*>(hg + kMtMaxHalo);                 // > 0: excess; < 0: remaining capacity to the sink
@@ -333,7 +332,7 @@ les_maxflow_tiled_kernel(MtArgs a)
                 if (tid < s2) red[tid] += red[tid + s2];
                 __syncthreads();
             }
-            if (tid == 0 && red[0] != 0.0) mt_atomic_add_f64(a.flows + t.cell, red[0]);
+            if (tid == 0 && red[0] != 0.0) mt_atomic_add_i64(&ctl->flow_fix, (long long)rint(red[0] * (double)(1ll << kMtFlowShift)));
         }
         __syncthreads();
         relax(rm);
@@ -413,6 +412,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             // ---- K synchronous iterations: pushes | barrier | receive + relabel | barrier.  All LDS reads of a step are issued together and
             // unconditionally (a chain of conditional reads costs a round trip each); a wave none of whose lanes has work skips the step.
             for (int it = 0; it < Kit; it++) {
+                int hnew[kMtNpt];                                             // heights this iteration's relabel raises (-1: unchanged)
                 const int fl = 8 + it % 3;
                 if (tid == 0) sflag[8 + (it + 1) % 3] = 0;
                 bool act = false;
@@ -462,6 +462,8 @@ les_maxflow_tiled_kernel(MtArgs a)
                     bool f[kMtNpt];
                     uint8_t fb[kMtNpt];
 #pragma unroll
+                    for (int j = 0; j < kMtNpt; j++) hnew[j] = -1;
+#pragma unroll
                     for (int j = 0; j < kMtNpt; j++) {
                         const int v = has[j] ? tid + j * kMtThreads : 0;
                         e[j] = exs[v];
@@ -498,8 +500,8 @@ les_maxflow_tiled_kernel(MtArgs a)
                         }
                         const bool on = has[j] && e[j] > 0.0f && hv[j] < BIG;
                         if (!mt_wave_any(on)) continue;
-                        // relabel when no residual arc leads downhill: in place -- heights only rise, and a neighbour that reads the old or
-                        // the new value computes a valid (lower-bound) height either way
+                        // relabel when no residual arc leads downhill -- from a SNAPSHOT: the new height is kept in a register and stored after the
+                        // barrier below, so that what a neighbour reads in this half never depends on which wave ran first (bit-reproducible flows)
                         int hw[8];
                         int hij = hi[j];
                         MT_OPAQUE(hij);
@@ -509,13 +511,17 @@ les_maxflow_tiled_kernel(MtArgs a)
                         int best = BIG;
 #pragma unroll
                         for (int k = 0; k < 8; k++) best = (r[j][k] > 0.0f && hw[k] + 1 < best) ? hw[k] + 1 : best;
-                        if (best > hv[j]) hg[hi[j]] = best;
+                        if (best > hv[j]) hnew[j] = best;
                         if (best < BIG) act = true;
                     }
                 }
                 if (act) sflag[fl] = 1;
                 __syncthreads();
-                if (!sflag[fl]) break;
+#pragma unroll
+                for (int j = 0; j < kMtNpt; j++)
+                    if (hnew[j] >= 0) hg[hi[j]] = hnew[j];
+                if (!sflag[fl]) break;                                        // (own heights only from here on: the write-back below reads hg[hi[j]])
+                __syncthreads();
             }
             // ---- write the tile back
 #pragma unroll
@@ -566,7 +572,7 @@ les_maxflow_tiled_kernel(MtArgs a)
                 if (tid < s2) red[tid] += red[tid + s2];
                 __syncthreads();
             }
-            if (tid == 0 && red[0] != 0.0) mt_atomic_add_f64(a.flows + t.cell, -red[0]);
+            if (tid == 0 && red[0] != 0.0) mt_atomic_add_i64(&ctl->flow_fix, -(long long)rint(red[0] * (double)(1ll << kMtFlowShift)));
         }
     }
 
@@ -589,6 +595,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             else next = kMtDone;
             if (next == kMtDone) {
                 a.status[t.cell] = 0;
+                if (a.flows) a.flows[t.cell] = (double)mt_load_i64(&ctl->flow_fix) * (1.0 / (double)(1ll << kMtFlowShift));      // (every tile's share arrived before its count did)
                 mt_atomic_add(&hdr->cells_done, 1);
                 mt_host_add(a.host_flags, 1);
             } else if (launch + 1 >= a.max_launches) {
@@ -623,6 +630,7 @@ __global__ void les_maxflow_tiled_init_kernel(char* ws, long long nodes, int nce
     c->phase = kMtRelabel0; c->arrived = 0; c->changed = 0; c->active = 0;
     c->parity = 0; c->sweeps = 0; c->launches = 0; c->rounds = 0;
     c->ntiles = tiles_per_cell[i];
+    c->hand = -1; c->hoff = 0; c->flow_fix = 0;
     status[i] = 1;
     if (flows) flows[i] = 0.0;
     if (tiles_per_cell[i] == 0) {                     // an empty cell has nothing to cut
@@ -630,6 +638,141 @@ __global__ void les_maxflow_tiled_init_kernel(char* ws, long long nodes, int nce
         status[i] = 0;
         mt_atomic_add(&reinterpret_cast<MtHeader*>(ws)->cells_done, 1);
         mt_host_add(host_flags, 1);
+    }
+}
+
+// ---- hand-over of straggler cells to the host cores (round 6; host/ResidualCut.h) -------------------------------------------------
+// A lock-step lasts as long as its slowest cell, and the scheme above is at its worst on the tail of a hard cell (a few hundred small
+// excesses, hundreds of launches, one cell's tiles on a 256-CU chip).  Once few cells are still open the host stops enqueueing launches:
+//   collect  (one thread) lists the open cells if they are few enough -- all of them or none --, gives every one a slot and a node offset in
+//            the staging arrays and parks it in kMtHandover (launches leave it alone);
+//   pack     (grid = tiles) writes the residual graph of the parked cells -- 8 residual capacities and the excess of every node, with what
+//            the neighbouring tiles still had in flight folded in exactly as the next launch would have -- into host-mapped memory, and
+//            takes the sink capacity that is left out of the cell's flow value;
+//   the host finishes each cell with a search from the remaining excess nodes (same cut: the residual graph of a feasible preflow has the
+//            minimum cuts of the graph it came from) and writes the masks and the flow it routed into host-mapped memory;
+//   unpack   (grid = tiles) copies the masks into place and completes the flow value and the status word.
+struct MtHandArgs {
+    const MtTile* tiles;
+    char* ws;
+    long long nodes;
+    int ncells;
+    const GraphCellMf* cells;
+    int max_cells;                   // policy: hand over only when at most this many cells ...
+    long long max_nodes;             // ... of at most this many nodes in total are still open
+    MtHandCell* list;                // host-mapped, [max_cells]
+    float* rc8;                      // host-mapped staging: [max_nodes][8]
+    float* ex;                       // [max_nodes]
+    const uint8_t* hmasks;           // [max_nodes], written by the host
+    const double* hflows;            // [max_cells], written by the host: the flow it routed
+    uint8_t* masks;
+    int* status;
+    double* flows;                   // optional
+    int* host_flags;                 // [2] cells handed over, [3] their nodes
+};
+
+__global__ void les_maxflow_tiled_collect_kernel(MtHandArgs a)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const MtLayout L = mt_layout(a.nodes, a.ncells);
+    MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl);
+    int open = 0;
+    long long nodes = 0;
+    for (int i = 0; i < a.ncells; i++)
+        if (ctl[i].phase < kMtDone) { open++; nodes += (long long)a.cells[i].w * a.cells[i].h; }
+    if (open == 0 || open > a.max_cells || nodes > a.max_nodes) { mt_store(a.host_flags + 2, 0); return; }
+    int slot = 0;
+    long long hoff = 0;
+    for (int i = 0; i < a.ncells; i++) {
+        if (ctl[i].phase >= kMtDone) continue;
+        ctl[i].hand = slot; ctl[i].hoff = hoff;
+        ctl[i].phase = kMtHandover;
+        a.list[slot].cell = i; a.list[slot].pad = 0; a.list[slot].hoff = hoff;
+        slot++;
+        hoff += (long long)a.cells[i].w * a.cells[i].h;
+    }
+    mt_fence();
+    mt_store(a.host_flags + 3, (int)hoff);
+    mt_store(a.host_flags + 2, slot);
+}
+
+// grid = tiles of the lock-step; block = kMtThreads
+__global__ void __launch_bounds__(kMtThreads)
+les_maxflow_tiled_pack_kernel(MtHandArgs a)
+{
+#if defined(LES_SIM)
+    static thread_local double red[kMtThreads];
+#else
+    __shared__ double red[kMtThreads];
+#endif
+    const MtTile t = a.tiles[blockIdx.x];
+    const MtLayout L = mt_layout(a.nodes, a.ncells);
+    MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl) + t.cell;
+    if (ctl->phase != kMtHandover) return;
+    const int tid = (int)threadIdx.x;
+    const int parity = ctl->parity;
+    const long long hoff = ctl->hoff;
+    const int W = t.W, H = t.H, tw = t.tw, th = t.th, n = tw * th;
+    const float* g_r = reinterpret_cast<const float*>(a.ws + L.r);
+    const float* g_ex = reinterpret_cast<const float*>(a.ws + L.ex);
+    const float* ob = reinterpret_cast<const float*>(a.ws + L.outbox) + (size_t)(parity ^ 1) * (size_t)a.nodes * 8;     // what is still in flight (zeros outside a discharge)
+    double t_out = 0.0;
+    for (int v = tid; v < n; v += kMtThreads) {
+        const int ly = v / tw, lx = v - ly * tw;
+        const int gx = t.x0 + lx, gy = t.y0 + ly;
+        const long long gl = (long long)gy * W + gx;
+        const size_t gi = (size_t)(t.off + gl);
+        float r[8];
+        const float4* p = reinterpret_cast<const float4*>(g_r + gi * 8);
+        const float4 lo = p[0], hi4 = p[1];
+        r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi4.x; r[5] = hi4.y; r[6] = hi4.z; r[7] = hi4.w;
+        float e = g_ex[gi];
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {            // the sender along k is the neighbour in direction k ^ 1: counted when it lies outside the tile and inside the cell
+            const int sx = lx + mf_dx(k ^ 1), sy = ly + mf_dy(k ^ 1);
+            const int cx = gx + mf_dx(k ^ 1), cy = gy + mf_dy(k ^ 1);
+            const bool out_tile = sx < 0 || sx >= tw || sy < 0 || sy >= th;
+            const bool in_cell = cx >= 0 && cx < W && cy >= 0 && cy < H;
+            g[k] = (out_tile && in_cell) ? ob[(size_t)((long long)gi - ((long long)mf_dy(k) * W + mf_dx(k))) * 8 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (g[k] > 0.0f) { r[k ^ 1] += g[k]; e += g[k]; }
+        float4* q = reinterpret_cast<float4*>(a.rc8 + (size_t)(hoff + gl) * 8);
+        q[0] = make_float4(r[0], r[1], r[2], r[3]);
+        q[1] = make_float4(r[4], r[5], r[6], r[7]);
+        a.ex[hoff + gl] = e;
+        if (e < 0.0f) t_out += (double)(-e);
+    }
+    if (a.flows) {
+        red[tid] = t_out;
+        __syncthreads();
+        for (int s2 = kMtThreads / 2; s2 > 0; s2 >>= 1) {
+            if (tid < s2) red[tid] += red[tid + s2];
+            __syncthreads();
+        }
+        if (tid == 0 && red[0] != 0.0) mt_atomic_add_i64(&ctl->flow_fix, -(long long)rint(red[0] * (double)(1ll << kMtFlowShift)));
+    }
+}
+
+// grid = tiles of the lock-step; block = 256
+__global__ void les_maxflow_tiled_unpack_kernel(MtHandArgs a)
+{
+    const MtTile t = a.tiles[blockIdx.x];
+    const MtLayout L = mt_layout(a.nodes, a.ncells);
+    MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl) + t.cell;
+    if (ctl->phase != kMtHandover) return;
+    const long long hoff = ctl->hoff;
+    const int n = t.tw * t.th;
+    for (int v = (int)threadIdx.x; v < n; v += (int)blockDim.x) {
+        const int ly = v / t.tw, lx = v - ly * t.tw;
+        const long long gl = (long long)(t.y0 + ly) * t.W + t.x0 + lx;
+        a.masks[t.off + gl] = a.hmasks[hoff + gl];
+    }
+    if (threadIdx.x == 0 && t.x0 == 0 && t.y0 == 0) {
+        a.status[t.cell] = 0;
+        if (a.flows) a.flows[t.cell] = (double)mt_load_i64(&ctl->flow_fix) * (1.0 / (double)(1ll << kMtFlowShift)) + a.hflows[ctl->hand];
     }
 }
 

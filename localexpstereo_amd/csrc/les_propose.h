@@ -202,19 +202,23 @@ __device__ inline int ransac_sample_count(int ni, int ptNum, int pf, double conf
     return cnt < 1 ? 1 : cnt;
 }
 
-// RANSACPlane (LES/Proposer.h:177-240) with the reference's sequential semantics, split so that the whole GPU
-// works even when a disjoint set has only a handful of (large) cells:
+// RANSACPlane (LES/Proposer.h:177-240) with the reference's sequential semantics AND its adaptive schedule (`while (no_sam < max_sam)`,
+// :193; `max_sam = min(max_sam, computeSampleCount(...))`, :229-236), split so that the whole GPU works even when a disjoint set has
+// only a handful of (large) cells.  The MAX_SAM candidates are processed in CHUNKS (16, then 48, 64, 128, 244: kRansacChunkEnds);
+// a cell whose loop has ended is marked done and every later launch returns at once for it, so a planar region costs one chunk of 16
+// candidates instead of 500 (round 6; rounds 1-5 evaluated all 500 with a refit each before looking at the stop rule):
 //   snapshot : disparities of the unit region under the current labelling (startIterations, :283-301)
-//   draw     : one lane per cell draws ALL MAX_SAM sample triples in order (the generator is sequential) and
-//              records the generator state after every sample
-//   eval     : one lane per (cell, candidate): solves the 3-point plane, counts its inliers and -- if the candidate
-//              could ever trigger the "better than max_i" branch (no_i > 3) -- computes the least-squares refit on
-//              the inliers among the first no_i points and the refit's inlier count.  None of this depends on the
-//              evolving RANSAC state, so it is embarrassingly parallel over candidates.
-//   walk     : one lane per cell replays the reference's acceptance / adaptive-termination logic over the
-//              precomputed candidates IN ORDER, stops where the sequential algorithm stops and rewinds the
-//              generator to the last consumed sample.
-// Result and generator state are exactly those of the sequential algorithm.
+//   begin    : one lane per cell: loop state (:180-185), draws the sample triples of the first chunk in order (the generator is
+//              sequential) and records the generator state after every sample
+//   eval     : one quad of lanes per (cell, candidate of the chunk that the loop can still reach: j < max_sam): solves the 3-point
+//              plane, counts its inliers and -- only if the candidate can still trigger the "better than max_i" branch (no_i > the
+//              cell's max_i at the start of the chunk; max_i only grows, :234) -- the least-squares refit on the inliers among the
+//              first no_i points and the refit's inlier count.  None of this depends on the state evolving INSIDE the chunk.
+//   walk     : one lane per cell replays the reference's acceptance / adaptive-termination logic over the chunk's candidates IN
+//              ORDER; when the loop ends it rewinds the generator to the last consumed sample and writes the plane, otherwise it
+//              draws the next chunk.
+// Result and generator state are exactly those of the sequential algorithm (and of the all-candidates schedule of rounds 1-5).
+struct RansacCell { int max_i, max_sam, no_sam, no_i_c; float result[3]; int done; };     // loop state of one cell (:180-185); 32 B
 struct RansacScratch {
     float* disp;       // [n][stride]            disparity snapshot
     int* idx;          // [n][MAX_SAM][3]        sample triples
@@ -223,6 +227,7 @@ struct RansacScratch {
     int* no;           // [n][MAX_SAM]           inliers of the refit (-1: not computed)
     float* refit;      // [n][MAX_SAM][3]        refitted plane
     int stride;
+    RansacCell* cell;  // [n]
 };
 
 __global__ void les_ransac_snapshot_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W, RansacScratch sc)
@@ -238,17 +243,14 @@ __global__ void les_ransac_snapshot_kernel(const Rect4* __restrict__ units, cons
     }
 }
 
-__global__ void les_ransac_draw_kernel(const Rect4* __restrict__ units, const uint64_t* __restrict__ rng, RansacScratch sc, int n, int MAX_SAM)
+// samples j0 <= j < j1 of one cell, continuing the generator from the recorded state before sample j0
+__device__ inline void ransac_draw(const Rect4& u, RansacScratch& sc, int cell, int MAX_SAM, int j0, int j1)
 {
-    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (cell >= n) return;
-    const Rect4 u = units[cell];
     const int len = u.w * u.h;
-    Rng r{rng[cell]};
     int* idxp = sc.idx + (size_t)cell * MAX_SAM * 3;
     uint64_t* st = sc.state + (size_t)cell * (MAX_SAM + 1);
-    st[0] = r.state;
-    for (int j = 0; j < MAX_SAM; j++) {
+    Rng r{st[j0]};
+    for (int j = j0; j < j1; j++) {
         // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
         int idx[3];
         for (int i = 0; i < 3; i++) {
@@ -264,22 +266,38 @@ __global__ void les_ransac_draw_kernel(const Rect4* __restrict__ units, const ui
     }
 }
 
-// One QUAD of lanes per (cell, candidate): lane s of the quad scans the rows yy = s (mod 4) of the unit region.
+__global__ void les_ransac_begin_kernel(const Rect4* __restrict__ units, const uint64_t* __restrict__ rng, RansacScratch sc, int n, int MAX_SAM, int first)
+{
+    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cell >= n) return;
+    RansacCell c;
+    c.max_i = 3; c.max_sam = MAX_SAM; c.no_sam = 0; c.no_i_c = 0;      // :180-185
+    c.result[0] = c.result[1] = c.result[2] = 0.0f; c.done = 0;
+    sc.cell[cell] = c;
+    sc.state[(size_t)cell * (MAX_SAM + 1)] = rng[cell];
+    ransac_draw(units[cell], sc, cell, MAX_SAM, 0, first < MAX_SAM ? first : MAX_SAM);
+}
+
+// Candidates j0 <= j < j1 of every cell that is still running.  One QUAD of lanes per (cell, candidate): lane s of the quad scans the
+// rows yy = s (mod 4) of the unit region.
 // Inlier counts are integer sums over the quad.  The normal equations of the refit are accumulated per lane in
 // increasing (row, column) order and combined as (p0 + p1) + (p2 + p3): a DEFINED order, shared with the host RansacProposer
 // (host/Proposer.h), so that the per-call drop-in loop and the device proposals are bit-identical.  (The test oracle sums in the
 // natural row order since round 4; the comparison with it is to float round-off.)
-__global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold)
+__global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold, int j0, int j1)
 {
     const int cell = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
-    const int j = (int)blockIdx.y * ((int)blockDim.x / 4) + (tid >> 2);    // candidate
+    const RansacCell cs = sc.cell[cell];
+    const int jend = j1 < cs.max_sam ? j1 : cs.max_sam;                    // the loop never reaches a candidate at or beyond max_sam (it only shrinks)
+    if (cs.done || j0 + (int)blockIdx.y * ((int)blockDim.x / 4) >= jend) return;
+    const int j = j0 + (int)blockIdx.y * ((int)blockDim.x / 4) + (tid >> 2);    // candidate
     const int sub = tid & 3;                                               // row phase of this lane
-    const bool live = j < MAX_SAM;                                          // whole quads are live or not
+    const bool live = j < jend;                                             // whole quads are live or not
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     const float* disp = sc.disp + (size_t)cell * sc.stride;
-    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + (live ? j : 0)) * 3;
+    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + (live ? j : j0)) * 3;
 
     // visits this lane's rows of the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
     auto scan = [&](int upto, const float N[3], auto&& f) {
@@ -315,9 +333,9 @@ __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacSc
     const int no_i = quad_sum(cnt);
     int no = -1;
     float N2[3] = {0, 0, 0};
-    // max_i starts at 3 and only grows (:180,:234): candidates with no_i <= 3 can never enter the refit branch.
-    // no_i is uniform over the quad, so the quad operations below are executed by whole quads.
-    if (no_i > 3) {
+    // max_i starts at 3 and only grows (:180,:234): a candidate with no_i <= the cell's max_i at the start of this chunk can never
+    // enter the refit branch.  no_i is uniform over the quad, so the quad operations below are executed by whole quads.
+    if (no_i > cs.max_i) {
         // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound quirk, :216)
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                   // xx xy x yy y 1 | xd yd d
         scan(no_i, N, [&](float x, float y, float d, bool in) {
@@ -344,33 +362,40 @@ __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacSc
     }
 }
 
+// the loop of :193-237 over the candidates j0 <= j < j1 of every running cell; draws the candidates j1 <= j < j2 when the loop goes on
 __global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t* __restrict__ rng, float4* __restrict__ planes,
-                                       RansacScratch sc, int n, int MAX_SAM, float conf)
+                                       RansacScratch sc, int n, int MAX_SAM, float conf, int j0, int j1, int j2)
 {
     const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (cell >= n) return;
+    RansacCell c = sc.cell[cell];
+    if (c.done) return;
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     const size_t base = (size_t)cell * MAX_SAM;
-    int max_i = 3, max_sam = MAX_SAM, no_sam = 0, no_i_c = 0;          // :180-185
-    float result[3] = {0, 0, 0};
-    while (no_sam < max_sam) {                                         // :193
-        const int j = no_sam;
-        no_sam++;
+    while (c.no_sam < c.max_sam && c.no_sam < j1) {                    // :193
+        const int j = c.no_sam;
+        c.no_sam++;
         const int no_i = sc.noi[base + j];
-        if (max_i < no_i) {                                            // :208
+        if (c.max_i < no_i) {                                          // :208
             const int no = sc.no[base + j];
-            if (no > no_i_c) {                                         // :229-236
-                result[0] = sc.refit[(base + j) * 3]; result[1] = sc.refit[(base + j) * 3 + 1]; result[2] = sc.refit[(base + j) * 3 + 2];
-                no_i_c = no;
-                max_i = no_i;
+            if (no > c.no_i_c) {                                       // :229-236
+                c.result[0] = sc.refit[(base + j) * 3]; c.result[1] = sc.refit[(base + j) * 3 + 1]; c.result[2] = sc.refit[(base + j) * 3 + 2];
+                c.no_i_c = no;
+                c.max_i = no_i;
                 const int cnt = ransac_sample_count(no, len, 3, conf);
-                max_sam = max_sam < cnt ? max_sam : cnt;
+                c.max_sam = c.max_sam < cnt ? c.max_sam : cnt;
             }
         }
     }
-    planes[cell] = make_float4(result[0], result[1], result[2], 0.0f);   // :239
-    rng[cell] = sc.state[(size_t)cell * (MAX_SAM + 1) + no_sam];          // state after the last consumed sample
+    if (c.no_sam >= c.max_sam) {
+        c.done = 1;
+        planes[cell] = make_float4(c.result[0], c.result[1], c.result[2], 0.0f);   // :239
+        rng[cell] = sc.state[(size_t)cell * (MAX_SAM + 1) + c.no_sam];              // state after the last consumed sample
+    } else {
+        ransac_draw(u, sc, cell, MAX_SAM, j1, j2 < c.max_sam ? j2 : c.max_sam);
+    }
+    sc.cell[cell] = c;
 }
 
 }  // namespace les

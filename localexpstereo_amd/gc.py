@@ -11,7 +11,7 @@ from . import api
 
 DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "liblocalexp_host.so")
 SYMBOLS = ["les_gc_create", "les_gc_destroy", "les_gc_last_error", "les_gc_labels", "les_gc_costs", "les_gc_expansion_moves",
-           "les_gc_expansion_moves_prebuilt", "les_gc_solve_prebuilt", "les_gc_build_graphs", "les_gc_smoothness_cost", "les_gc_data_cost"]
+           "les_gc_expansion_moves_prebuilt", "les_gc_solve_prebuilt", "les_gc_solve_residual", "les_gc_build_graphs", "les_gc_smoothness_cost", "les_gc_data_cost"]
 _lib = None
 
 
@@ -34,6 +34,7 @@ def load(path=None):
         "les_gc_expansion_moves_prebuilt": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
         "les_gc_build_graphs": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp]),
         "les_gc_solve_prebuilt": (ci, [ci, vp, vp, vp, ci, vp, vp]),
+        "les_gc_solve_residual": (ci, [ci, vp, vp, vp, vp, ci, ci, vp, vp]),
         "les_gc_smoothness_cost": (C.c_double, [vp, ci]),
         "les_gc_data_cost": (C.c_double, [vp, ci]),
     }
@@ -73,6 +74,19 @@ def solve_prebuilt(regions, payload, offsets, masks_out, nthreads=0, lib=None, f
     assert flows_out is None or (flows_out.dtype == np.float64 and flows_out.flags.c_contiguous and len(flows_out) >= len(regions))
     offsets = np.ascontiguousarray(offsets, np.int64)
     if L.les_gc_solve_prebuilt(len(regions), api._ptr(regions), api._ptr(payload), api._ptr(offsets), nthreads, api._ptr(masks_out),
+                               api._ptr(flows_out) if flows_out is not None else None):
+        raise RuntimeError(L.les_gc_last_error().decode())
+
+
+def solve_residual(regions, rc8, ex, offsets, masks_out, nthreads=0, solver=0, lib=None, flows_out=None):
+    """The cut of every cell continued from a residual graph (8 residual capacities + one excess float per node, host/ResidualCut.h):
+    what the tiled device max-flow hands over for its straggler cells.  Fills masks_out; flows_out = the flow routed here."""
+    L = load(lib)
+    regions = api._rects(regions)
+    assert rc8.dtype == np.float32 and rc8.flags.c_contiguous and ex.dtype == np.float32 and ex.flags.c_contiguous
+    assert masks_out.dtype == np.uint8 and masks_out.flags.c_contiguous
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    if L.les_gc_solve_residual(len(regions), api._ptr(regions), api._ptr(rc8), api._ptr(ex), api._ptr(offsets), nthreads, solver, api._ptr(masks_out),
                                api._ptr(flows_out) if flows_out is not None else None):
         raise RuntimeError(L.les_gc_last_error().decode())
 

@@ -100,6 +100,22 @@ public:
         sign_[i] = src ? 2 : snk ? 0 : 1;
         dirty_[i] = snk ? 0 : 1;
     }
+    // A node of a RESIDUAL graph (after reset_for_load): all 8 residual capacities + the terminal residual, i.e. the continuation of a
+    // feasible (pre)flow another solver routed -- the tiled device max-flow hands its straggler cells over in this form
+    // (csrc/les_maxflow_tiled.h, ResidualCut.h).  Lazy mode as after prepush_rows: only the nodes that still have source excess are
+    // queued, the sink trees are not grown, classify() reads the segments off the residual graph.
+    void load_residual(int x, int y, const float* rc8, float tr)
+    {
+        lazy_ = true;
+        const size_t i = (size_t)id(x, y);
+        Node& n = nodes_[i];
+        for (int k = 0; k < 8; k++) n.rc[k] = rc8[k];
+        const bool src = tr > 0, snk = tr < 0;
+        n.tr = tr; n.next_active = NOT_QUEUED; n.ts = 0;
+        n.dist = (src || snk) ? 1 : 0; n.parent = (src || snk) ? P_TERMINAL : P_NONE; n.is_sink = snk ? 1 : 0;
+        sign_[i] = src ? 2 : snk ? 0 : 1;
+        dirty_[i] = snk ? 1 : 0;                 // lazy mode: the map of the nodes with sink capacity (kept by augment)
+    }
     // mask row for the caller: 255 = SOURCE segment (LES/FastGCStereo.h:557: the proposal is taken), 0 = SINK
     void segment_row(int y, uint8_t* out) const
     {

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "ExpansionMove.h"
+#include "ResidualCut.h"
 
 using namespace les_host;
 
@@ -210,6 +211,24 @@ int les_gc_solve_prebuilt(int n, const les_hip_rect* regions, const float* paylo
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fprintf(trace, "%zx %d %d %d %.6f\n", std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffff, n, n > 0 ? regions[0].w : 0, nthreads, dt);
         fflush(trace);
+    }
+    return 0;
+}
+
+int les_gc_solve_residual(int n, const les_hip_rect* regions, const float* rc8, const float* ex, const long long* offsets, int nthreads, int solver,
+                          unsigned char* masks, double* flows)
+{
+    if (n < 0 || (n > 0 && (!regions || !rc8 || !ex || !offsets || !masks))) return fail("les_gc_solve_residual: bad argument");
+    for (int i = 0; i < n; i++)
+        if (regions[i].w < 0 || regions[i].h < 0 || offsets[i] < 0) return fail("les_gc_solve_residual: negative region size or offset (call %d)", i);
+    nthreads = defaultThreads(nthreads, n);
+    tuneBandSpin(n, nthreads, [&](int i) { return Rect(0, 0, regions[i].w, regions[i].h); });
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int i = 0; i < n; i++) {
+        const int w = regions[i].w, h = regions[i].h;
+        if (w <= 0 || h <= 0) continue;
+        const double flow = finishResidualCut(rc8 + 8 * offsets[i], ex + offsets[i], w, h, masks + offsets[i], residualBands(w, h), solver);
+        if (flows) flows[i] = flow;
     }
     return 0;
 }

@@ -265,6 +265,75 @@ class PMRunner:
             sh.payload, sh.payload_host = self._gc_payload[: n * 5], self._gc_payload_host[: n * 5]
             sh.masks, sh.masks_host = self._gc_masks[:n], self._gc_masks_host[:n]
 
+    def _dump_tiled(self, sh, m, iteration, li, ms, launches):
+        """Tooling (tools/tiled_cut_replay.py): LES_DUMP_TILED=dir LES_DUMP_EVERY=n [LES_DUMP_VIEW=v LES_DUMP_MAX=k] writes the graphs of every
+        n-th lock-step the tiled solver cut (regions, node offsets, the 5-float payload) with its wall time and launch count."""
+        import os
+        d = os.environ.get("LES_DUMP_TILED")
+        if not d or os.environ.get("LES_DUMP_VIEW", str(m)) != str(m):
+            return
+        self._dump_tiled_count = getattr(self, "_dump_tiled_count", 0) + 1
+        every = int(os.environ.get("LES_DUMP_EVERY", "50"))
+        if self._dump_tiled_count % every or getattr(self, "_dump_tiled_done", 0) >= int(os.environ.get("LES_DUMP_MAX", "6")):
+            return
+        self._dump_tiled_done = getattr(self, "_dump_tiled_done", 0) + 1
+        nn = int(sh.graph_off[-1] + int(sh.regions[-1]["w"]) * int(sh.regions[-1]["h"]))
+        np.savez_compressed(os.path.join(d, f"tiled_view{m}_it{iteration}_layer{li}_{self._dump_tiled_count}.npz"), regions=sh.regions, offsets=sh.graph_off,
+                            payload=sh.payload[: nn * 5].cpu().numpy(), ms=ms, launches=launches, cells=sh.n)
+
+    def _gc_set_without_round_trips(self, sh, li, iteration):
+        """All proposals of one disjoint set of the FINEST layer (cells that fit a workgroup's LDS: propose -> unary costs -> graph -> cut -> apply, nine
+        times) enqueued without a single host round trip; the cuts count the cells that hit their iteration limit in ONE device word, read once at the
+        end of the set (rounds 2-5 read a status word per lock-step: 720 synchronisations per view).  In the -- so far unobserved -- case that the word
+        is not zero the set is rolled back (labels, costs, generator states were saved in device memory: 30 MB, microseconds) and the caller repeats it
+        lock-step by lock-step with the host fall-back.  -> True: done."""
+        import os
+        import time
+        if self.device.type != "cuda" and not getattr(self, "speculative_sets_on_cpu", False):
+            return False
+        if self.device_cuts not in ("all", "fine") or sh.batch.max_cell_nodes > api.Batch.MAXFLOW_MAX_NODES:
+            return False
+        if os.environ.get("LES_DUMP_GRAPHS") or os.environ.get("LES_GC_PER_LOCKSTEP_CHECK"):
+            return False
+        t0 = time.perf_counter()
+        if getattr(self, "_gc_snap", None) is None:
+            self._gc_snap = (torch.empty_like(self.labels), torch.empty_like(self.cur))
+            self._gc_fail = torch.zeros(1, dtype=torch.int32, device=self.device)
+            nmax = max([1] + [s_.n for layer_ in self.shards for s_ in layer_])
+            if getattr(self, "_gc_status", None) is None:
+                self._gc_status = torch.zeros(nmax, dtype=torch.int32, device=self.device)
+        self._gc_buffers(sh)
+        self._gc_snap[0].copy_(self.labels)
+        self._gc_snap[1].copy_(self.cur)
+        rng0 = sh.rng.clone()
+        self._gc_fail.zero_()
+        st = self._gc_status[: sh.n]
+        p, m = self.gc.params, self.mode
+        locksteps = 0
+        for kind, K in self.table[li]:
+            for it in range(K):
+                mm = iteration + it
+                if kind == api.PROPOSE_RANDOM and (self.maxd - self.mind) * 0.5 ** (mm + 1) < 0.1:
+                    break
+                sh.batch.propose(kind, self.labels.data_ptr(), sh.rng.data_ptr(), sh.planes.data_ptr(), m=mm)
+                sh.batch.run(sh.planes.data_ptr(), self.prop.data_ptr(), mode=m, check=True, planes_on_device=True)
+                sh.batch.expansion_graph(sh.planes.data_ptr(), self.labels.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), sh.payload.data_ptr(), mode=m,
+                                         lambda_=p["lambda_"], th_smooth=p["th_smooth"], omega=p["omega"], epsilon=p["epsilon"])
+                sh.batch.solve_graphs(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr(), unsolved_total_dev=self._gc_fail.data_ptr())
+                sh.batch.apply_masks(sh.planes.data_ptr(), sh.masks.data_ptr(), self.cur.data_ptr(), self.prop.data_ptr(), self.labels.data_ptr())
+                locksteps += 1
+        failed = int(self._gc_fail.item())                 # the set's only synchronisation
+        self.gc_seconds["device"] += time.perf_counter() - t0
+        if failed:
+            self.labels.copy_(self._gc_snap[0])
+            self.cur.copy_(self._gc_snap[1])
+            sh.rng.copy_(rng0)
+            self.gc_seconds["sets_rolled_back"] = self.gc_seconds.get("sets_rolled_back", 0) + 1
+            return False
+        self.gc_seconds["cells_cut_on_device"] = self.gc_seconds.get("cells_cut_on_device", 0) + sh.n * locksteps
+        self.gc_seconds["sets_without_round_trips"] = self.gc_seconds.get("sets_without_round_trips", 0) + 1
+        return True
+
     def gc_iteration(self, iteration, check=False, nthreads=0):
         import os
         import time
@@ -277,6 +346,10 @@ class PMRunner:
             cur_host = torch.from_numpy(gc.costs[m])
         for li, layer in enumerate(self.shards):
             for sh in layer:
+                if sh.n and not host_path and self._gc_set_without_round_trips(sh, li, iteration):
+                    if self.world > 1:
+                        self._exchange(sh)
+                    continue
                 if sh.n:
                     for kind, K in self.table[li]:
                         for it in range(K):
@@ -322,8 +395,13 @@ class PMRunner:
                                         nl = sh.batch.solve_graphs_tiled(sh.payload.data_ptr(), sh.masks.data_ptr(), st.data_ptr(), wp, ws.numel() - (wp - ws.data_ptr()))
                                         self.gc_seconds["tiled_launches"] = self.gc_seconds.get("tiled_launches", 0) + nl
                                         self.gc_seconds["tiled_locksteps"] = self.gc_seconds.get("tiled_locksteps", 0) + 1
+                                        ts_ = sh.batch.tiled_stats                       # cells the host cores finished from their residual graphs (hand-over)
+                                        self.gc_seconds["tiled_handed_cells"] = self.gc_seconds.get("tiled_handed_cells", 0) + ts_["handed_cells"]
+                                        self.gc_seconds["tiled_handed_locksteps"] = self.gc_seconds.get("tiled_handed_locksteps", 0) + (1 if ts_["handed_cells"] else 0)
+                                        self.gc_seconds["tiled_handed_host_seconds"] = self.gc_seconds.get("tiled_handed_host_seconds", 0.0) + 1e-3 * ts_["host_ms"]
                                         self.gc_seconds[f"tiled_seconds_layer{li}"] = self.gc_seconds.get(f"tiled_seconds_layer{li}", 0.0) + time.perf_counter() - tl0
                                         self.tiled_lockstep_ms.setdefault(li, []).append((1e3 * (time.perf_counter() - tl0), nl))      # (wall of the solve call, launches enqueued)
+                                        self._dump_tiled(sh, m, iteration, li, 1e3 * (time.perf_counter() - tl0), nl)
                                     # (the only synchronisation of the lock-step; the tiled solver reports "cells that gave up" through a host-mapped word: no copy)
                                     on_dev = (sh.batch.tiled_unsolved == 0) if not small else not bool(st.any().item())
                                     if on_dev:

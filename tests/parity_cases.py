@@ -392,11 +392,11 @@ def _seeds(n, seed):
     return np.where(x == 0, np.uint64(0xFFFFFFFF), x).astype(np.uint64)
 
 
-def _label_map(H, W, D, seed, noise=0.0):
+def _label_map(H, W, D, seed, noise=0.0, block=(9, 11)):
     rng = np.random.default_rng(seed)
     lab = np.zeros((H, W), api.PLANE_DT)
     ys, xs = np.mgrid[0:H, 0:W]
-    by, bx = ys // 9, xs // 11
+    by, bx = ys // block[0], xs // block[1]
     na, nb = by.max() + 1, bx.max() + 1
     A = rng.uniform(-0.2, 0.2, (na, nb)).astype(np.float32)
     B = rng.uniform(-0.2, 0.2, (na, nb)).astype(np.float32)
@@ -482,6 +482,56 @@ def case_proposers(pr, unit=14, set_index=5, seed=11):
         for d in (d_lab, d_rng, d_pl):
             d.free()
         b.destroy()
+
+
+def case_ransac_schedule(pr, combos=((14, 0.0), (14, 0.3), (14, 3.0), (40, 1.0), (40, 30.0)), seed=23):
+    """The device RANSAC follows the reference's ADAPTIVE schedule (LES/Proposer.h:193 `while (no_sam < max_sam)`, :229-236) in chunks of candidates
+    (csrc/les_propose.h): label maps from exactly planar (the loop ends after its first sample) over noisy (a few dozen samples) to garbage (all 500)
+    must give the oracle's planes and -- the proof that the same number of samples was consumed -- the oracle's generator state in EVERY cell.
+    -> {(unit, noise): share of cells whose generator advanced past the first chunk of 16 candidates}"""
+    H, W, D = pr.H, pr.W, pr.D
+    mind, maxd = 0.0, float(D - 1)
+    out = {}
+    for unit, noise in combos:
+        layer = om.Layer(W, H, 20, unit)
+        cells = layer.sets[min(3, len(layer.sets) - 1)]
+        units = layer.unit[cells]
+        n = len(cells)
+        b = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
+        b.set_units(units)
+        labels = _label_map(H, W, D, seed + unit, noise=noise, block=(H, W) if noise == 0.0 else (9, 11))     # noise 0: ONE plane over the image
+        d_lab, d_rng, d_pl = api.DeviceBuffer(pr.e, labels.nbytes), api.DeviceBuffer(pr.e, 8 * n), api.DeviceBuffer(pr.e, 16 * n)
+        try:
+            seeds = _seeds(n, seed + 3 * unit)
+            d_lab.upload(labels)
+            d_rng.upload(seeds)
+            b.propose(api.PROPOSE_RANSAC, d_lab.ptr, d_rng.ptr, d_pl.ptr, m=0)
+            pr.e.synchronize()
+            got = d_pl.download((n,), api.PLANE_DT).view(np.float32).reshape(n, 4)
+            st = d_rng.download((n,), np.uint64)
+            ref, rst = _oracle_proposals(api.PROPOSE_RANSAC, labels, W, units, seeds, 0, mind, maxd)
+            ref = ref.view(np.float32).reshape(n, 4)
+            assert np.array_equal(st, rst), f"unit {unit}, noise {noise}: generator states differ in {int((st != rst).sum())} of {n} cells"
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+            # how far the loop went: the first chunk is 16 candidates = at least 48 draws of the generator (duplicates inside a triple only add
+            # draws); a state that is not among the first 48 + 8 successors of the seed belongs to a loop that went past the first chunk
+            far = sum(_draws_between(int(seeds[i]), int(st[i]), 16 * 3 + 8) is None for i in range(n))
+            out[(unit, noise)] = far / max(1, n)
+        finally:
+            for d in (d_lab, d_rng, d_pl):
+                d.free()
+            b.destroy()
+    return out
+
+
+def _draws_between(s0, s1, limit):
+    """number of generator steps from state s0 to state s1 if at most `limit`, else None (cv::RNG: state = (uint32)state * 4164903690 + (state >> 32))"""
+    s = s0
+    for k in range(limit + 1):
+        if s == s1:
+            return k
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+    return None
 
 
 def pm_iteration_oracle(pr, layers_units, proposer_table, seeds_per_layer, labels, cur, iteration, mode=0):
@@ -865,6 +915,51 @@ def case_quality_cones_gc(lib, device, pm_iters=1, gc_iters=1, units=(5, 15, 25)
     return hist, gap
 
 
+def case_gc_sets_without_round_trips(lib, device, monkeypatch, units=(12,)):
+    """pm.PMRunner._gc_set_without_round_trips (the finest layer: all proposals of a disjoint set enqueued without a host round trip, one failure word read
+    per set) against the lock-step-by-lock-step path: bit-identical labels and costs.  And the roll-back: with the device solver's iteration limit forced to
+    1 every cell fails, every set is rolled back and repeated on the slow path, whose host cuts must give the run with host cuts only."""
+    from localexpstereo_amd import gc as lgc
+    from localexpstereo_amd import pm
+    imL, vol, gt = cones_ad_volume()
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANSAC, 1), (api.PROPOSE_RANDOM, 2)]]
+
+    def run(mode):
+        for k in ("LES_GC_PER_LOCKSTEP_CHECK", "LES_HIP_MAXFLOW_MAX_ITER"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "per_lockstep":
+            monkeypatch.setenv("LES_GC_PER_LOCKSTEP_CHECK", "1")
+        if mode == "rollback":
+            monkeypatch.setenv("LES_HIP_MAXFLOW_MAX_ITER", "1")
+        e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0, lib=lib)
+        r = pm.PMRunner(e, units, table, seed=11, device=device)
+        r.speculative_sets_on_cpu = True
+        g = lgc.GraphCut(imL, None, lambda_=1.0)
+        r.init_labels()
+        r.iteration(0)
+        r.device_cuts = "none" if mode == "host" else "all"
+        r.begin_gc(g)
+        r.gc_iteration(0)
+        r.sync_gc_state()
+        out = (r.labels.cpu().numpy().copy(), r.cur.cpu().numpy().copy(), dict(r.gc_seconds), [sh.rng.cpu().numpy().copy() for sh in r.shards[0]])
+        r.close(); e.close(); g.close()
+        return out
+
+    lab_a, cur_a, sec_a, rng_a = run("per_lockstep")
+    lab_b, cur_b, sec_b, rng_b = run("speculative")
+    assert sec_a.get("sets_without_round_trips", 0) == 0 and sec_b.get("sets_without_round_trips", 0) > 0 and sec_b.get("sets_rolled_back", 0) == 0, (sec_a, sec_b)
+    assert lab_a.tobytes() == lab_b.tobytes() and cur_a.tobytes() == cur_b.tobytes()
+    assert all(np.array_equal(x, y) for x, y in zip(rng_a, rng_b))
+    lab_c, cur_c, sec_c, rng_c = run("rollback")
+    lab_d, cur_d, sec_d, rng_d = run("host")
+    assert sec_c.get("sets_rolled_back", 0) > 0 and sec_c.get("sets_without_round_trips", 0) == 0, sec_c
+    assert lab_c.tobytes() == lab_d.tobytes() and cur_c.tobytes() == cur_d.tobytes()
+    assert all(np.array_equal(x, y) for x, y in zip(rng_c, rng_d))
+    for k in ("LES_GC_PER_LOCKSTEP_CHECK", "LES_HIP_MAXFLOW_MAX_ITER"):
+        monkeypatch.delenv(k, raising=False)
+    return sec_b["sets_without_round_trips"], sec_c["sets_rolled_back"]
+
+
 def case_device_cuts_vs_host_cuts(lib, device, gc_iters=2, units=(14, 43)):
     """(1) Lock-step by lock-step, on the graphs of real graph-cut iterations: the cells cut on the device
     (les_hip_batch_solve_graphs) against the host solver on the same payload.  Both are minimum cuts of the same float graphs
@@ -975,6 +1070,8 @@ def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
     if tiled:                                                 # the region-parallel solver (any cell size) on the same awkward shapes
         ws = api.DeviceBuffer(pr.e, batch.tiled_workspace_bytes())
         batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
+        if stats is not None:
+            stats.update(batch.tiled_stats)
         ws.free()
     else:
         batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
@@ -1074,7 +1171,7 @@ def _random_cell_payloads(rng, shapes, dyadic):
     return pays
 
 
-def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False):
+def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=None):
     """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel."""
     H, W = pr.H, pr.W
     rects, x, y, rowh = [], 0, 0, 0
@@ -1101,6 +1198,8 @@ def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False):
         if poison:
             ws.fill(0xA5); dm.fill(0x5A); ds.fill(0x7F)
         batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
+        if stats is not None:
+            stats.update(batch.tiled_stats)
         ws.free()
     else:
         batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
@@ -1243,6 +1342,56 @@ def case_tiled_maxflow_hard_cells(pr):
         assert 0 < dev.mean() < 1
         switched += int(dev.sum())
     return switched
+
+
+def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
+    """The hand-over of the tiled solver (csrc/les_maxflow_tiled.h, host/ResidualCut.h): with the threshold lowered so that cells ARE still open
+    when the host looks (after the first 12 launches), the open cells' residual graphs go to the host cores, which finish them.  The masks must be
+    those of the solve without hand-over and of the host solver on the original payload (dyadic capacities: node for node; float capacities: a
+    minimum cut of the same value), the flow values must agree, for both host finishers (search trees / push-relabel).  Also the two committed
+    hard crops.  -> cells handed over"""
+    import os
+    from localexpstereo_amd import gc as lgc
+    rng = np.random.default_rng(seed)
+    if shapes is None:
+        shapes = [(150, 130), (65, 31), (129, 129), (200, 45), (31, 65), (64, 30)]
+    shapes = [(min(w, pr.W), min(h, pr.H)) for (w, h) in shapes]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_cells.npz"))
+    hard_shapes = [(z[k].shape[1], z[k].shape[0]) for k in z.files]
+    hard_pays = [np.ascontiguousarray(z[k].reshape(-1, 5), np.float32) for k in z.files]
+    handed = 0
+    for name, shp, pays, dyadic in (("dyadic", shapes, _random_cell_payloads(rng, shapes, True), True), ("float", shapes, _random_cell_payloads(rng, shapes, False), False),
+                                    ("hard", hard_shapes, hard_pays, False)):
+        monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER", "0")
+        off, status0, masks0, flows0 = _solve_cells_on_device(pr, shp, pays, tiled=True)
+        assert not status0.any()
+        for solver in (0, 1):
+            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER", "1")
+            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_AFTER", "1")
+            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_SOLVER", str(solver))
+            st = {}
+            off1, status1, masks1, flows1 = _solve_cells_on_device(pr, shp, pays, tiled=True, poison=True, stats=st)
+            assert not status1.any() and np.array_equal(off, off1)
+            assert st["handed_cells"] > 0 and st["handed_nodes"] > 0, f"{name}: nothing was handed over ({st})"
+            handed += st["handed_cells"]
+            for i, ((w, h), p) in enumerate(zip(shp, pays)):
+                a, b = masks0[off[i]: off[i] + w * h] != 0, masks1[off[i]: off[i] + w * h] != 0
+                tsum = max(1.0, float(np.abs(p[:, 0]).astype(np.float64).sum()))
+                if dyadic:
+                    assert np.array_equal(a, b), f"{name} cell {i} ({w}x{h}), solver {solver}: {int((a != b).sum())} nodes differ from the cut without hand-over"
+                    assert abs(flows1[i] - flows0[i]) <= 1e-9 * tsum, (flows1[i], flows0[i])
+                else:
+                    assert abs(flows1[i] - flows0[i]) <= 1e-6 * tsum + 1e-5 * abs(flows0[i]) + 1e-5, (name, i, flows1[i], flows0[i])
+                    if name == "hard":
+                        hm = np.zeros(w * h, np.uint8)
+                        lgc.solve_prebuilt(api._rects(np.array([(0, 0, w, h)], np.int32)), np.ascontiguousarray(p.reshape(-1)), np.array([0], np.int64), hm, nthreads=1)
+                        assert np.array_equal(b, hm != 0), f"hard cell {i}, solver {solver}: {int((b != (hm != 0)).sum())} nodes differ from the host cut"
+                    else:
+                        ca, cb = _cut_capacity(p, w, h, a), _cut_capacity(p, w, h, b)
+                        assert abs(ca - cb) <= 1e-6 * tsum, f"{name} cell {i}: the cut after hand-over is not a minimum cut ({cb} vs {ca})"
+        for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER"):
+            monkeypatch.delenv(k, raising=False)
+    return handed
 
 
 def case_refresh_volume(lib, H=90, W=130, D=10):

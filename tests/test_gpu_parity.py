@@ -351,6 +351,14 @@ def test_gpu_proposers(mid):
     pc.case_proposers(mid, unit=15, set_index=5)
 
 
+def test_gpu_ransac_adaptive_schedule(mid):
+    """The device RANSAC in chunks with the reference's early stop (LES/Proposer.h:193, :229-236): planar, noisy and garbage label maps, unit regions of
+    the three layers' sizes, against the oracle cell by cell (planes to float round-off, generator states exactly = the same samples consumed)."""
+    far = pc.case_ransac_schedule(mid, combos=((15, 0.0), (15, 0.3), (15, 3.0), (45, 1.0), (45, 30.0), (125, 0.5), (125, 40.0)))
+    print("share of cells whose RANSAC loop went past its first chunk of 16 candidates:", far)
+    assert far[(15, 0.0)] == 0.0 and far[(45, 30.0)] > 0.5 and far[(125, 40.0)] > 0.5, far
+
+
 def test_gpu_pm_iteration(oracle_mod):
     """PatchMatch lock-steps on the device vs the oracle (proposal generation, unary costs, WTA)."""
     pr = pc.synth_pair(None, 120, 160, 16)
@@ -437,6 +445,28 @@ def test_gpu_tiled_device_maxflow(mid):
     assert ties <= 2e-4 * nodes
     sw = pc.case_tiled_maxflow_hard_cells(mid)
     print(f"tiled device max-flow on tests/golden/hard_cells.npz: masks equal to the host solver's, {sw} nodes switch")
+
+
+def test_gpu_tiled_maxflow_handover(oracle_mod, monkeypatch):
+    """Straggler cells of the tiled solver finished by the host cores from their residual graphs (csrc/les_maxflow_tiled.h: collect / pack / unpack,
+    host/ResidualCut.h): cells up to 300 x 260 nodes (row bands on the host), dyadic and float capacities, the committed hard crops; both host finishers;
+    cuts and flow values of the solve without hand-over."""
+    pr = pc.synth_pair(None, 375, 450, 8)
+    try:
+        handed = pc.case_tiled_maxflow_handover(pr, monkeypatch, shapes=[(300, 260), (150, 130), (65, 31), (129, 129), (200, 45), (31, 65), (64, 30)])
+        print(f"hand-over: {handed} cells finished by the host cores")
+        assert handed > 0
+    finally:
+        pr.close()
+
+
+def test_gpu_gc_sets_without_round_trips(oracle_mod, monkeypatch):
+    """pm.PMRunner: the finest layer's disjoint sets enqueued without per-lock-step status reads == the per-lock-step path, bit for bit, and the roll-back of a
+    set whose cuts hit the iteration limit == host cuts."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    done, rolled = pc.case_gc_sets_without_round_trips(None, "cuda", monkeypatch, units=(14,))
+    assert done > 0 and rolled > 0
 
 
 def test_gpu_exchange_pack_unpack(mid):
@@ -762,6 +792,8 @@ def test_adirondack_shape_midv3_end_to_end(dual, scene):
     # objects 1.95-2.0 s (one view) / 6.3-6.4 s (two views + post-processing), three_surfaces 3.1-3.4 / 4.7-5.4 s over the boxes of the pool.  The bounds are 1.3 x the
     # largest of those.
     bound = {("objects", False): 2.6, ("objects", True): 8.3, ("three_surfaces", False): 4.4, ("three_surfaces", True): 7.0}[(scene, dual)]
+    if not os.environ.get("LES_TEST_STRICT_TIMING"):          # default: 3 x the measured numbers (a slower box of the pool must not fail a parity run); strict: 1.3 x
+        bound = min(10.0, bound * 3.0 / 1.3)
     assert wall < bound, f"Adirondack-shape run (scene {scene}, dual={dual}) took {wall:.1f} s"
 
 

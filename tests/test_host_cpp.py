@@ -87,7 +87,7 @@ def test_host_demo_full_size_on_gpu(demo):
     # round 5: 3.75-3.96 s on the MI355X boxes with every cut on the GPU (the coarse layers by the tiled solver; 11.5 s with their cuts on the host cores as in
     # rounds 2-4: `les_host_demo full 1436 992 256 5 2 0`).  The bound is 1.3 x the largest measured.
     assert "host cuts 0.000 s" in r.stdout, "a lock-step was cut on the host"
-    assert sec < 5.2, sec
+    assert sec < (5.2 if os.environ.get("LES_TEST_STRICT_TIMING") else 10.0), sec      # (default: north_star's 10 s; LES_TEST_STRICT_TIMING=1: 1.3 x the measured)
 
 
 @pytest.mark.gpu

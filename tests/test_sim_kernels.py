@@ -189,6 +189,13 @@ def test_sim_proposers(cones):
     pc.case_proposers(cones, unit=14, set_index=5)
 
 
+def test_sim_ransac_adaptive_schedule(cones):
+    """Chunked candidates with the reference's early stop: planar, noisy and garbage label maps against the oracle, cell by cell."""
+    far = pc.case_ransac_schedule(cones, combos=((14, 0.0), (14, 0.3), (14, 3.0), (30, 20.0)))
+    assert far[(14, 0.0)] == 0.0, far            # exactly planar regions: the loop ends with its first sample
+    assert far[(30, 20.0)] > 0.5, far            # garbage: (nearly) every cell goes through all chunks
+
+
 def test_sim_pm_iteration(sim_lib, oracle_mod):
     pr = pc.synth_pair(sim_lib, 48, 64, 10)
     try:
@@ -238,6 +245,15 @@ def test_sim_tiled_device_maxflow(sim_lib, oracle_mod):
         pr.close()
 
 
+def test_sim_tiled_maxflow_handover(sim_lib, oracle_mod, monkeypatch):
+    """Straggler cells of the tiled device max-flow finished by the host cores from their residual graphs: same cuts, same flow values."""
+    pr = pc.synth_pair(sim_lib, 140, 210, 4)
+    try:
+        assert pc.case_tiled_maxflow_handover(pr, monkeypatch, shapes=[(100, 70), (65, 31), (129, 129), (31, 65)]) > 0
+    finally:
+        pr.close()
+
+
 def test_sim_device_maxflow_against_independent_checkers(cones):
     """The same kernel source against networkx and brute force (no product code as the checker); the full-size version runs on the GPU."""
     cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24)
@@ -269,6 +285,15 @@ def test_sim_graph_cut_iteration_with_device_cuts(sim_lib, oracle_mod, monkeypat
     hist, gap = pc.case_quality_cones_gc(sim_lib, "cpu", units=(12,), device_cuts=True, table=[[(pc.api.PROPOSE_EXPANSION, 1), (pc.api.PROPOSE_RANDOM, 1)]],
                                          check_quality=False)      # (two proposals per cell: the energy must go down, convergence is not expected)
     print("cones crop PM+GC with device cuts (bad1.0, data, smooth):", hist)
+
+
+def test_sim_gc_sets_without_round_trips(sim_lib, oracle_mod, monkeypatch):
+    """The finest layer's disjoint sets enqueued without per-lock-step status reads == the per-lock-step path, bit for bit; the roll-back path too."""
+    monkeypatch.setenv("LES_HIP_KERNEL", "strip")
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    done, rolled = pc.case_gc_sets_without_round_trips(sim_lib, "cpu", monkeypatch)
+    assert done > 0 and rolled > 0
 
 
 def test_sim_ingest_files(sim_lib, oracle_mod, tmp_path):

@@ -144,6 +144,8 @@ static inline unsigned atomicMax(unsigned* p, unsigned v)
     return old;
 }
 
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
 static inline void __syncthreads() { hipsim::sync_block(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

@@ -66,7 +66,7 @@ def main():
             hms.append(1e3 * (time.perf_counter() - t0))
         diff = int((dev != (host != 0)).sum())
         print(f"{os.path.basename(f)}: {n} cells, {nn} nodes, status {int(st.any())}, launches <= {launches}, device {min(ms):.2f} ms, host({args.threads} threads) {min(hms[1:]):.2f} ms "
-              f"(recorded {1e3 * float(z['seconds']):.1f}), {int(dev.sum())} nodes switch, {diff} differ from the host cut", flush=True)
+              f"(recorded {(1e3 * float(z['seconds'])) if 'seconds' in z else float(z['ms']):.1f}), {int(dev.sum())} nodes switch, {diff} differ from the host cut; hand-over: {batch.tiled_stats['handed_cells']} cells / {batch.tiled_stats['handed_nodes']} nodes, host {batch.tiled_stats['host_ms']:.2f} ms", flush=True)
         for b_ in (dp, dm, ds, ws):
             b_.free()
         batch.destroy()
