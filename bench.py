@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
+import math
 import json
 import os
 import sys
@@ -46,7 +47,8 @@ HBM_ACHIEVABLE_GUIDE_GBS = 6290.0  # float4-copy ceiling quoted by the guide (79
 
 
 def kernel_source_hash():
-    """sha1 over the kernel sources: profiles/traffic.json is only quoted when it was collected for this very code."""
+    """sha1 over the sources that determine the march kernel and its launches (the kernel headers + les_hip.hip: context, job tables, launch; the other parts of
+    the C ABI -- les_hip_*.inc: batches' proposers, cuts, exchange -- do not touch it): profiles/traffic.json is only quoted when it was collected for this very code."""
     h = hashlib.sha1()
     for f in ("les_march.h", "les_kernels.h", "les_hip.hip", "les_simt.h"):
         h.update(open(os.path.join(ROOT, "localexpstereo_amd", "csrc", f), "rb").read())
@@ -240,6 +242,25 @@ def main():
         except Exception as ex:
             traffic, traffic_source = None, f"profiles/traffic.json unreadable: {ex!r}"
 
+    # What actually bounds the kernel: it is frozen at this formulation, and a reader of the line alone should see why `frac` ends where
+    # it does.  From the committed counters: VALU wave-instructions per launch x 64 lanes / evaluations = lane-operations per evaluation; the issue floor
+    # is those instructions at the measured issue costs with every wait hidden; the kernel runs at kernel_ms / floor of it.
+    bound_actual = None
+    if co_bounds and co_bounds.get("valu_insts_per_launch") and args.workload in ("h1", "h2"):
+        lane_ops = co_bounds["valu_insts_per_launch"] * 64.0 / evals_rank
+        floor_ms = co_bounds.get("valu_issue_floor_ms")
+        bound_actual = {
+            "bound_actual": "valu issue",
+            "lane_ops_per_eval": round(lane_ops, 1),
+            "valu_issue_floor_ms": floor_ms,
+            "frac_of_issue_floor": round(floor_ms / kern_ms, 4) if floor_ms else None,
+            "hbm_frac_at_issue_floor": round(alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if floor_ms else None,
+            "note": ("the HBM roofline is the wrong ceiling for this formulation: at %.0f VALU lane-operations per evaluation (exact integer box sums: 8 box filters = "
+                     "4 vertical running sums + 4 prefix-sum passes, the 3x3 algebra, fixed-point conversions) the 1024 SIMDs need valu_issue_floor_ms with every "
+                     "wait hidden, i.e. `frac` could reach hbm_frac_at_issue_floor at most; >= 0.50 needs <= 60 lane-operations per evaluation (LES/GuidedFilter.h:142-247 "
+                     "has 8 box filters + 25 multiply-adds per pixel: no such formulation is known to us; the i8-MFMA box sums measured slower, profiles/round3_mfma_box.log)" % lane_ops),
+        }
+
     result = {
         "metric": "Mcost-evals/s (pixels x hypotheses / s), guided-filter cost aggregation, 1500x1000x256 vol",
         "value": round(value, 2),
@@ -276,6 +297,11 @@ def main():
             # costs of the two instruction classes, with every wait hidden), the share of instructions outside the dual-issue class, how busy
             # the LDS pipe is, and the occupancy the 155 KB of LDS per workgroup leave
             "co_bounds": co_bounds,
+            "bound_actual": bound_actual["bound_actual"] if bound_actual else None,
+            "lane_ops_per_eval": bound_actual["lane_ops_per_eval"] if bound_actual else None,
+            "frac_of_issue_floor": bound_actual["frac_of_issue_floor"] if bound_actual else None,
+            "hbm_frac_at_issue_floor": bound_actual["hbm_frac_at_issue_floor"] if bound_actual else None,
+            "bound_note": bound_actual["note"] if bound_actual else None,
             "kernel": kernel_name,
             "kernel_ms": round(kern_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -302,6 +328,16 @@ def main():
                 "kernel": "march" if bt.kernel_kind(0) == 1 else "strip",
                 "workgroups_first_launch": bt.num_jobs,
             }
+            if name == "h3":
+                # How much of what a finest-layer launch pays for is used: a cell's filter tile is 85 of the 128 lanes of its
+                # job slot, 85 rows are 12.1 of the 16 ticks of 7 rows the march takes (3 of them pipeline fill), and the set's workgroups (two cells
+                # each) are one round on fewer than the 256 CUs.  The product bounds any re-packing of these dependent launches.
+                u0 = int(W * 0.01)
+                fw = 3 * u0 + 40
+                wgs = bt.num_jobs
+                result["h3"]["useful_lane_row_share"] = round((fw / 128.0) * ((fw / 7.0) / (math.ceil(fw / 7.0) + 3)) * min(1.0, wgs / 256.0), 3)
+                result["h3"]["useful_lane_row_share_note"] = (f"finest layer (81 % of H3's evaluations): filter tile {fw} of 128 lanes x {fw / 7.0:.1f} of {math.ceil(fw / 7.0) + 3} ticks x "
+                                                              f"{wgs} of 256 CUs per dependent launch; the optimiser's schedule leaves no second launch to fill the rest")
         step()                        # the H1 result buffer is compared with the oracle below
         torch.cuda.synchronize(dev)
         saved = out[: min(D, 256)].clone() if args.cpu_planes != 0 else None

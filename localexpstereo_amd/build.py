@@ -35,7 +35,7 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("les_hip.hip", "les_kernels.h", "les_march.h", "les_march_lab.h", "les_propose.h", "les_post.h", "les_pairwise.h", "les_maxflow.h", "les_maxflow_tiled.h", "les_simt.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]      # les_hip.hip (one translation unit) + its parts + the kernel headers
     srcs.append(os.path.join(ROOT, "include", "localexp_hip.h"))
     srcs += [os.path.join(HOST, f) for f in ("ResidualCut.h", "GridMaxFlow.h", "GridPushRelabel.h", "BandPool.h")]      # the host cores' finisher of the tiled max-flow
     if not force and _newer(HIP_SO, srcs):
@@ -56,7 +56,8 @@ def build_hip_plain(force=False):
     plain C++ (the DPP scan, the tied-destination statistics loads with hand-kept vmcnt, the SDWA / cvt / med3 / mad64 primitives).  Test
     infrastructure: the GPU tests run the product and this build on the same inputs and require bit-identical outputs (the CPU simulator
     cannot see the assembly).  Never loaded by the package."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "localexp_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))] + [os.path.join(ROOT, "include", "localexp_hip.h")]
+    srcs += [os.path.join(HOST, f) for f in ("ResidualCut.h", "GridMaxFlow.h", "GridPushRelabel.h", "BandPool.h")]
     if not force and _newer(PLAIN_SO, srcs):
         return PLAIN_SO
     cmd = [_hipcc()] + HIPCC_FLAGS + PLAIN_FLAGS + [os.path.join(CSRC, "les_hip.hip"), "-o", PLAIN_SO] + HIPCC_LIBS

@@ -1428,6 +1428,25 @@ def case_refresh_volume(lib, H=90, W=130, D=10):
     b_ref = run(fresh)
     assert np.array_equal(b_dev.view(np.uint32), b_ref.view(np.uint32)), f"{int((b_dev.view(np.uint32) != b_ref.view(np.uint32)).sum())} values differ after the refresh"
     assert not np.array_equal(a_dev, b_dev)
+    # A context created on a PLACEHOLDER volume (NaN: the march kernel's preconditions fail, the strip kernel serves it) must reach the march kernel once the
+    # caller has filled the volume and refreshed -- the guide's tables are built at creation whatever the volume holds (round 5 left such a context on
+    # the 2.2 x slower strip kernel for good) -- and a refresh onto an unusable volume must fall back again and release the tiled copy.
+    dv2 = api.DeviceBuffer(helper, D * H * W * 4)
+    dv2.upload(np.full((D, H, W), np.nan, np.float32))
+    e2 = api.HipCostVolumeEnergy(imL, None, dv2.ptr, None, windR=20, eps=1e-4, th_col=0.5, volumes_on_device=True, shape=(D, H, W), lib=lib)
+    b0 = api.Batch(e2, full, full, out_slabs=True)
+    assert b0.kernel_kind(0) == 0 and e2.tiled_volume_bytes(0) == 0
+    b0.destroy()
+    dv2.upload(volB)
+    e2.refresh_volume(0)
+    c_dev = run(e2)                                            # (asserts the march kernel)
+    assert np.array_equal(c_dev.view(np.uint32), b_ref.view(np.uint32))
+    dv2.upload(np.full((D, H, W), np.nan, np.float32))
+    e2.refresh_volume(0)
+    b0 = api.Batch(e2, full, full, out_slabs=True)
+    assert b0.kernel_kind(0) == 0 and e2.tiled_volume_bytes(0) == 0, "a refresh onto an unusable volume kept the march kernel or the stale tiled copy"
+    b0.destroy()
+    e2.close(); dv2.free()
     fresh.close(); e.close(); dv.free(); helper.close()
     return n
 

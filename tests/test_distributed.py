@@ -86,10 +86,11 @@ def test_four_ranks_equal_one_rank(tmp_path, oracle_mod):
     assert one["cur"].tobytes() == four["cur"].tobytes()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_two_views_view_split_equals_one_rank(tmp_path, oracle_mod, world):
     """BASELINE configs[3] (doDual on several GPUs): the ranks are split into one group per view (world 2: one rank per view; world 4:
-    two ranks per view, which also shard that view's cells), PatchMatch + graph-cut iterations, then one broadcast per view and the
+    two ranks per view, which also shard that view's cells; world 8 -- the shape of the 8-GPU node: four ranks per view, ranks without a cell
+    of a coarse set, empty slots, the broadcast between the groups), PatchMatch + graph-cut iterations, then one broadcast per view and the
     left-right post-processing on every rank -> labelling and raw labelling of a single rank bit for bit."""
     from localexpstereo_amd import build
     build.build_host_lib()

@@ -895,12 +895,12 @@ def test_config4_size_steep_planes_tiled_taps_equal_planar_taps(monkeypatch):
 def test_max_size_volume_32bit_offsets(oracle_mod):
     """BASELINE configs[4] shape: 3000 x 2000 x 512 (12.3 GB, 3.07e9 floats: element offsets above 2^31).
     Fronto-parallel planes in the lowest and the highest slices are checked against the oracle on host copies of
-    just those slices (same arithmetic: the lerp fraction is exact)."""
+    just those slices (same arithmetic: the lerp fraction is exact); then STEEP planes (tiled-copy taps) in slices 420-443 and 488-511."""
     import torch
     from localexpstereo_amd import api, synth
     H, W, D = 2000, 3000, 512
     free, _ = torch.cuda.mem_get_info()
-    if free < 16 * 2**30:
+    if free < 32 * 2**30:
         pytest.skip("not enough free HBM")
     gen = torch.Generator(device="cuda")
     gen.manual_seed(7)
@@ -920,6 +920,37 @@ def test_max_size_volume_32bit_offsets(oracle_mod):
         got = e.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl[None], n, 0), check=False)
         ref = o.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl_o[None], n, 0), check=False)
         pc.compare_maps(got, ref)
+    # STEEP planes against the oracle where the element offsets exceed 2^31 (round 6; LES/CostVolumeEnergy.h:70-98 is what the taps must equal): |a| = 0.15
+    # disparities per column puts the cell batches on the short gather FROM THE TILED COPY (|a| >= 0.125 in the two-job geometry; the copy is 12.3 GB, its
+    # descriptor starts at the job's own rows).  The cells of one column of the grid share their disparity range, so the oracle runs on host copies of the 24
+    # slices that column touches: slices 420 ... 443 (element offsets 2.5e9 ... 2.7e9), and 488 ... 511 with planes that leave the range at the top
+    # (the d >= MAXD branch, :79, next to the last interpolated pair).
+    assert e.tiled_volume_bytes(0) > 0, "the tiled copy of the volume was not built (needs twice the volume + 4 GB of free memory)"
+    ux = layer.unit["x"]
+    col = np.array([c for c in range(len(layer.unit)) if 1440 <= ux[c] < 1470], np.int64)[::5]      # one column of cells in the middle of the image, every fifth row
+    assert len(col) >= 8
+    fr, sh = layer.filter[col], layer.shared[col]
+    x_lo, x_hi = int(fr["x"].min()), int((fr["x"] + fr["w"]).max())
+    checked = 0
+    for lo, S, top in ((420, 24, False), (488, 24, True)):
+        sub = vol[lo:lo + S].cpu().numpy()
+        o = pc.om.Oracle(guide, None, sub, None, max_disp=float(S - 1))
+        for a in (0.15, -0.15):
+            b_ = 0.0004
+            span = abs(a) * (x_hi - x_lo) + b_ * H                          # disparity range of the plane over the column's filter rects
+            assert span < S - 3
+            d_min = (lo + S - 4.0 - 0.6 * span) if top else (lo + 1.5)       # top: the plane's upper part lies above MAXD = 511
+            c0 = d_min - min(a * x_lo, a * x_hi)
+            pl = np.array([a, b_, c0, 0], np.float32)
+            pl_o = pl.copy()
+            pl_o[2] -= lo
+            n = len(col)
+            got = e.unary_batch(fr, sh, np.repeat(pl[None], n, 0), check=False)
+            ref = o.unary_batch(fr, sh, np.repeat(pl_o[None], n, 0), check=False)
+            pc.compare_maps(got, ref)
+            checked += n
+        del sub, o
+    print(f"configs[4] size: {checked} cell evaluations of planes with |a| = 0.15 in slices 420-443 / 488-511 equal the oracle (tiled-copy taps, offsets > 2^31)")
     e.close()
     del vol
     torch.cuda.empty_cache()
@@ -982,8 +1013,9 @@ def test_bench_record_fields_on_one_gpu():
     assert cb["gpu_vs_oracle_max_abs_err_on_sample"] <= 2e-6
 
 
-def test_bench_multi_rank_code_path_on_one_gpu():
-    """`bench.py --gpus 4` launched exactly as the driver does (torch.distributed.run, one process per rank), with all ranks on
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_multi_rank_code_path_on_one_gpu(world):
+    """`bench.py --gpus 4` / `--gpus 8` (the shape the first 8-GPU node will see: four ranks per view group) launched exactly as the driver does (torch.distributed.run, one process per rank), with all ranks on
     cuda:0 and gloo for the rendezvous / max-over-ranks reductions (LES_BENCH_BACKEND / LES_BENCH_ONE_DEVICE: test hooks, the
     measured configuration is RCCL with one GPU per rank): rank 0 prints one JSON line for the whole job."""
     import json
@@ -992,19 +1024,19 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LES_BENCH_BACKEND="gloo", LES_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--height", "500", "--width", "700", "--ndisp", "8", "--cpu-planes", "0"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29533 + world),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--height", "500", "--width", "700", "--ndisp", "8", "--cpu-planes", "0"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 4 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["evals_per_step_per_gpu"] == 500 * 700 * 8
     # the leg WITH a collective (BASELINE configs[3]): view split x cell split -- four ranks = two per view group, so every disjoint set
     # ends with an all-gather inside its group, and the groups meet for the broadcast of the final label maps
     x = d["e2e_sharded"]
     assert "error" not in x, x
-    assert x["seconds"] > 0 and len(x["bytes_exchanged_per_rank"]) == 4 and len(x["host_cut_seconds_per_rank"]) == 4
+    assert x["seconds"] > 0 and len(x["bytes_exchanged_per_rank"]) == world and len(x["host_cut_seconds_per_rank"]) == world
     assert min(x["all_gathers_per_rank"]) > 0 and min(x["bytes_exchanged_per_rank"]) > 0
     assert x["bad_all_last"] is not None and x["bad_all_last"] < 50.0
