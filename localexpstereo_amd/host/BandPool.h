@@ -56,6 +56,14 @@ public:
         static thread_local BandPool pool;
         return pool;
     }
+    // A second team of the calling thread for work whose items use mine() themselves: run() is not re-entrant, and item 0 of a team runs on the
+    // calling thread -- a cell-per-thread team whose cells split their phases over row bands (ResidualCut.h from the tiled solver's hand-over)
+    // must therefore not be the pool the bands run on.
+    static BandPool& outer()
+    {
+        static thread_local BandPool pool;
+        return pool;
+    }
     template <class F>
     void run(int n, F&& f)
     {

@@ -82,8 +82,10 @@ inline double finishResidualCut(const float* rc8, const float* ex, int w, int h,
 inline int residualBands(int w, int h)
 {
     const long long nodes = (long long)w * h;
-    if (nodes < 40000) return 1;
-    return (int)std::max<long long>(2, std::min<long long>(8, nodes / 20000));
+    const char* e = getenv("LES_GC_RESIDUAL_BAND_NODES");            // tests: row bands on small cells as well (default: 20 000 nodes per band from 40 000 nodes on)
+    const long long per_band = e && atoll(e) > 0 ? atoll(e) : 20000;
+    if (nodes < 2 * per_band) return 1;
+    return (int)std::max<long long>(2, std::min<long long>(8, nodes / per_band));
 }
 
 }  // namespace les_host

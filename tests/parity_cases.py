@@ -1369,6 +1369,7 @@ def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER", "1")
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_AFTER", "1")
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_SOLVER", str(solver))
+            monkeypatch.setenv("LES_GC_RESIDUAL_BAND_NODES", "2000")      # row bands inside the handed-over cells (a team inside the cell-per-thread team) at test sizes too
             st = {}
             off1, status1, masks1, flows1 = _solve_cells_on_device(pr, shp, pays, tiled=True, poison=True, stats=st)
             assert not status1.any() and np.array_equal(off, off1)
@@ -1389,7 +1390,7 @@ def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
                     else:
                         ca, cb = _cut_capacity(p, w, h, a), _cut_capacity(p, w, h, b)
                         assert abs(ca - cb) <= 1e-6 * tsum, f"{name} cell {i}: the cut after hand-over is not a minimum cut ({cb} vs {ca})"
-        for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER"):
+        for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER", "LES_GC_RESIDUAL_BAND_NODES"):
             monkeypatch.delenv(k, raising=False)
     return handed
 
