@@ -278,35 +278,66 @@ __global__ void les_ransac_begin_kernel(const Rect4* __restrict__ units, const u
     ransac_draw(units[cell], sc, cell, MAX_SAM, 0, first < MAX_SAM ? first : MAX_SAM);
 }
 
-// Candidates j0 <= j < j1 of every cell that is still running.  One QUAD of lanes per (cell, candidate): lane s of the quad scans the
-// rows yy = s (mod 4) of the unit region.
-// Inlier counts are integer sums over the quad.  The normal equations of the refit are accumulated per lane in
-// increasing (row, column) order and combined as (p0 + p1) + (p2 + p3): a DEFINED order, shared with the host RansacProposer
-// (host/Proposer.h), so that the per-call drop-in loop and the device proposals are bit-identical.  (The test oracle sums in the
-// natural row order since round 4; the comparison with it is to float round-off.)
-__global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold, int j0, int j1)
+// Candidates j0 <= j < j1 of every cell that is still running.  grid = (cells, ceil((j1 - j0) / 16)), block = 1024: ONE WAVE per (cell,
+// candidate), sixteen candidates per workgroup (round 6; rounds 1-5: a quad of lanes per candidate -- a scan of a 129 x 129 unit region by four
+// lanes is a chain of 4 160 dependent iterations, 150 us whatever the rest of the GPU does).  Lane l of the wave visits the points with
+// yy = l / 16 (mod 4) and xx = l % 16 (mod 16) in increasing (row, column) order.
+// The 3-point planes of the workgroup's sixteen candidates are solved first, one lane each (the 3 x 3 eigen-solve is a long scalar chain: done
+// by every lane of sixteen waves it would occupy sixteen times the issue slots).  Inlier counts are integer sums over the wave.  The normal
+// equations of the refit are accumulated per lane in that order and combined by the butterfly l ^ 1, l ^ 2, ... l ^ 32: a DEFINED order,
+// shared with the host RansacProposer (host/Proposer.h: refitSums), so that the per-call drop-in loop and the device proposals are
+// bit-identical.  (The test oracle sums in the natural row order; the comparison with it is to float round-off.)
+constexpr int kRansacCandPerBlock = 16;
+__global__ void __launch_bounds__(64 * kRansacCandPerBlock)
+les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MAX_SAM, float threshold, int j0, int j1)
 {
+#if defined(LES_SIM)
+    static thread_local float sN[kRansacCandPerBlock][3];
+#else
+    __shared__ float sN[kRansacCandPerBlock][3];
+#endif
     const int cell = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const RansacCell cs = sc.cell[cell];
     const int jend = j1 < cs.max_sam ? j1 : cs.max_sam;                    // the loop never reaches a candidate at or beyond max_sam (it only shrinks)
-    if (cs.done || j0 + (int)blockIdx.y * ((int)blockDim.x / 4) >= jend) return;
-    const int j = j0 + (int)blockIdx.y * ((int)blockDim.x / 4) + (tid >> 2);    // candidate
-    const int sub = tid & 3;                                               // row phase of this lane
-    const bool live = j < jend;                                             // whole quads are live or not
+    const int jb = j0 + (int)blockIdx.y * kRansacCandPerBlock;
+    if (cs.done || jb >= jend) return;                                      // (uniform over the workgroup)
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     const float* disp = sc.disp + (size_t)cell * sc.stride;
-    const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + (live ? j : j0)) * 3;
 
-    // visits this lane's rows of the first `upto` points in index order: f(x, y, disparity, is_inlier_of_N)
+    if (tid < kRansacCandPerBlock && jb + tid < jend) {
+        const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + jb + tid) * 3;
+        double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            const int id = idxp[i];
+            const int yy = id / u.w, xx = id - yy * u.w;
+            const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
+            const double d = disp[id];
+            for (int a = 0; a < 3; a++) {
+                rhs[a] += c[a] * d;
+                for (int b = 0; b < 3; b++) M[a][b] += c[a] * c[b];
+            }
+        }
+        float N3[3];
+        solve_normal_3x3(M, rhs, N3);                                   // cv::solve(ranpts, div, N, DECOMP_SVD) :203
+        sN[tid][0] = N3[0]; sN[tid][1] = N3[1]; sN[tid][2] = N3[2];
+    }
+    __syncthreads();
+    const int j = jb + wave;                                            // candidate of this wave
+    if (j >= jend) return;                                              // (whole waves; no barrier follows)
+    const int rp = lane >> 4, cp = lane & 15;                           // row / column phase of this lane
+
+    // visits this lane's points among the first `upto` in index order: f(x, y, disparity, is_inlier_of_N)
     auto scan = [&](int upto, const float N[3], auto&& f) {
-        for (int yy = sub; yy < u.h; yy += 4) {
-            int i = yy * u.w;
-            if (i >= upto) break;
+        for (int yy = rp; yy < u.h; yy += 4) {
+            const int row = yy * u.w;
+            if (row >= upto) break;
             const float y = (float)yy + u.y;
             const double ty = (double)y * N[1];
-            for (int xx = 0; xx < u.w && i < upto; xx++, i++) {
+            for (int xx = cp; xx < u.w; xx += 16) {
+                const int i = row + xx;
+                if (i >= upto) break;
                 const float x = (float)xx + u.x;
                 const float d = disp[i];
                 const float dot = (float)(((double)x * N[0] + ty) + (double)1.0f * N[2]);   // pts * N (:204): x*N0 + y*N1 + 1*N2
@@ -315,26 +346,14 @@ __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacSc
         }
     };
 
-    double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
-    for (int i = 0; i < 3; i++) {
-        const int id = idxp[i];
-        const int yy = id / u.w, xx = id - yy * u.w;
-        const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
-        const double d = disp[id];
-        for (int a = 0; a < 3; a++) {
-            rhs[a] += c[a] * d;
-            for (int b = 0; b < 3; b++) M[a][b] += c[a] * c[b];
-        }
-    }
-    float N[3];
-    solve_normal_3x3(M, rhs, N);                                       // cv::solve(ranpts, div, N, DECOMP_SVD) :203 (all 4 lanes: same result)
+    const float N[3] = {sN[wave][0], sN[wave][1], sN[wave][2]};
     int cnt = 0;
     scan(len, N, [&](float, float, float, bool in) { cnt += in; });   // :204-206
-    const int no_i = quad_sum(cnt);
+    const int no_i = wave_sum_tree(cnt);
     int no = -1;
     float N2[3] = {0, 0, 0};
     // max_i starts at 3 and only grows (:180,:234): a candidate with no_i <= the cell's max_i at the start of this chunk can never
-    // enter the refit branch.  no_i is uniform over the quad, so the quad operations below are executed by whole quads.
+    // enter the refit branch.  no_i is uniform over the wave.
     if (no_i > cs.max_i) {
         // least-squares refit on the inliers among the FIRST no_i points (the reference's loop bound quirk, :216)
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                   // xx xy x yy y 1 | xd yd d
@@ -346,15 +365,15 @@ __global__ void les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacSc
             }
         });
         double t[9];
-        for (int k = 0; k < 9; k++) t[k] = quad_sum(acc[k]);
+        for (int k = 0; k < 9; k++) t[k] = wave_sum_tree(acc[k]);
         double A[3][3] = {{t[0], t[1], t[2]}, {t[1], t[3], t[4]}, {t[2], t[4], t[5]}};
         double r3[3] = {t[6], t[7], t[8]};
-        solve_normal_3x3(A, r3, N2);                                   // :224
+        solve_normal_3x3(A, r3, N2);                                   // :224 (every lane: the same result)
         int c2 = 0;
         scan(len, N2, [&](float, float, float, bool in) { c2 += in; });   // :225-227
-        no = quad_sum(c2);
+        no = wave_sum_tree(c2);
     }
-    if (live && sub == 0) {
+    if (lane == 0) {
         const size_t o = (size_t)cell * MAX_SAM + j;
         sc.noi[o] = no_i;
         sc.no[o] = no;

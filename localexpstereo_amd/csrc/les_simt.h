@@ -38,6 +38,14 @@ __device__ inline T quad_sum(T v)
     return a + b;
 }
 
+// sum over the 64 lanes of the wave as the butterfly (l ^ 1), (l ^ 2), ... (l ^ 32) evaluates it: a fixed balanced tree, every lane gets the same value
+template <typename T>
+__device__ inline T wave_sum_tree(T v)
+{
+    for (int m = 1; m < 64; m <<= 1) v = v + hipsim::wave_xor(v, m);
+    return v;
+}
+
 // ---- primitives of the march kernel (les_march.h)
 struct alignas(16) int4 { int x, y, z, w; };
 #define LES_MARCH_SCHED_FENCE() ((void)0)
@@ -156,6 +164,21 @@ __device__ __forceinline__ void quad_allgather(T v, T out[4])
     out[1] = quad_bcast<1>(v);
     out[2] = quad_bcast<2>(v);
     out[3] = quad_bcast<3>(v);
+}
+
+// sum over the 64 lanes of the wave as the butterfly (l ^ 1), (l ^ 2), ... (l ^ 32) evaluates it: a fixed balanced tree, every lane gets the same value
+// (IEEE addition is commutative, so both partners of an exchange compute the same sum)
+__device__ __forceinline__ int wave_sum_tree(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_tree(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
 }
 
 // ---- primitives of the march kernel (les_march.h)

@@ -187,22 +187,28 @@ private:
         for (int i = 0; i < upto; i++) cnt += inlier(i % rect.width, i / rect.width, i, N);
         return cnt;
     }
-    // normal equations of the refit over the inliers among the first `upto` points: xx xy x yy y 1 | xd yd d
+    // normal equations of the refit over the inliers among the first `upto` points: xx xy x yy y 1 | xd yd d.
+    // The DEFINED accumulation order shared with the device kernel (csrc/les_propose.h: les_ransac_eval_kernel, one wave of 64 lanes per
+    // candidate; round 6 -- rounds 1-5: four row phases): partial sum l = 16 (yy mod 4) + (xx mod 16) takes its points in increasing
+    // (row, column) order, and the 64 partial sums are combined by the balanced tree of the butterfly l ^ 1, l ^ 2, ... l ^ 32.
     void refitSums(int upto, const float N[3], double t[9]) const
     {
-        double acc[4][9] = {{0}};
+        double acc[64][9] = {{0}};
         for (int yy = 0; yy < rect.height; yy++) {
             int i = yy * rect.width;
             if (i >= upto) break;
-            double* a = acc[yy & 3];
             for (int xx = 0; xx < rect.width && i < upto; xx++, i++) {
                 if (!inlier(xx, yy, i, N)) continue;
+                double* a = acc[16 * (yy & 3) + (xx & 15)];
                 const double dx = (float)xx + rect.x, dy = (float)yy + rect.y, dd = disp[(size_t)i];
                 a[0] += dx * dx; a[1] += dx * dy; a[2] += dx; a[3] += dy * dy; a[4] += dy; a[5] += 1.0;
                 a[6] += dx * dd; a[7] += dy * dd; a[8] += dd;
             }
         }
-        for (int k = 0; k < 9; k++) t[k] = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
+        for (int m = 1; m < 64; m <<= 1)
+            for (int l = 0; l < 64; l += 2 * m)
+                for (int k = 0; k < 9; k++) acc[l][k] = acc[l][k] + acc[l + m][k];
+        for (int k = 0; k < 9; k++) t[k] = acc[0][k];
     }
     // pseudo-inverse solve of the 3x3 normal equations by cyclic Jacobi sweeps in double (csrc/les_propose.h: solve_normal_3x3)
     static void solveNormal3x3(double M[3][3], const double rhs[3], float x[3])

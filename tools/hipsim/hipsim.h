@@ -106,6 +106,23 @@ inline void quad_allgather(T v, T out[4])
     quad_sync();
 }
 
+// value of v in work-item (lane ^ mask) of this wave of 64 (every work-item of the wave must call it)
+template <typename T>
+inline T wave_xor(T v, int mask)
+{
+    static_assert(sizeof(T) <= 8, "wave exchange of <= 8 byte values");
+    Block* B = g_block;
+    const int tid = B->current;
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    B->exch[tid] = bits;
+    group_sync(6);
+    T r;
+    memcpy(&r, &B->exch[((tid & ~63) | ((tid & 63) ^ mask))], sizeof(T));
+    group_sync(6);
+    return r;
+}
+
 // exchange among the 16 work-items of a DPP row (lanes 16r .. 16r+15): every one of them must call it
 template <typename T>
 inline void group16_allgather(T v, T out[16])
