@@ -78,12 +78,15 @@ inline double finishResidualCut(const float* rc8, const float* ex, int w, int h,
     return total;
 }
 
-// row bands of a residual cut: the same function of the region size as bandsFor (ExpansionMove.h)
+// Row bands of a residual cut: ONE.  The parallel first phase of the host solvers pays on whole problems (ExpansionMove.h: bandsFor); on what the device
+// hands over -- a few hundred excess nodes, most of the flow routed -- the band phase finds nothing the whole-graph run does not find as fast, and its
+// threads compete with the other cells' (and the other view's) finishers: measured on 387 x 387 residuals, 7 bands / 1 band: 35 / 31, 26 / 15, 19 / 7.4,
+// 29 / 18 ms (tools/residual_probe.py).  LES_GC_RESIDUAL_BAND_NODES=n (tests, A/B): n nodes per band, at most 8 bands.
 inline int residualBands(int w, int h)
 {
-    const long long nodes = (long long)w * h;
-    const char* e = getenv("LES_GC_RESIDUAL_BAND_NODES");            // tests: row bands on small cells as well (default: 20 000 nodes per band from 40 000 nodes on)
-    const long long per_band = e && atoll(e) > 0 ? atoll(e) : 20000;
+    const char* e = getenv("LES_GC_RESIDUAL_BAND_NODES");
+    if (!e || atoll(e) <= 0) return 1;
+    const long long nodes = (long long)w * h, per_band = atoll(e);
     if (nodes < 2 * per_band) return 1;
     return (int)std::max<long long>(2, std::min<long long>(8, nodes / per_band));
 }
