@@ -234,7 +234,7 @@ struct les_hip_batch {
     // cell geometry for the proposers / WTA
     les::Rect4* d_units = nullptr;
     les::WtaJob* d_targets = nullptr;
-    les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0};   // RANSAC proposer scratch
+    les::RansacScratch rs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};   // RANSAC proposer scratch
     int wta_chunks = 1;                  // blocks per target rect in the WTA kernel
     // expansion-graph payload layout (les_hip_batch_expansion_graph): node offset of every target, total node count
     std::vector<long long> graph_off;

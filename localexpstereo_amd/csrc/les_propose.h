@@ -219,18 +219,15 @@ __device__ inline int ransac_sample_count(int ni, int ptNum, int pf, double conf
 //              draws the next chunk.
 // Result and generator state are exactly those of the sequential algorithm (and of the all-candidates schedule of rounds 1-5).
 struct RansacCell { int max_i, max_sam, no_sam, no_i_c; float result[3]; int done; };     // loop state of one cell (:180-185); 32 B
-// (candidate-major tables: the lane-per-cell kernels -- draw, walk -- read and write them with consecutive lanes on consecutive addresses;
-//  cell-major, every store of the draw loop touched 64 cache lines)
 struct RansacScratch {
     float* disp;       // [n][stride]            disparity snapshot
-    int* idx;          // [MAX_SAM][3][n]        sample triples
-    uint64_t* state;   // [MAX_SAM + 1][n]       generator state before sample j
-    int* noi;          // [MAX_SAM][n]           inliers of the 3-point plane
-    int* no;           // [MAX_SAM][n]           inliers of the refit (-1: not computed)
-    float* refit;      // [MAX_SAM][3][n]        refitted plane
+    int* idx;          // [n][MAX_SAM][3]        sample triples
+    uint64_t* state;   // [n][MAX_SAM + 1]       generator state before sample j
+    int* noi;          // [n][MAX_SAM]           inliers of the 3-point plane
+    int* no;           // [n][MAX_SAM]           inliers of the refit (-1: not computed)
+    float* refit;      // [n][MAX_SAM][3]        refitted plane
     int stride;
     RansacCell* cell;  // [n]
-    int n;             // cells of the batch
 };
 
 __global__ void les_ransac_snapshot_kernel(const Rect4* __restrict__ units, const float4* __restrict__ labels, int W, RansacScratch sc)
@@ -246,25 +243,39 @@ __global__ void les_ransac_snapshot_kernel(const Rect4* __restrict__ units, cons
     }
 }
 
+// x mod d for 32-bit x and d >= 1 with the precomputed M = floor((2^64 - 1) / d) + 1 (Lemire, Kaser, Kurz 2019: exact for all 32-bit operands): two
+// multiplications instead of the ~35-instruction division sequence -- the draw loop below is ONE lane's dependent instruction stream
+__device__ __forceinline__ uint32_t fastmod_u32(uint32_t x, uint64_t M, uint32_t d)
+{
+    const uint64_t low = M * (uint64_t)x;
+#if defined(LES_SIM)
+    return (uint32_t)(((unsigned __int128)low * d) >> 64);
+#else
+    return (uint32_t)__umul64hi(low, (uint64_t)d);
+#endif
+}
+
 // samples j0 <= j < j1 of one cell, continuing the generator from the recorded state before sample j0
 __device__ inline void ransac_draw(const Rect4& u, RansacScratch& sc, int cell, int MAX_SAM, int j0, int j1)
 {
     const int len = u.w * u.h;
-    const size_t n = (size_t)sc.n;
-    Rng r{sc.state[(size_t)j0 * n + cell]};
+    int* idxp = sc.idx + (size_t)cell * MAX_SAM * 3;
+    uint64_t* st = sc.state + (size_t)cell * (MAX_SAM + 1);
+    Rng r{st[j0]};
+    const uint64_t M = len > 0 ? ~0ull / (uint32_t)len + 1 : 0;          // uniform(0, len) = next() % len (cv::RNG), as fastmod_u32
     for (int j = j0; j < j1; j++) {
         // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
         int idx[3];
         for (int i = 0; i < 3; i++) {
             bool again;
             do {
-                idx[i] = len > 0 ? r.uniform_int(0, len) : 0;
+                idx[i] = len > 0 ? (int)fastmod_u32(r.next(), M, (uint32_t)len) : 0;
                 again = false;
                 for (int q = 0; q < i; q++) if (idx[q] == idx[i] && len > i) again = true;
             } while (again);
         }
-        sc.idx[((size_t)j * 3 + 0) * n + cell] = idx[0]; sc.idx[((size_t)j * 3 + 1) * n + cell] = idx[1]; sc.idx[((size_t)j * 3 + 2) * n + cell] = idx[2];
-        sc.state[(size_t)(j + 1) * n + cell] = r.state;
+        idxp[j * 3 + 0] = idx[0]; idxp[j * 3 + 1] = idx[1]; idxp[j * 3 + 2] = idx[2];
+        st[j + 1] = r.state;
     }
 }
 
@@ -276,7 +287,7 @@ __global__ void les_ransac_begin_kernel(const Rect4* __restrict__ units, const u
     c.max_i = 3; c.max_sam = MAX_SAM; c.no_sam = 0; c.no_i_c = 0;      // :180-185
     c.result[0] = c.result[1] = c.result[2] = 0.0f; c.done = 0;
     sc.cell[cell] = c;
-    sc.state[cell] = rng[cell];
+    sc.state[(size_t)cell * (MAX_SAM + 1)] = rng[cell];
     ransac_draw(units[cell], sc, cell, MAX_SAM, 0, first < MAX_SAM ? first : MAX_SAM);
 }
 
@@ -309,9 +320,10 @@ les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MA
     const float* disp = sc.disp + (size_t)cell * sc.stride;
 
     if (tid < kRansacCandPerBlock && jb + tid < jend) {
+        const int* idxp = sc.idx + ((size_t)cell * MAX_SAM + jb + tid) * 3;
         double M[3][3] = {{0}}, rhs[3] = {0, 0, 0};
         for (int i = 0; i < 3; i++) {
-            const int id = sc.idx[((size_t)(jb + tid) * 3 + i) * sc.n + cell];
+            const int id = idxp[i];
             const int yy = id / u.w, xx = id - yy * u.w;
             const double c[3] = {(double)((float)xx + u.x), (double)((float)yy + u.y), 1.0};
             const double d = disp[id];
@@ -375,10 +387,10 @@ les_ransac_eval_kernel(const Rect4* __restrict__ units, RansacScratch sc, int MA
         no = wave_sum_tree(c2);
     }
     if (lane == 0) {
-        const size_t n = (size_t)sc.n;
-        sc.noi[(size_t)j * n + cell] = no_i;
-        sc.no[(size_t)j * n + cell] = no;
-        sc.refit[((size_t)j * 3 + 0) * n + cell] = N2[0]; sc.refit[((size_t)j * 3 + 1) * n + cell] = N2[1]; sc.refit[((size_t)j * 3 + 2) * n + cell] = N2[2];
+        const size_t o = (size_t)cell * MAX_SAM + j;
+        sc.noi[o] = no_i;
+        sc.no[o] = no;
+        sc.refit[o * 3 + 0] = N2[0]; sc.refit[o * 3 + 1] = N2[1]; sc.refit[o * 3 + 2] = N2[2];
     }
 }
 
@@ -392,15 +404,15 @@ __global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t
     if (c.done) return;
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
-    const size_t nn = (size_t)sc.n;
+    const size_t base = (size_t)cell * MAX_SAM;
     while (c.no_sam < c.max_sam && c.no_sam < j1) {                    // :193
         const int j = c.no_sam;
         c.no_sam++;
-        const int no_i = sc.noi[(size_t)j * nn + cell];
+        const int no_i = sc.noi[base + j];
         if (c.max_i < no_i) {                                          // :208
-            const int no = sc.no[(size_t)j * nn + cell];
+            const int no = sc.no[base + j];
             if (no > c.no_i_c) {                                       // :229-236
-                c.result[0] = sc.refit[((size_t)j * 3 + 0) * nn + cell]; c.result[1] = sc.refit[((size_t)j * 3 + 1) * nn + cell]; c.result[2] = sc.refit[((size_t)j * 3 + 2) * nn + cell];
+                c.result[0] = sc.refit[(base + j) * 3]; c.result[1] = sc.refit[(base + j) * 3 + 1]; c.result[2] = sc.refit[(base + j) * 3 + 2];
                 c.no_i_c = no;
                 c.max_i = no_i;
                 const int cnt = ransac_sample_count(no, len, 3, conf);
@@ -411,7 +423,7 @@ __global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t
     if (c.no_sam >= c.max_sam) {
         c.done = 1;
         planes[cell] = make_float4(c.result[0], c.result[1], c.result[2], 0.0f);   // :239
-        rng[cell] = sc.state[(size_t)c.no_sam * nn + cell];                          // state after the last consumed sample
+        rng[cell] = sc.state[(size_t)cell * (MAX_SAM + 1) + c.no_sam];              // state after the last consumed sample
     } else {
         ransac_draw(u, sc, cell, MAX_SAM, j1, j2 < c.max_sam ? j2 : c.max_sam);
     }

@@ -1366,6 +1366,7 @@ def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
         for solver in (0, 1):
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER", "1")
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_AFTER", "1")
+            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_NODES", "1000000")
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE", "1")   # (the product waits for a group of launches in which no cell finished)
             monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_SOLVER", str(solver))
             monkeypatch.setenv("LES_GC_RESIDUAL_BAND_NODES", "2000")      # row bands inside the handed-over cells (a team inside the cell-per-thread team) at test sizes too
@@ -1389,7 +1390,7 @@ def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
                     else:
                         ca, cb = _cut_capacity(p, w, h, a), _cut_capacity(p, w, h, b)
                         assert abs(ca - cb) <= 1e-6 * tsum, f"{name} cell {i}: the cut after hand-over is not a minimum cut ({cb} vs {ca})"
-        for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER", "LES_GC_RESIDUAL_BAND_NODES", "LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE"):
+        for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER", "LES_GC_RESIDUAL_BAND_NODES", "LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE", "LES_HIP_MAXFLOW_HANDOVER_NODES"):
             monkeypatch.delenv(k, raising=False)
     return handed
 
