@@ -210,7 +210,8 @@ int les_hip_batch_solve_graphs_counted(les_hip_ctx* ctx, const les_hip_batch* ba
  * cut into tiles of <= 1920 nodes, one workgroup per tile, and the lock-step is a sequence of launches in which every cell moves
  * through exact relabelling / discharge phases on its own (region-parallel push-relabel, csrc/les_maxflow_tiled.h).  Same payload,
  * masks, status (0 = solved, non-zero = launch limit reached: cut that cell with the host solver) and flows as
- * les_hip_batch_solve_graphs; same cut (SINK side = the nodes that can still reach the sink).  Bit-reproducible from run to run.
+ * les_hip_batch_solve_graphs; same cut (SINK side = the nodes that can still reach the sink).  Bit-reproducible from run to run (heights relabelled from a snapshot, flow
+ * values summed as 64-bit integers; round 6).
  * d_workspace: caller-owned device scratch of at least les_hip_batch_tiled_workspace_bytes(batch) bytes, 256-byte aligned, not
  * shared between host threads that call concurrently (109 bytes per graph node + 64 per cell).  The call synchronises the calling
  * thread's stream (between groups of launches it looks at a host-mapped "cells done" word the kernel adds to: no copy); launches_out
@@ -219,11 +220,13 @@ int les_hip_batch_solve_graphs_counted(les_hip_ctx* ctx, const les_hip_batch* ba
 long long les_hip_batch_tiled_workspace_bytes(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs_tiled(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
                                      double* d_flows, void* d_workspace, long long workspace_bytes, int* launches_out, int* unsolved_out);
-/* Hand-over (round 6): a lock-step lasts as long as its slowest cell, and the launches are at their worst on the tail of a hard cell.  After
- * 28 launches, as soon as at most 8 cells of at most 400 000 nodes in total are still open, their residual graphs (8 residual capacities +
- * the excess per node) go to host-mapped memory and the host cores -- idle during device cuts -- finish each with a search from the
- * remaining excess nodes (host/ResidualCut.h; one thread per cell).  The residual graph of a feasible preflow has the minimum cuts of the
- * graph it came from, so masks, status and flows mean what they mean without it.  LES_HIP_MAXFLOW_HANDOVER=0 switches it off.
+/* Hand-over (round 6): a lock-step lasts as long as its slowest cell, and the launches are at their worst on the tail of a hard cell (a few
+ * hundred small excesses, one cell's tiles on a 256-CU chip).  After 28 launches, once at most 8 cells of at most 140 000 nodes in total are
+ * still open AND a whole group of 16 launches went by without a cell finishing, the open cells' residual graphs (8 residual capacities + the
+ * excess per node, 36 bytes) go to host-mapped memory and the host cores -- idle during device cuts -- finish each with FIFO push-relabel from
+ * the remaining excess nodes (host/ResidualCut.h; one thread per cell).  Larger open sets (the coarsest layer's 150 000-node cells) only after
+ * 220 launches, everything that is still open after 300.  The residual graph of a feasible preflow has the minimum cuts of the graph it came
+ * from, so masks, status and flows mean what they mean without it.  LES_HIP_MAXFLOW_HANDOVER=0 switches it off.
  * The _stats form reports what happened (the plain form = the _stats form without the report). */
 typedef struct les_hip_tiled_stats {
     int launches;            /* launches of les_maxflow_tiled_kernel enqueued */
