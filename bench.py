@@ -328,6 +328,15 @@ def main():
                 "kernel": "march" if bt.kernel_kind(0) == 1 else "strip",
                 "workgroups_first_launch": bt.num_jobs,
             }
+            # HBM bytes per step from the committed counter passes of THIS workload (tools/pmc_workload.sh + tools/traffic_merge.py), quoted only for these sources and shape
+            try:
+                tw = json.load(open(tf)).get(name) if os.path.exists(tf) else None
+                if tw and tw.get("kernel_source_sha1") == kernel_source_hash() and [H, W, D] == list(tw.get("shape", ())):
+                    result[name]["traffic"] = tw["bytes_per_step"]
+                    result[name]["traffic_over_algorithmic"] = round(tw["bytes_per_step"] / ab, 3)
+                    result[name]["traffic_source"] = tw.get("source")
+            except Exception:
+                pass
             if name == "h3":
                 # How much of what a finest-layer launch pays for is used: a cell's filter tile is 85 of the 128 lanes of its
                 # job slot, 85 rows are 12.1 of the 16 ticks of 7 rows the march takes (3 of them pipeline fill), and the set's workgroups (two cells

@@ -411,8 +411,20 @@ class PMRunner:
                                 else:
                                     self._sync()
                                     sh.payload_host.copy_(sh.payload)
+                                    # only the cells the device gave up on are cut again (their status word is non-zero); the masks of the others stay
+                                    failed = None
+                                    if sh.n and self.device_cuts in ("all", "fine") and getattr(self, "_gc_status", None) is not None and (self.device_cuts == "all" or small):
+                                        bad = np.nonzero(self._gc_status[: sh.n].cpu().numpy())[0]
+                                        if 0 < len(bad) < sh.n:
+                                            failed = bad
                                     t1 = time.perf_counter()
-                                    lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
+                                    if failed is None:
+                                        lgc.solve_prebuilt(sh.regions, sh.payload_host.numpy(), sh.graph_off, sh.masks_host.numpy(), nthreads=nthreads)
+                                    else:
+                                        sh.masks_host.copy_(sh.masks)
+                                        lgc.solve_prebuilt(np.ascontiguousarray(sh.regions[failed]), sh.payload_host.numpy(), np.ascontiguousarray(sh.graph_off[failed]),
+                                                           sh.masks_host.numpy(), nthreads=nthreads)
+                                        self.gc_seconds["cells_recut_on_host"] = self.gc_seconds.get("cells_recut_on_host", 0) + len(failed)
                                     t2 = time.perf_counter()
                                 dump = os.environ.get("LES_DUMP_GRAPHS")           # tooling: timing log of the lock-steps + the graphs of the slowest one of the coarsest layer
                                 if dump:

@@ -538,6 +538,40 @@ def test_gpu_device_cuts_fall_back_to_the_host(oracle_mod, monkeypatch):
     assert out[0].tobytes() == out[1].tobytes()
 
 
+def test_gpu_partial_host_recut(oracle_mod, monkeypatch):
+    """A lock-step in which only SOME cells hit the device solver's launch limit (tiled solver, limit 12, hand-over off): the driver copies the status words
+    back and cuts exactly those cells on the host, keeping the device masks of the others (advisor, round 5).  The fused energy must match the run in which
+    the device solves every cell (the two are minimum cuts of the same graphs; ties aside the labellings coincide)."""
+    from localexpstereo_amd import gc as lgc, pm
+    imL, vol, gt = pc.cones_ad_volume()
+    api = pc.api
+    table = [[(api.PROPOSE_EXPANSION, 1), (api.PROPOSE_RANDOM, 1)], [(api.PROPOSE_EXPANSION, 2), (api.PROPOSE_RANSAC, 1)]]
+    res = []
+    monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER", "0")
+    monkeypatch.setenv("LES_GC_PER_LOCKSTEP_CHECK", "1")              # (the finest layer's cuts are limited too: check them per lock-step)
+    for limit in ("12", None):
+        if limit is None:
+            monkeypatch.delenv("LES_HIP_MAXFLOW_MAX_ITER", raising=False)
+        else:
+            monkeypatch.setenv("LES_HIP_MAXFLOW_MAX_ITER", limit)
+        e = api.HipCostVolumeEnergy(imL, None, vol, None, windR=20, eps=1e-4, th_col=0.12, max_disp=63.0)
+        r = pm.PMRunner(e, (14, 43), table, seed=5, device="cuda")
+        g = lgc.GraphCut(imL, None, lambda_=1.0)
+        r.init_labels()
+        r.iteration(0)
+        r.device_cuts = "all"
+        r.begin_gc(g)
+        r.gc_iteration(0)
+        r.sync_gc_state()
+        res.append((g.data_cost(0) + g.smoothness_cost(0), dict(r.gc_seconds), r.labels.cpu().numpy().copy()))
+        r.close(); e.close(); g.close()
+    (e_lim, sec_lim, lab_lim), (e_dev, sec_dev, lab_dev) = res
+    assert sec_lim.get("cells_recut_on_host", 0) > 0, sec_lim
+    assert sec_dev.get("cells_recut_on_host", 0) == 0 and sec_dev.get("host_cuts", 0.0) == 0.0
+    assert abs(e_lim - e_dev) <= 2e-3 * abs(e_dev), (e_lim, e_dev)
+    assert (lab_lim != lab_dev).any(axis=-1).mean() < 0.02
+
+
 def test_gpu_stereo_driver_two_views(oracle_mod):
     rows = pc.case_stereo_driver(None, "cuda", units=(5, 15, 25), pmInit=1, maxIteration=1)
     print("FastGCStereo mirror, cones crop, two views:", rows)
@@ -895,7 +929,7 @@ def test_config4_size_steep_planes_tiled_taps_equal_planar_taps(monkeypatch):
 def test_max_size_volume_32bit_offsets(oracle_mod):
     """BASELINE configs[4] shape: 3000 x 2000 x 512 (12.3 GB, 3.07e9 floats: element offsets above 2^31).
     Fronto-parallel planes in the lowest and the highest slices are checked against the oracle on host copies of
-    just those slices (same arithmetic: the lerp fraction is exact); then STEEP planes (tiled-copy taps) in slices 420-443 and 488-511."""
+    just those slices (same arithmetic: the lerp fraction is exact); then STEEP planes (tiled-copy taps) in slices 416-443 and 484-511."""
     import torch
     from localexpstereo_amd import api, synth
     H, W, D = 2000, 3000, 512
@@ -920,10 +954,10 @@ def test_max_size_volume_32bit_offsets(oracle_mod):
         got = e.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl[None], n, 0), check=False)
         ref = o.unary_batch(layer.filter[cells], layer.shared[cells], np.repeat(pl_o[None], n, 0), check=False)
         pc.compare_maps(got, ref)
-    # STEEP planes against the oracle where the element offsets exceed 2^31 (round 6; LES/CostVolumeEnergy.h:70-98 is what the taps must equal): |a| = 0.15
+    # STEEP planes against the oracle where the element offsets exceed 2^31 (round 6; LES/CostVolumeEnergy.h:70-98 is what the taps must equal): |a| = 5/32
     # disparities per column puts the cell batches on the short gather FROM THE TILED COPY (|a| >= 0.125 in the two-job geometry; the copy is 12.3 GB, its
-    # descriptor starts at the job's own rows).  The cells of one column of the grid share their disparity range, so the oracle runs on host copies of the 24
-    # slices that column touches: slices 420 ... 443 (element offsets 2.5e9 ... 2.7e9), and 488 ... 511 with planes that leave the range at the top
+    # descriptor starts at the job's own rows).  The cells of one column of the grid share their disparity range, so the oracle runs on host copies of the 28
+    # slices that column touches: slices 416 ... 443 (element offsets 2.5e9 ... 2.7e9), and 484 ... 511 with planes that leave the range at the top
     # (the d >= MAXD branch, :79, next to the last interpolated pair).
     assert e.tiled_volume_bytes(0) > 0, "the tiled copy of the volume was not built (needs twice the volume + 4 GB of free memory)"
     ux = layer.unit["x"]
@@ -932,15 +966,17 @@ def test_max_size_volume_32bit_offsets(oracle_mod):
     fr, sh = layer.filter[col], layer.shared[col]
     x_lo, x_hi = int(fr["x"].min()), int((fr["x"] + fr["w"]).max())
     checked = 0
-    for lo, S, top in ((420, 24, False), (488, 24, True)):
+    for lo, S, top in ((416, 28, False), (484, 28, True)):
         sub = vol[lo:lo + S].cpu().numpy()
         o = pc.om.Oracle(guide, None, sub, None, max_disp=float(S - 1))
-        for a in (0.15, -0.15):
-            b_ = 0.0004
+        # (dyadic coefficients: a = +-5/32, b = 2^-11 and c a multiple of 2^-11 make d = a*x + (b*y + c) EXACT in float for the device's plane and for the
+        #  oracle's plane shifted by -lo alike, so both interpolate with the same fraction -- the comparison is then as tight as at small sizes)
+        for a in (0.15625, -0.15625):
+            b_ = 2.0 ** -11
             span = abs(a) * (x_hi - x_lo) + b_ * H                          # disparity range of the plane over the column's filter rects
             assert span < S - 3
             d_min = (lo + S - 4.0 - 0.6 * span) if top else (lo + 1.5)       # top: the plane's upper part lies above MAXD = 511
-            c0 = d_min - min(a * x_lo, a * x_hi)
+            c0 = np.round((d_min - min(a * x_lo, a * x_hi)) * 2048.0) / 2048.0
             pl = np.array([a, b_, c0, 0], np.float32)
             pl_o = pl.copy()
             pl_o[2] -= lo
@@ -950,7 +986,7 @@ def test_max_size_volume_32bit_offsets(oracle_mod):
             pc.compare_maps(got, ref)
             checked += n
         del sub, o
-    print(f"configs[4] size: {checked} cell evaluations of planes with |a| = 0.15 in slices 420-443 / 488-511 equal the oracle (tiled-copy taps, offsets > 2^31)")
+    print(f"configs[4] size: {checked} cell evaluations of planes with |a| = 5/32 in slices 416-443 / 484-511 equal the oracle (tiled-copy taps, offsets > 2^31)")
     e.close()
     del vol
     torch.cuda.empty_cache()

@@ -6,7 +6,7 @@
 # is what bench.py quotes as roofline.traffic.  Usage: bash tools/collect_profiles.sh [tag]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-round5}
+TAG=${1:-round6}
 O=gpurun_out/prof; mkdir -p $O
 B="python bench.py --steps 5 --warmup 1 --cpu-planes 0 --sub-steps 0 --e2e 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --steps 100 --warmup 5 --cpu-planes 0 --sub-steps 0 --e2e 0 > $O/stats.log 2>&1     # enough launches that the cold first ones do not weigh on the average
@@ -30,8 +30,8 @@ python tools/prof_summary.py $O/e2e --md > $O/${TAG}_e2e_kernel_stats.md
 # and the launches of the tiled solver on dumped lock-steps (per-launch durations in sequence: RELABEL0 / RELABEL / DISCHARGE phases)
 rocprofv3 --kernel-trace --stats -d $O/e2e_ts -- python tools/e2e_bench.py --scene three_surfaces > $O/e2e_ts.log 2>&1
 python tools/prof_summary.py $O/e2e_ts --md > $O/${TAG}_e2e_three_surfaces_kernel_stats.md
-if ls tools/_samples/ts1/*.npz > /dev/null 2>&1; then
-  rocprofv3 --kernel-trace --output-format csv -d $O/mf -- python tools/tiled_cut_replay.py tools/_samples/ts1/*.npz tools/_samples/obj/*.npz --reps 1 > $O/${TAG}_tiled_replay.log 2>&1
+if ls tools/_samples/r6/*.npz > /dev/null 2>&1; then
+  rocprofv3 --kernel-trace --output-format csv -d $O/mf -- python tools/tiled_cut_replay.py tools/_samples/r6/*.npz --reps 1 > $O/${TAG}_tiled_replay.log 2>&1
   python tools/trace_summary.py $O/mf tiled_kernel --seq 160 > $O/${TAG}_tiled_maxflow_trace.md
 fi
 rm -rf $O/h3 $O/e2e $O/e2e_ts $O/mf
@@ -93,4 +93,8 @@ with open(f"{O}/{tag}_pmc.md", "w") as f:
     f.write(f"\nHBM traffic per launch: {bytes_per_launch / 1e9:.3f} GB (fetch {fetch * 1024 * kf / 1e9:.3f} + write {write * 1024 * kw / 1e9:.3f}); algorithmic 3.144 GB\n")
 print(open(f"{O}/traffic.json").read())
 PY
+# the other two workloads' counters (VERDICT r5 #3b): H2 (256 slanted planes, tiled-copy taps) and H3 (the optimiser's cell batches) -> traffic.json entries
+bash tools/pmc_workload.sh h2 $TAG > /dev/null 2>&1
+bash tools/pmc_workload.sh h3 $TAG > /dev/null 2>&1
+python tools/traffic_merge.py $TAG $O
 head -12 $O/${TAG}_kernel_stats.md

@@ -4,7 +4,7 @@
 #   bash tools/pmc_workload.sh h2 [tag]      -> gpurun_out/prof/<tag>_<workload>_pmc.md     (run on the GPU box through gpurun)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-WL=${1:-h2}; TAG=${2:-round4}
+WL=${1:-h2}; TAG=${2:-round6}
 O=gpurun_out/prof; mkdir -p $O
 B="python bench.py --workload $WL --steps 3 --warmup 1 --cpu-planes 0 --sub-steps 0 --e2e 0"
 for c in FETCH_SIZE WRITE_SIZE; do
