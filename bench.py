@@ -47,10 +47,11 @@ HBM_ACHIEVABLE_GUIDE_GBS = 6290.0  # float4-copy ceiling quoted by the guide (79
 
 
 def kernel_source_hash():
-    """sha1 over the sources that determine the march kernel and its launches (the kernel headers + les_hip.hip: context, job tables, launch; the other parts of
-    the C ABI -- les_hip_*.inc: batches' proposers, cuts, exchange -- do not touch it): profiles/traffic.json is only quoted when it was collected for this very code."""
+    """sha1 over the sources that determine the unary-cost kernels and their launches (the kernel headers + les_hip_march_tables.inc: the instantiations +
+    les_hip_march.inc: job tables, launches, per-view set-up; the rest of the C ABI -- context, proposers, cuts, exchange -- does not touch them):
+    profiles/traffic.json is only quoted when it was collected for this very code."""
     h = hashlib.sha1()
-    for f in ("les_march.h", "les_kernels.h", "les_hip.hip", "les_simt.h"):
+    for f in ("les_march.h", "les_kernels.h", "les_simt.h", "les_hip_march_tables.inc", "les_hip_march.inc"):
         h.update(open(os.path.join(ROOT, "localexpstereo_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 

@@ -18,8 +18,9 @@ KNOWN = 384_000_000 * 4.0          # tools/calib_copy.py: bytes read = bytes wri
 
 def section(text, name):
     """-> (sum over the workload's march launches of the counter [KiB], number of those launches, calibration average [KiB])"""
-    m = re.search(r"## %s \(KiB\)(.*?)(?=\n## |\Z)" % name, text, re.S)
-    body = m.group(1)
+    start = text.index("## %s (KiB)" % name)
+    ends = [text.find(mark, start + 5) for mark in ("## FETCH_SIZE (KiB)", "## WRITE_SIZE (KiB)", "## SQ instruction counters", "## L2 (TCC) requests")]
+    body = text[start: min([e for e in ends if e > start] + [len(text)])]
     work, cal = body.split("calibration copy", 1)
     rows = lambda t: [(float(a), int(n)) for a, n in re.findall(r"\|\s*%s\s*\|\s*([0-9.eE+-]+)\s*\|\s*(\d+)\s*\|" % name, t)]
     w, c = rows(work), rows(cal)
