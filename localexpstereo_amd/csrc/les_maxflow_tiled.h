@@ -665,7 +665,6 @@ struct MtHandArgs {
     long long max_nodes_hist;        // ... or of at most this many when every open cell needed at least hist_min launches the last time it was cut
     int hist_min;                    //     (a cell that was hard is usually hard again: its long tail is not worth waiting for)
     int* hist;
-    long long cap_nodes;             // capacity of the staging arrays (never exceeded, whatever the policy says)
     MtHandCell* list;                // host-mapped, [max_cells]
     float* rc8;                      // host-mapped staging: [max_nodes][8]
     float* ex;                       // [max_nodes]
@@ -690,7 +689,7 @@ __global__ void les_maxflow_tiled_collect_kernel(MtHandArgs a)
             open++; nodes += (long long)a.cells[i].w * a.cells[i].h;
             if (a.hist && a.hist[i] < a.hist_min) all_hard = false;
         }
-    const bool fits = (nodes <= a.max_nodes || (all_hard && nodes <= a.max_nodes_hist)) && nodes <= a.cap_nodes;
+    const bool fits = nodes <= a.max_nodes || (all_hard && nodes <= a.max_nodes_hist);
     if (open == 0 || open > a.max_cells || !fits) { mt_store(a.host_flags + 2, 0); return; }
     int slot = 0;
     long long hoff = 0;

@@ -1169,7 +1169,7 @@ def _random_cell_payloads(rng, shapes, dyadic):
     return pays
 
 
-def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=None, repeat=1):
+def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=None):
     """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel."""
     H, W = pr.H, pr.W
     rects, x, y, rowh = [], 0, 0, 0
@@ -1195,11 +1195,9 @@ def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=No
         ws = api.DeviceBuffer(pr.e, batch.tiled_workspace_bytes())
         if poison:
             ws.fill(0xA5); dm.fill(0x5A); ds.fill(0x7F)
-        for rep in range(repeat):                  # (repeat > 1: the batch keeps the launches every cell needed -- the hand-over policy's history)
-            batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
-            if stats is not None:
-                stats.update(batch.tiled_stats)
-                stats.setdefault("handed_per_solve", []).append(batch.tiled_stats["handed_cells"])
+        batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
+        if stats is not None:
+            stats.update(batch.tiled_stats)
         ws.free()
     else:
         batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
@@ -1394,23 +1392,6 @@ def case_tiled_maxflow_handover(pr, monkeypatch, seed=13, shapes=None):
                         assert abs(ca - cb) <= 1e-6 * tsum, f"{name} cell {i}: the cut after hand-over is not a minimum cut ({cb} vs {ca})"
         for k in ("LES_HIP_MAXFLOW_HANDOVER", "LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_SOLVER", "LES_GC_RESIDUAL_BAND_NODES", "LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE", "LES_HIP_MAXFLOW_HANDOVER_NODES"):
             monkeypatch.delenv(k, raising=False)
-        if name == "dyadic":
-            # the per-cell history of the policy: with an early limit nothing fits (1 node) the first solve of a batch hands nothing over and records how many
-            # launches every cell needed; the second solve of the SAME batch finds the open cells "hard last time" (>= 1 launch) and hands them over at once
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_AFTER", "1")
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE", "1")
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_NODES", "1")
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_NODES_LATE", "1000000")
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_LATE_AFTER", "100000")
-            monkeypatch.setenv("LES_HIP_MAXFLOW_HANDOVER_HIST", "1")
-            st = {}
-            off2, status2, masks2, flows2 = _solve_cells_on_device(pr, shp, pays, tiled=True, stats=st, repeat=2)
-            assert st["handed_per_solve"][0] == 0 and st["handed_per_solve"][1] > 0, st
-            assert not status2.any() and np.array_equal(masks2, masks0)
-            handed += st["handed_per_solve"][1]
-            for k in ("LES_HIP_MAXFLOW_HANDOVER_AFTER", "LES_HIP_MAXFLOW_HANDOVER_NO_STALL_RULE", "LES_HIP_MAXFLOW_HANDOVER_NODES", "LES_HIP_MAXFLOW_HANDOVER_NODES_LATE",
-                      "LES_HIP_MAXFLOW_HANDOVER_LATE_AFTER", "LES_HIP_MAXFLOW_HANDOVER_HIST"):
-                monkeypatch.delenv(k, raising=False)
     return handed
 
 
