@@ -155,7 +155,6 @@ struct les_hip_batch {
     mutable les::MtTile* d_mt_tiles = nullptr;
     mutable int* d_mt_tiles_per_cell = nullptr;
     mutable int mt_ntiles = -1;          // -1: not built yet
-    mutable int* d_mt_hist = nullptr;    // launches every cell needed the last time this batch was cut (hand-over policy)
 };
 
 // Caller-owned scratch of the one-call operator (the reference's `Reusable`, LES/StereoEnergy.h:616-623): its own stream, a

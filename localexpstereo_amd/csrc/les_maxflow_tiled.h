@@ -123,7 +123,6 @@ struct MtArgs {
     int* status;
     double* flows;                   // optional
     int* host_flags;                 // host-mapped (pinned) words the host reads after a stream synchronisation, no copy: [0] cells finished, [1] of them: gave up
-    int* hist;                       // per cell of the BATCH, kept from lock-step to lock-step: launches the cell needed last time (1000: it was handed over)
 };
 
 // grid = tiles of the lock-step; block = kMtThreads; dynamic LDS = kMtLdsBytes
@@ -596,7 +595,6 @@ les_maxflow_tiled_kernel(MtArgs a)
             else next = kMtDone;
             if (next == kMtDone) {
                 a.status[t.cell] = 0;
-                if (a.hist) a.hist[t.cell] = launch + 1;
                 if (a.flows) a.flows[t.cell] = (double)mt_load_i64(&ctl->flow_fix) * (1.0 / (double)(1ll << kMtFlowShift));      // (every tile's share arrived before its count did)
                 mt_atomic_add(&hdr->cells_done, 1);
                 mt_host_add(a.host_flags, 1);
@@ -661,10 +659,7 @@ struct MtHandArgs {
     int ncells;
     const GraphCellMf* cells;
     int max_cells;                   // policy: hand over only when at most this many cells ...
-    long long max_nodes;             // ... of at most this many nodes in total are still open,
-    long long max_nodes_hist;        // ... or of at most this many when every open cell needed at least hist_min launches the last time it was cut
-    int hist_min;                    //     (a cell that was hard is usually hard again: its long tail is not worth waiting for)
-    int* hist;
+    long long max_nodes;             // ... of at most this many nodes in total are still open
     MtHandCell* list;                // host-mapped, [max_cells]
     float* rc8;                      // host-mapped staging: [max_nodes][8]
     float* ex;                       // [max_nodes]
@@ -683,21 +678,15 @@ __global__ void les_maxflow_tiled_collect_kernel(MtHandArgs a)
     MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl);
     int open = 0;
     long long nodes = 0;
-    bool all_hard = a.hist != nullptr;
     for (int i = 0; i < a.ncells; i++)
-        if (ctl[i].phase < kMtDone) {
-            open++; nodes += (long long)a.cells[i].w * a.cells[i].h;
-            if (a.hist && a.hist[i] < a.hist_min) all_hard = false;
-        }
-    const bool fits = nodes <= a.max_nodes || (all_hard && nodes <= a.max_nodes_hist);
-    if (open == 0 || open > a.max_cells || !fits) { mt_store(a.host_flags + 2, 0); return; }
+        if (ctl[i].phase < kMtDone) { open++; nodes += (long long)a.cells[i].w * a.cells[i].h; }
+    if (open == 0 || open > a.max_cells || nodes > a.max_nodes) { mt_store(a.host_flags + 2, 0); return; }
     int slot = 0;
     long long hoff = 0;
     for (int i = 0; i < a.ncells; i++) {
         if (ctl[i].phase >= kMtDone) continue;
         ctl[i].hand = slot; ctl[i].hoff = hoff;
         ctl[i].phase = kMtHandover;
-        if (a.hist) a.hist[i] = 1000;
         a.list[slot].cell = i; a.list[slot].pad = 0; a.list[slot].hoff = hoff;
         slot++;
         hoff += (long long)a.cells[i].w * a.cells[i].h;

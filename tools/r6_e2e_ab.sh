@@ -2,11 +2,9 @@
 # Round 6: same-box A/B of the tiled max-flow's hand-over on whole runs (two scenes, one and two views), then the kernel-trace stats of a one-view run.
 # Usage (GPU box): bash tools/r6_e2e_ab.sh <outdir>
 O=${1:-gpurun_out/r6_ab}; mkdir -p $O
-# ho1 = the product (hand-over with the per-cell history), hoH0 = hand-over without the history (LES_HIP_MAXFLOW_HANDOVER_HIST=0), ho0 = no hand-over (round 5)
-for sc in objects three_surfaces; do for ho in 1 H0 0; do
-  if [ $ho = H0 ]; then E="LES_HIP_MAXFLOW_HANDOVER=1 LES_HIP_MAXFLOW_HANDOVER_HIST=0"; else E="LES_HIP_MAXFLOW_HANDOVER=$ho"; fi
-  env $E timeout 150 python tools/e2e_bench.py --dual 1 --scene $sc > $O/e2e_${sc}_dual_ho$ho.json 2>/dev/null
-  env $E timeout 100 python tools/e2e_bench.py --scene $sc > $O/e2e_${sc}_single_ho$ho.json 2>/dev/null
+for sc in objects three_surfaces; do for ho in 1 0; do
+  LES_HIP_MAXFLOW_HANDOVER=$ho timeout 150 python tools/e2e_bench.py --dual 1 --scene $sc > $O/e2e_${sc}_dual_ho$ho.json 2>/dev/null
+  LES_HIP_MAXFLOW_HANDOVER=$ho timeout 100 python tools/e2e_bench.py --scene $sc > $O/e2e_${sc}_single_ho$ho.json 2>/dev/null
 done; done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_e2e -- python tools/e2e_bench.py > $O/prof_e2e.log 2>&1
