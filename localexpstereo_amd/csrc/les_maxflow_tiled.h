@@ -660,6 +660,7 @@ struct MtHandArgs {
     const GraphCellMf* cells;
     int max_cells;                   // policy: hand over only when at most this many cells ...
     long long max_nodes;             // ... of at most this many nodes in total are still open
+    long long cap_nodes;             // capacity of the staging arrays (never exceeded, whatever the policy says)
     MtHandCell* list;                // host-mapped, [max_cells]
     float* rc8;                      // host-mapped staging: [max_nodes][8]
     float* ex;                       // [max_nodes]
@@ -680,7 +681,7 @@ __global__ void les_maxflow_tiled_collect_kernel(MtHandArgs a)
     long long nodes = 0;
     for (int i = 0; i < a.ncells; i++)
         if (ctl[i].phase < kMtDone) { open++; nodes += (long long)a.cells[i].w * a.cells[i].h; }
-    if (open == 0 || open > a.max_cells || nodes > a.max_nodes) { mt_store(a.host_flags + 2, 0); return; }
+    if (open == 0 || open > a.max_cells || nodes > a.max_nodes || nodes > a.cap_nodes) { mt_store(a.host_flags + 2, 0); return; }
     int slot = 0;
     long long hoff = 0;
     for (int i = 0; i < a.ncells; i++) {
