@@ -73,10 +73,13 @@ namespace hipsim {
 
 struct Block {
     int nthreads = 0, current = 0, alive = 0;
-    std::vector<ucontext_t> ctx;
+    std::vector<ucontext_t> ctx;      // (architectures without the hand-written switch of hipsim.cpp)
+    std::vector<void*> sp;            // x86-64: saved stack pointer of every work-item ...
+    void* sched_sp = nullptr;         // ... and of the scheduler
     std::vector<char> done;
     ucontext_t sched;
-    std::vector<char> stacks;
+    char* stack_base = nullptr;       // work-item stacks (mmap, grown on demand, never zero-filled)
+    size_t stack_bytes = 0;
     unsigned bar_count = 0, bar_gen = 0;
     std::vector<unsigned> quad_count, quad_gen;
     std::vector<unsigned> g16_count, g16_gen;
