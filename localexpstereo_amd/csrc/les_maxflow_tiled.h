@@ -52,9 +52,10 @@ constexpr int kMtFlowShift = 22;                           // flow values are ac
 
 struct MtTile { int cell, x0, y0, tw, th, W, H, pad; long long off, pad2; };   // cell-local rectangle + the cell's size and node offset; 48 B
 struct MtCtl {                                                                // per cell; 64 B
-    int phase, arrived, changed, active;
-    int parity, sweeps, launches, rounds;
-    int ntiles, hand;                 // hand: the cell's slot in the hand-over list (kMtHandover)
+    int phase, launches;
+    long long votes;                  // this launch's arrivals: bits 0-20 tiles arrived, 21-41 of them "changed", 42-62 "active" (ONE relaxed atomic per tile)
+    int parity, sweeps, rounds, ntiles;
+    int hand, pad0;                   // hand: the cell's slot in the hand-over list (kMtHandover)
     long long hoff;                   // ... and its node offset in the hand-over staging arrays
     long long flow_fix;               // sink capacity at load time minus what is left of it, in units of 2^-kMtFlowShift
     int pad[2];
@@ -92,6 +93,7 @@ __device__ inline void mt_store(int* p, int v) { __atomic_store_n(p, v, __ATOMIC
 __device__ inline void mt_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 __device__ inline void mt_host_add(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 __device__ inline void mt_atomic_add_i64(long long* p, long long v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+__device__ inline long long mt_vote(long long* p, long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 __device__ inline long long mt_load_i64(const long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 #else
 // Keeps the LDS addresses derived from x inside the loop they are used in: hoisted out of the iteration loop (32 of them are loop
@@ -105,7 +107,24 @@ __device__ __forceinline__ void mt_store(int* p, int v) { __hip_atomic_store(p, 
 __device__ __forceinline__ void mt_fence() { __threadfence(); }
 __device__ __forceinline__ void mt_host_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }   // (fine-grained host memory)
 __device__ __forceinline__ void mt_atomic_add_i64(long long* p, long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the arrival of a tile: RELAXED -- nothing another tile wrote in this launch is read before the next launch (the kernel boundary orders it), and a
+// release here is a write-back of the XCD's whole L2 (measured with the clock stamps of tools/lab/mt_probe.py: 4.5 us median, 30 us worst, per tile and launch)
+__device__ __forceinline__ long long mt_vote(long long* p, long long v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ long long mt_load_i64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+// Lab build (-DLES_MT_PROBE, tools/lab/mt_probe.py): thread 0 of every tile stamps the 100-MHz clock at eight points of a launch into
+// g_mt_probe[launch of the cell][tile][16] -- where the time of a launch goes.  Empty in the product.
+#if defined(LES_MT_PROBE) && !defined(LES_SIM)
+__device__ unsigned long long* g_mt_probe = nullptr;
+__device__ int g_mt_probe_launches = 0;
+#define MT_STAMP0() const unsigned long long mt_t0 = __builtin_amdgcn_s_memrealtime()
+#define MT_STAMP(i) do { if (threadIdx.x == 0 && g_mt_probe && launch < g_mt_probe_launches) { unsigned long long* q_ = g_mt_probe + ((size_t)launch * gridDim.x + blockIdx.x) * 16; \
+                         if ((i) == 1) { q_[0] = mt_t0; q_[2] = q_[3] = q_[4] = q_[5] = q_[6] = q_[7] = 0; q_[8] = (unsigned long long)phase; q_[9] = gridDim.x; } \
+                         q_[(i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MT_STAMP0() ((void)0)
+#define MT_STAMP(i) ((void)0)
 #endif
 
 struct MtArgs {
@@ -136,6 +155,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     extern __shared__ __attribute__((aligned(16))) char s_dyn_mt[];
     char* base = s_dyn_mt;
 #endif
+    MT_STAMP0();
     const MtTile t = a.tiles[blockIdx.x];
     const MtLayout L = mt_layout(a.nodes, a.ncells);
     MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl) + t.cell;
@@ -146,6 +166,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     const bool first_round = ctl->rounds <= 1;
     const int Kit = first_round ? a.K : a.K2, Ssw = first_round ? a.S : a.S2;
     if (phase >= kMtDone) return;
+    MT_STAMP(1);
 
     int* hg = reinterpret_cast<int*>(base);                                 // heights / distances, halo-pitched: (th + 2) x (tw + 2)
     float* exs = reinterpret_cast<float*>(hg + kMtMaxHalo);                 // > 0: excess; < 0: remaining capacity to the sink
@@ -207,6 +228,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     if (tid < 16) sflag[tid] = 0;
     for (int i = tid; i < 3 * 72; i += kMtThreads) rowchg[i] = i < 72 ? 1 : 0;     // sweep 0 looks at every row
     __syncthreads();
+    MT_STAMP(2);
 
     // halo of the height array from the global heights (nodes outside the cell: BIG); own nodes are loaded by the phases
     auto load_halo = [&](bool from_global) {
@@ -335,6 +357,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             if (tid == 0 && red[0] != 0.0) mt_atomic_add_i64(&ctl->flow_fix, (long long)rint(red[0] * (double)(1ll << kMtFlowShift)));
         }
         __syncthreads();
+        MT_STAMP(3);
         relax(rm);
 #pragma unroll
         for (int j = 0; j < kMtNpt; j++) {
@@ -357,6 +380,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             hg[hi[j]] = d0[j];
         }
         __syncthreads();
+        MT_STAMP(3);
         relax(rm);
 #pragma unroll
         for (int j = 0; j < kMtNpt; j++) {
@@ -395,6 +419,7 @@ les_maxflow_tiled_kernel(MtArgs a)
         }
         if (mine) sflag[4] = 1;
         __syncthreads();
+        MT_STAMP(3);
         const bool busy = sflag[4] != 0;
         if (busy) {
 #pragma unroll
@@ -409,6 +434,7 @@ les_maxflow_tiled_kernel(MtArgs a)
                 for (int k = 0; k < 8; k++) sent[k * NP + v] = 0.0f;
             }
             __syncthreads();
+            MT_STAMP(4);
             // ---- K synchronous iterations: pushes | barrier | receive + relabel | barrier.  All LDS reads of a step are issued together and
             // unconditionally (a chain of conditional reads costs a round trip each); a wave none of whose lanes has work skips the step.
             for (int it = 0; it < Kit; it++) {
@@ -523,6 +549,7 @@ les_maxflow_tiled_kernel(MtArgs a)
                 if (!sflag[fl]) break;                                        // (own heights only from here on: the write-back below reads hg[hi[j]])
                 __syncthreads();
             }
+            MT_STAMP(5);
             // ---- write the tile back
 #pragma unroll
             for (int j = 0; j < kMtNpt; j++) {
@@ -580,14 +607,16 @@ les_maxflow_tiled_kernel(MtArgs a)
     if (tile_changed) sflag[3] = 1;
     if (tile_active) sflag[7] = 1;
     __syncthreads();
+    MT_STAMP(6);
     if (tid == 0) {
-        if (sflag[3]) mt_atomic_or(&ctl->changed, 1);
-        if (sflag[7]) mt_atomic_or(&ctl->active, 1);
-        mt_fence();
-        const int prev = mt_atomic_add(&ctl->arrived, 1);
-        if (prev == ctl->ntiles - 1) {
-            mt_fence();
-            const int changed = mt_load(&ctl->changed), active = mt_load(&ctl->active);
+        // (the flow value is read by the last tile of the FINAL launch: there, and only there, a tile's share must be visible before its arrival)
+        const bool ordered = a.flows != nullptr && phase == kMtFinal;
+        if (ordered) mt_fence();
+        const long long vote = 1ll + (sflag[3] ? 1ll << 21 : 0ll) + (sflag[7] ? 1ll << 42 : 0ll);
+        const long long all = mt_vote(&ctl->votes, vote) + vote;
+        if ((int)(all & 0x1fffff) == ctl->ntiles) {
+            if (ordered) mt_fence();
+            const int changed = (int)((all >> 21) & 0x1fffff), active = (int)((all >> 42) & 0x1fffff);
             int next = phase, par = parity, sweeps = ctl->sweeps, rounds = ctl->rounds;
             if (phase == kMtRelabel0) { next = ctl->ntiles > 1 ? kMtRelabel : (active ? kMtDischarge : kMtFinal); par ^= 1; sweeps = 0; rounds++; }
             else if (phase == kMtRelabel) next = changed ? kMtRelabel : (active ? kMtDischarge : kMtFinal);
@@ -606,13 +635,12 @@ les_maxflow_tiled_kernel(MtArgs a)
                 mt_host_add(a.host_flags, 1);
             }
             ctl->parity = par; ctl->sweeps = sweeps; ctl->rounds = rounds;
-            mt_store(&ctl->changed, 0);
-            mt_store(&ctl->active, 0);
-            mt_store(&ctl->arrived, 0);
-            mt_store(&ctl->launches, launch + 1);
-            mt_store(&ctl->phase, next);
+            ctl->votes = 0;
+            ctl->launches = launch + 1;
+            ctl->phase = next;
         }
     }
+    MT_STAMP(7);
 }
 
 // sets up the per-cell control words of a lock-step: grid = ceil(cells / 256), block = 256
@@ -627,10 +655,10 @@ __global__ void les_maxflow_tiled_init_kernel(char* ws, long long nodes, int nce
     }
     if (i >= ncells) return;
     MtCtl* c = reinterpret_cast<MtCtl*>(ws + L.ctl) + i;
-    c->phase = kMtRelabel0; c->arrived = 0; c->changed = 0; c->active = 0;
+    c->phase = kMtRelabel0; c->votes = 0;
     c->parity = 0; c->sweeps = 0; c->launches = 0; c->rounds = 0;
     c->ntiles = tiles_per_cell[i];
-    c->hand = -1; c->hoff = 0; c->flow_fix = 0;
+    c->hand = -1; c->pad0 = 0; c->hoff = 0; c->flow_fix = 0;
     status[i] = 1;
     if (flows) flows[i] = 0.0;
     if (tiles_per_cell[i] == 0) {                     // an empty cell has nothing to cut
