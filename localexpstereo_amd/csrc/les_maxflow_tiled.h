@@ -100,12 +100,12 @@ __device__ inline long long mt_load_i64(const long long* p) { return __atomic_lo
 // invariant) they do not fit the 128 registers and come back from scratch memory on every iteration; recomputing one is one v_add.
 #define MT_OPAQUE(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ bool mt_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
-__device__ __forceinline__ int mt_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int mt_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // (counters: read after the launch)
 __device__ __forceinline__ int mt_atomic_or(int* p, int v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int mt_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mt_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mt_fence() { __threadfence(); }
-__device__ __forceinline__ void mt_host_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }   // (fine-grained host memory)
+__device__ __forceinline__ void mt_host_add(int* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // (fine-grained host memory)
 __device__ __forceinline__ void mt_atomic_add_i64(long long* p, long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the arrival of a tile: RELAXED -- nothing another tile wrote in this launch is read before the next launch (the kernel boundary orders it), and a
 // release here is a write-back of the XCD's whole L2 (measured with the clock stamps of tools/lab/mt_probe.py: 4.5 us median, 30 us worst, per tile and launch)
