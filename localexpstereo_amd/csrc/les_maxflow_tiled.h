@@ -225,9 +225,15 @@ les_maxflow_tiled_kernel(MtArgs a)
     auto loff = [&](int k) { return mf_dy(k) * tw + mf_dx(k); };            // neighbour k in the tile-local arrays
     auto goff = [&](int k) { return (long long)mf_dy(k) * W + mf_dx(k); };  // neighbour k in the global arrays
 
+    // No barrier behind this initialisation on the device: every use of these words lies behind the phase's own first barrier (the one that waits for
+    // the tile's loads) -- measured with the clock stamps: a barrier here costs 2.9 us per launch, the waves of a workgroup do not start together.
+    // DISCHARGE keeps its "is there anything to do in this tile" vote in rowchg[0 .. 15] (one word per wave, written unconditionally) and does not use the row flags.
     if (tid < 16) sflag[tid] = 0;
-    for (int i = tid; i < 3 * 72; i += kMtThreads) rowchg[i] = i < 72 ? 1 : 0;     // sweep 0 looks at every row
+    if (phase != kMtDischarge)
+        for (int i = tid; i < 3 * 72; i += kMtThreads) rowchg[i] = i < 72 ? 1 : 0;     // sweep 0 looks at every row
+#if defined(LES_SIM)
     __syncthreads();
+#endif
     MT_STAMP(2);
 
     // halo of the height array from the global heights (nodes outside the cell: BIG); own nodes are loaded by the phases
@@ -247,15 +253,17 @@ les_maxflow_tiled_kernel(MtArgs a)
     };
 
     // what the neighbouring tiles pushed towards node j in the previous outbox launch (added in direction order)
-    auto apply_inbox = [&](int j, float (&r)[8], float& e) {
+    auto apply_inbox = [&](int j, float (&r)[8], float& e) -> bool {        // -> something arrived
         const float* ob = g_out + (size_t)(parity ^ 1) * out_par;
         float g[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)             // the sender along k is the neighbour in direction k ^ 1
             g[k] = ((outm[j] >> (k ^ 1) & 1u) && (incell[j] >> (k ^ 1) & 1u)) ? ob[(size_t)(gi(j) - goff(k)) * 8 + k] : 0.0f;
+        bool any = false;
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (g[k] > 0.0f) { r[k ^ 1] += g[k]; e += g[k]; }
+            if (g[k] > 0.0f) { r[k ^ 1] += g[k]; e += g[k]; any = true; }
+        return any;
     };
     auto store_r = [&](int j, const float (&r)[8]) {
         float4* p = reinterpret_cast<float4*>(g_r + (size_t)gi(j) * 8);
@@ -392,44 +400,48 @@ les_maxflow_tiled_kernel(MtArgs a)
     } else if (phase == kMtDischarge) {
         load_halo(true);
         float r[kMtNpt][8];
-        float e0[kMtNpt];
+        float e0[kMtNpt], e1[kMtNpt];      // excess before / after what the neighbouring tiles pushed across the border
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < kMtNpt; j++) {
-            e0[j] = 0.0f;
+            e0[j] = 0.0f; e1[j] = 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; k++) r[j][k] = 0.0f;
             if (!has[j]) continue;
             const int v = tid + j * kMtThreads;
             const int h = g_h_rd[gi(j)];
             hg[hi[j]] = h;
-            float e = g_ex[gi(j)];
-            // the residuals are only needed when something can happen in this tile; whether it can is known after the inbox
-            float got = 0.0f;
-            if (outm[j]) {
-                const float* ob = g_out + (size_t)(parity ^ 1) * out_par;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if ((outm[j] >> (k ^ 1) & 1u) && (incell[j] >> (k ^ 1) & 1u)) got += ob[(size_t)(gi(j) - goff(k)) * 8 + k];
-            }
-            e0[j] = e;
+            const float e = g_ex[gi(j)];
+            // the residuals are loaded together with the rest of the tile's state (one trip to memory instead of two: an idle tile reads them for nothing)
+            load_r(j, r[j]);
+            float ein = e;
+            const bool got = outm[j] ? apply_inbox(j, r[j], ein) : false;
+            e0[j] = e; e1[j] = ein;
             exs[v] = e;
             flg[v] = 0;
-            if ((e > 0.0f && h < BIG) || got > 0.0f) mine = true;
+            if ((e > 0.0f && h < BIG) || got) mine = true;
         }
+#if defined(LES_SIM)
         if (mine) sflag[4] = 1;
         __syncthreads();
-        MT_STAMP(3);
         const bool busy = sflag[4] != 0;
+#else
+        {
+            const bool any = mt_wave_any(mine);
+            if ((tid & 63) == 0) rowchg[tid >> 6] = any ? 1 : 0;
+        }
+        __syncthreads();
+        bool busy = false;
+#pragma unroll
+        for (int w = 0; w < kMtThreads / 64; w++) busy = busy || rowchg[w] != 0;
+#endif
+        MT_STAMP(3);
         if (busy) {
 #pragma unroll
             for (int j = 0; j < kMtNpt; j++) {
                 if (!has[j]) continue;
                 const int v = tid + j * kMtThreads;
-                load_r(j, r[j]);
-                float e = e0[j];
-                if (outm[j]) apply_inbox(j, r[j], e);
-                exs[v] = e;
+                exs[v] = e1[j];
 #pragma unroll
                 for (int k = 0; k < 8; k++) sent[k * NP + v] = 0.0f;
             }
