@@ -43,8 +43,10 @@ constexpr int kMtMaxTileNodes = 1920;                      // tw * th
 constexpr int kMtMaxSide = 64;                             // tw, th <= 64
 constexpr int kMtMaxHalo = kMtMaxTileNodes + 2 * (kMtMaxSide + kMtMaxTileNodes / kMtMaxSide) + 4;    // (tw + 2) * (th + 2) <= 2112
 static_assert(kMtThreads * kMtNpt >= kMtMaxTileNodes, "every node needs an owner");
-// LDS: heights incl. halo, excess, 8 exchange words and a flag byte per node, 16 control words, 3 x 72 row flags -- 80 416 B, two workgroups per CU
-constexpr size_t kMtLdsBytes = (size_t)kMtMaxHalo * 4 + (size_t)kMtMaxTileNodes * (4 + 8 * 4 + 1) + 64 + 3 * 72 * 4;
+// LDS: heights incl. halo TWICE (DISCHARGE alternates between the two: the relabel of an iteration writes the other buffer, so an iteration has two barriers
+// instead of three), 8 exchange words and a flag byte per node, 16 control words, 3 x 72 row flags -- 81 184 B, two workgroups per CU.  The excess of a
+// node is only ever looked at by its owner: a register.
+constexpr size_t kMtLdsBytes = (size_t)kMtMaxHalo * 8 + (size_t)kMtMaxTileNodes * (8 * 4 + 1) + 64 + 3 * 72 * 4;
 static_assert(2 * kMtLdsBytes <= 160 * 1024, "two workgroups per CU");
 
 enum MtPhase : int { kMtRelabel0 = 0, kMtRelabel = 1, kMtDischarge = 2, kMtFinal = 3, kMtDone = 4, kMtHandover = 5 };      // (>= kMtDone: the launches leave the cell alone)
@@ -169,8 +171,8 @@ les_maxflow_tiled_kernel(MtArgs a)
     MT_STAMP(1);
 
     int* hg = reinterpret_cast<int*>(base);                                 // heights / distances, halo-pitched: (th + 2) x (tw + 2)
-    float* exs = reinterpret_cast<float*>(hg + kMtMaxHalo);                 // > 0: excess; < 0: remaining capacity to the sink
-    float* sent = exs + kMtMaxTileNodes;                                    // sent[k * NP + v]
+    int* hg2 = hg + kMtMaxHalo;                                             // the second height buffer of DISCHARGE
+    float* sent = reinterpret_cast<float*>(hg2 + kMtMaxHalo);               // sent[k * NP + v]
     uint8_t* flg = reinterpret_cast<uint8_t*>(sent + 8 * kMtMaxTileNodes);  // "something was sent to this node"
     int* sflag = reinterpret_cast<int*>(flg + kMtMaxTileNodes);             // [0..2] rotating "changed" flags of relax, [3] tile changed, [4] busy, [7] tile active, [8..10] rotating "still active" flags of the iterations
     int* rowchg = sflag + 16;                                               // [3][72]: rows of the tile (halo rows included) in which a distance fell, per sweep
@@ -237,7 +239,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     MT_STAMP(2);
 
     // halo of the height array from the global heights (nodes outside the cell: BIG); own nodes are loaded by the phases
-    auto load_halo = [&](bool from_global) {
+    auto load_halo = [&](bool from_global, bool both = false) {
         const int ring = 2 * (tw + 2) + 2 * th;
         for (int i = tid; i < ring; i += kMtThreads) {
             int hx, hy;
@@ -249,6 +251,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             int val = BIG;
             if (from_global && gx >= 0 && gx < W && gy >= 0 && gy < H) val = g_h_rd[off + (long long)gy * W + gx];
             hg[hy * hp + hx] = val;
+            if (both) hg2[hy * hp + hx] = val;
         }
     };
 
@@ -317,10 +320,11 @@ les_maxflow_tiled_kernel(MtArgs a)
         // ---- (re)load the tile's residuals, fold in the inbox, distances inside the tile alone
         load_halo(false);
         unsigned rm[kMtNpt];
+        float ex0[kMtNpt];
         double t_in = 0.0;
 #pragma unroll
         for (int j = 0; j < kMtNpt; j++) {
-            rm[j] = 0;
+            rm[j] = 0; ex0[j] = 0.0f;
             if (!has[j]) continue;
             float r[8], e;
             if (launch == 0) {
@@ -339,7 +343,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             }
             store_r(j, r);
             g_ex[gi(j)] = e;
-            exs[tid + j * kMtThreads] = e;
+            ex0[j] = e;
 #pragma unroll
             for (int k = 0; k < 8; k++) rm[j] |= (r[k] > 0.0f ? 1u : 0u) << k;
             g_rm[gi(j)] = (uint8_t)rm[j];
@@ -372,7 +376,7 @@ les_maxflow_tiled_kernel(MtArgs a)
             if (!has[j]) continue;
             const int d = hg[hi[j]];
             g_h_wr[gi(j)] = d;
-            if (exs[tid + j * kMtThreads] > 0.0f && d < BIG) tile_active = true;
+            if (ex0[j] > 0.0f && d < BIG) tile_active = true;
         }
         tile_changed = true;                                          // (the neighbours have not seen these distances yet)
     } else if (phase == kMtRelabel) {
@@ -398,28 +402,28 @@ les_maxflow_tiled_kernel(MtArgs a)
             if (d < BIG && g_ex[gi(j)] > 0.0f) tile_active = true;
         }
     } else if (phase == kMtDischarge) {
-        load_halo(true);
+        load_halo(true, true);
         float r[kMtNpt][8];
-        float e0[kMtNpt], e1[kMtNpt];      // excess before / after what the neighbouring tiles pushed across the border
+        float e[kMtNpt];                   // excess of the own nodes (after what the neighbouring tiles pushed across the border)
+        int hv[kMtNpt];                    // heights of the own nodes (the neighbours read them from LDS)
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < kMtNpt; j++) {
-            e0[j] = 0.0f; e1[j] = 0.0f;
+            e[j] = 0.0f; hv[j] = BIG;
 #pragma unroll
             for (int k = 0; k < 8; k++) r[j][k] = 0.0f;
             if (!has[j]) continue;
             const int v = tid + j * kMtThreads;
-            const int h = g_h_rd[gi(j)];
-            hg[hi[j]] = h;
-            const float e = g_ex[gi(j)];
+            hv[j] = g_h_rd[gi(j)];
+            hg[hi[j]] = hv[j];
+            hg2[hi[j]] = hv[j];
+            const float e_in = g_ex[gi(j)];
             // the residuals are loaded together with the rest of the tile's state (one trip to memory instead of two: an idle tile reads them for nothing)
             load_r(j, r[j]);
-            float ein = e;
-            const bool got = outm[j] ? apply_inbox(j, r[j], ein) : false;
-            e0[j] = e; e1[j] = ein;
-            exs[v] = e;
+            e[j] = e_in;
+            const bool got = outm[j] ? apply_inbox(j, r[j], e[j]) : false;
             flg[v] = 0;
-            if ((e > 0.0f && h < BIG) || got) mine = true;
+            if ((e_in > 0.0f && hv[j] < BIG) || got) mine = true;
         }
 #if defined(LES_SIM)
         if (mine) sflag[4] = 1;
@@ -441,7 +445,6 @@ les_maxflow_tiled_kernel(MtArgs a)
             for (int j = 0; j < kMtNpt; j++) {
                 if (!has[j]) continue;
                 const int v = tid + j * kMtThreads;
-                exs[v] = e1[j];
 #pragma unroll
                 for (int k = 0; k < 8; k++) sent[k * NP + v] = 0.0f;
             }
@@ -449,63 +452,56 @@ les_maxflow_tiled_kernel(MtArgs a)
             MT_STAMP(4);
             // ---- K synchronous iterations: pushes | barrier | receive + relabel | barrier.  All LDS reads of a step are issued together and
             // unconditionally (a chain of conditional reads costs a round trip each); a wave none of whose lanes has work skips the step.
+            // The heights live in two buffers: an iteration reads `hc`, its relabel writes the raised heights into `hn`, which the next iteration
+            // reads -- the new height of a node is never stored where a neighbour may still be reading the old one (the snapshot rule that makes
+            // the flows bit-reproducible) without a third barrier.  A raised node brings the buffer it did NOT write up to date in the push half
+            // of the next iteration, when nobody reads it.
+            bool stale[kMtNpt];
+#pragma unroll
+            for (int j = 0; j < kMtNpt; j++) stale[j] = false;
             for (int it = 0; it < Kit; it++) {
-                int hnew[kMtNpt];                                             // heights this iteration's relabel raises (-1: unchanged)
+                int* hc = (it & 1) ? hg2 : hg;
+                int* hn = (it & 1) ? hg : hg2;
                 const int fl = 8 + it % 3;
                 if (tid == 0) sflag[8 + (it + 1) % 3] = 0;
                 bool act = false;
-                {
-                    float e[kMtNpt];
-                    int hv[kMtNpt];
 #pragma unroll
-                    for (int j = 0; j < kMtNpt; j++) {
-                        const int v = has[j] ? tid + j * kMtThreads : 0;
-                        e[j] = exs[v];
-                        hv[j] = hg[hi[j]];
-                    }
+                for (int j = 0; j < kMtNpt; j++) {
+                    LES_MARCH_SCHED_FENCE();                                  // (keeps the eight reads of one node together instead of hoisting all thirty-two)
+                    if (stale[j]) hn[hi[j]] = hv[j];
+                    const bool on = has[j] && e[j] > 0.0f && hv[j] < BIG;
+                    if (!mt_wave_any(on)) continue;
+                    int hw[8];
+                    int hij = hi[j];
+                    MT_OPAQUE(hij);
 #pragma unroll
-                    for (int j = 0; j < kMtNpt; j++) {
-                        LES_MARCH_SCHED_FENCE();                                  // (keeps the eight reads of one node together instead of hoisting all thirty-two)
-                        const bool on = has[j] && e[j] > 0.0f && hv[j] < BIG;
-                        if (!mt_wave_any(on)) continue;
-                        int hw[8];
-                        int hij = hi[j];
-                        MT_OPAQUE(hij);
+                    for (int k = 0; k < 8; k++) hw[k] = hc[hij + hoff(k)];
+                    if (!on) continue;
+                    int v = tid + j * kMtThreads;
+                    MT_OPAQUE(v);
+                    unsigned om = outm[j];
+                    MT_OPAQUE(om);                                            // (tested bit by bit here: 32 precomputed lane masks would live in spilled SGPRs)
+                    float ee = e[j];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) hw[k] = hg[hij + hoff(k)];
-                        if (!on) continue;
-                        int v = tid + j * kMtThreads;
-                        MT_OPAQUE(v);
-                        unsigned om = outm[j];
-                        MT_OPAQUE(om);                                            // (tested bit by bit here: 32 precomputed lane masks would live in spilled SGPRs)
-                        float ee = e[j];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const float rk = r[j][k];
-                            if (rk > 0.0f && ee > 0.0f && hv[j] > hw[k]) {
-                                const float d = ee < rk ? ee : rk;
-                                r[j][k] = rk - d;
-                                ee -= d;
-                                if (om >> k & 1u) sent[k * NP + v] += d;             // leaves the tile: accumulates for the outbox
-                                else { sent[k * NP + v] = d; flg[v + loff(k)] = 1; }
-                            }
+                    for (int k = 0; k < 8; k++) {
+                        const float rk = r[j][k];
+                        if (rk > 0.0f && ee > 0.0f && hv[j] > hw[k]) {
+                            const float d = ee < rk ? ee : rk;
+                            r[j][k] = rk - d;
+                            ee -= d;
+                            if (om >> k & 1u) sent[k * NP + v] += d;             // leaves the tile: accumulates for the outbox
+                            else { sent[k * NP + v] = d; flg[v + loff(k)] = 1; }
                         }
-                        if (ee != e[j]) exs[v] = ee;
                     }
+                    e[j] = ee;
                 }
                 __syncthreads();
                 {
-                    float e[kMtNpt];
-                    int hv[kMtNpt];
                     bool f[kMtNpt];
                     uint8_t fb[kMtNpt];
 #pragma unroll
-                    for (int j = 0; j < kMtNpt; j++) hnew[j] = -1;
-#pragma unroll
                     for (int j = 0; j < kMtNpt; j++) {
                         const int v = has[j] ? tid + j * kMtThreads : 0;
-                        e[j] = exs[v];
-                        hv[j] = hg[hi[j]];
                         fb[j] = flg[v];                                           // (unconditional: a guarded read is a round trip of its own)
                     }
 #pragma unroll
@@ -513,6 +509,7 @@ les_maxflow_tiled_kernel(MtArgs a)
 #pragma unroll
                     for (int j = 0; j < kMtNpt; j++) {
                         LES_MARCH_SCHED_FENCE();
+                        stale[j] = false;
                         int v = has[j] ? tid + j * kMtThreads : 0;
                         MT_OPAQUE(v);
                         if (mt_wave_any(f[j])) {
@@ -533,33 +530,27 @@ les_maxflow_tiled_kernel(MtArgs a)
                                     add += g[k];
                                 }
                                 e[j] += add;                                     // (a sink arc absorbs what it can right here)
-                                exs[v] = e[j];
                             }
                         }
                         const bool on = has[j] && e[j] > 0.0f && hv[j] < BIG;
                         if (!mt_wave_any(on)) continue;
-                        // relabel when no residual arc leads downhill -- from a SNAPSHOT: the new height is kept in a register and stored after the
-                        // barrier below, so that what a neighbour reads in this half never depends on which wave ran first (bit-reproducible flows)
+                        // relabel when no residual arc leads downhill -- from a SNAPSHOT (the buffer every wave reads in this iteration)
                         int hw[8];
                         int hij = hi[j];
                         MT_OPAQUE(hij);
 #pragma unroll
-                        for (int k = 0; k < 8; k++) hw[k] = hg[hij + hoff(k)];
+                        for (int k = 0; k < 8; k++) hw[k] = hc[hij + hoff(k)];
                         if (!on) continue;
                         int best = BIG;
 #pragma unroll
                         for (int k = 0; k < 8; k++) best = (r[j][k] > 0.0f && hw[k] + 1 < best) ? hw[k] + 1 : best;
-                        if (best > hv[j]) hnew[j] = best;
+                        if (best > hv[j]) { hv[j] = best; hn[hij] = best; stale[j] = true; }
                         if (best < BIG) act = true;
                     }
                 }
                 if (act) sflag[fl] = 1;
                 __syncthreads();
-#pragma unroll
-                for (int j = 0; j < kMtNpt; j++)
-                    if (hnew[j] >= 0) hg[hi[j]] = hnew[j];
-                if (!sflag[fl]) break;                                        // (own heights only from here on: the write-back below reads hg[hi[j]])
-                __syncthreads();
+                if (!sflag[fl]) break;
             }
             MT_STAMP(5);
             // ---- write the tile back
@@ -568,11 +559,9 @@ les_maxflow_tiled_kernel(MtArgs a)
                 if (!has[j]) continue;
                 const int v = tid + j * kMtThreads;
                 store_r(j, r[j]);
-                const float e = exs[v];
-                const int h = hg[hi[j]];
-                g_ex[gi(j)] = e;
-                g_h_wr[gi(j)] = h;
-                if (e > 0.0f && h < BIG) tile_active = true;
+                g_ex[gi(j)] = e[j];
+                g_h_wr[gi(j)] = hv[j];
+                if (e[j] > 0.0f && hv[j] < BIG) tile_active = true;
                 if (outm[j]) {
                     float o[8];
 #pragma unroll
@@ -587,7 +576,7 @@ les_maxflow_tiled_kernel(MtArgs a)
 #pragma unroll
             for (int j = 0; j < kMtNpt; j++) {
                 if (!has[j]) continue;
-                g_h_wr[gi(j)] = hg[hi[j]];                              // (an idle tile only carries its heights over)
+                g_h_wr[gi(j)] = hv[j];                                  // (an idle tile only carries its heights over)
                 if (!outm[j]) continue;
                 const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 store_outbox(j, z);
