@@ -690,6 +690,7 @@ struct MtHandArgs {
     int max_cells;                   // policy: hand over only when at most this many cells ...
     long long max_nodes;             // ... of at most this many nodes in total are still open
     long long cap_nodes;             // capacity of the staging arrays (never exceeded, whatever the policy says)
+    long long max_cell_nodes;        // policy: ... and none of them is larger than this
     MtHandCell* list;                // host-mapped, [max_cells]
     float* rc8;                      // host-mapped staging: [max_nodes][8]
     float* ex;                       // [max_nodes]
@@ -708,9 +709,13 @@ __global__ void les_maxflow_tiled_collect_kernel(MtHandArgs a)
     MtCtl* ctl = reinterpret_cast<MtCtl*>(a.ws + L.ctl);
     int open = 0;
     long long nodes = 0;
+    long long largest = 0;
     for (int i = 0; i < a.ncells; i++)
-        if (ctl[i].phase < kMtDone) { open++; nodes += (long long)a.cells[i].w * a.cells[i].h; }
-    if (open == 0 || open > a.max_cells || nodes > a.max_nodes || nodes > a.cap_nodes) { mt_store(a.host_flags + 2, 0); return; }
+        if (ctl[i].phase < kMtDone) {
+            const long long cn = (long long)a.cells[i].w * a.cells[i].h;
+            open++; nodes += cn; largest = cn > largest ? cn : largest;
+        }
+    if (open == 0 || open > a.max_cells || nodes > a.max_nodes || nodes > a.cap_nodes || largest > a.max_cell_nodes) { mt_store(a.host_flags + 2, 0); return; }
     int slot = 0;
     long long hoff = 0;
     for (int i = 0; i < a.ncells; i++) {
