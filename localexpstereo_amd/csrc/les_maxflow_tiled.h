@@ -49,6 +49,13 @@ static_assert(kMtThreads * kMtNpt >= kMtMaxTileNodes, "every node needs an owner
 constexpr size_t kMtLdsBytes = (size_t)kMtMaxHalo * 8 + (size_t)kMtMaxTileNodes * (8 * 4 + 1) + 64 + 3 * 72 * 4;
 static_assert(2 * kMtLdsBytes <= 160 * 1024, "two workgroups per CU");
 
+// the directions k (les_maxflow.h: E W S N SW NE SE NW) whose step has dx = +1 / dx = -1 / dy = +1 / dy = -1, as bit sets
+constexpr unsigned kMtDirsE = 1u << 0 | 1u << 5 | 1u << 6, kMtDirsW = 1u << 1 | 1u << 4 | 1u << 7, kMtDirsS = 1u << 2 | 1u << 4 | 1u << 6, kMtDirsN = 1u << 3 | 1u << 5 | 1u << 7;
+constexpr int mt_cdx(int k) { return (int)((0x02201102u >> (4 * k)) & 0xfu) - 1; }      // (mf_dx / mf_dy as constant expressions, for the check below)
+constexpr int mt_cdy(int k) { return (int)((0x02020211u >> (4 * k)) & 0xfu) - 1; }
+constexpr unsigned mt_dirs_where(int dx, int dy) { unsigned m = 0; for (int k = 0; k < 8; k++) if ((dx && mt_cdx(k) == dx) || (dy && mt_cdy(k) == dy)) m |= 1u << k; return m; }
+static_assert(mt_dirs_where(1, 0) == kMtDirsE && mt_dirs_where(-1, 0) == kMtDirsW && mt_dirs_where(0, 1) == kMtDirsS && mt_dirs_where(0, -1) == kMtDirsN, "direction sets");
+
 enum MtPhase : int { kMtRelabel0 = 0, kMtRelabel = 1, kMtDischarge = 2, kMtFinal = 3, kMtDone = 4, kMtHandover = 5 };      // (>= kMtDone: the launches leave the cell alone)
 constexpr int kMtFlowShift = 22;                           // flow values are accumulated as 64-bit integers in units of 2^-22 (integer additions commute: the sum over the tiles is the same in any order)
 
@@ -196,6 +203,7 @@ les_maxflow_tiled_kernel(MtArgs a)
     const size_t out_par = (size_t)a.nodes * 8;
 
     // ---- own nodes: v = tid + j * kMtThreads (row-major over the tile)
+    const float inv_tw = 1.0f / (float)tw;
     int hi[kMtNpt];                    // index of the node in the halo-pitched height array (a harmless own index for a missing node)
     int ly_[kMtNpt];
     bool has[kMtNpt];
@@ -207,19 +215,16 @@ les_maxflow_tiled_kernel(MtArgs a)
         const int v = tid + j * kMtThreads;
         has[j] = v < n;
         const int vv = has[j] ? v : 0;
-        const int ly = vv / tw, lx = vv - ly * tw;
+        // (every launch of every tile pays for this set-up, 32 waves per CU at once: the quotient through one reciprocal -- vv < 2048, tw <= 64, so
+        // (vv + 0.5) / tw keeps 1/128 of distance from every integer, three orders of magnitude above the rounding -- and the eight border tests as
+        // four comparisons against the direction sets)
+        const int ly = (int)(((float)vv + 0.5f) * inv_tw), lx = vv - ly * tw;
         ly_[j] = ly;
         hi[j] = (ly + 1) * hp + lx + 1;
         const int gx = t.x0 + lx, gy = t.y0 + ly;
         gl[j] = gy * W + gx;
-        outm[j] = 0; incell[j] = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int nx = lx + mf_dx(k), ny = ly + mf_dy(k);
-            if (nx < 0 || nx >= tw || ny < 0 || ny >= th) outm[j] |= 1u << k;
-            const int cx = gx + mf_dx(k), cy = gy + mf_dy(k);
-            if (cx >= 0 && cx < W && cy >= 0 && cy < H) incell[j] |= 1u << k;
-        }
+        outm[j] = (lx == tw - 1 ? kMtDirsE : 0u) | (lx == 0 ? kMtDirsW : 0u) | (ly == th - 1 ? kMtDirsS : 0u) | (ly == 0 ? kMtDirsN : 0u);
+        incell[j] = 0xffu & ~((gx == W - 1 ? kMtDirsE : 0u) | (gx == 0 ? kMtDirsW : 0u) | (gy == H - 1 ? kMtDirsS : 0u) | (gy == 0 ? kMtDirsN : 0u));
         if (!has[j]) { outm[j] = 0; incell[j] = 0; }
     }
     auto gi = [&](int j) -> size_t { return (size_t)(off + gl[j]); };
