@@ -189,14 +189,19 @@ int les_hip_batch_expansion_graph(les_hip_ctx* ctx, const les_hip_batch* batch, 
 
 /* replaces (on the device, for cells of at most LES_HIP_MAXFLOW_MAX_NODES nodes): the max-flow and the segment read-out of
  * FastGCStereo::expansionMoveBK -- graph.maxflow(); graph.what_segment(i) == SOURCE (LES/FastGCStereo.h:553-559) -- on the
- * payload of les_hip_batch_expansion_graph, for all cells of the batch, one workgroup per cell with the whole graph in LDS
+ * payload of les_hip_batch_expansion_graph, for all cells of the batch, one workgroup per cell with the whole graph on chip
  * (synchronous push-relabel; the cut is the canonical one of the reference's solver: SINK side = nodes that can still reach the
- * sink).  d_masks: one byte per graph node (255 = the node takes the proposal), the input of les_hip_batch_apply_masks;
+ * sink).  Two kernels: when every cell of the batch has at most 2048 nodes, (w + 2) * (h + 2) <= 2304 and h <= 70 -- the finest
+ * layer's cells do -- csrc/les_maxflow_cell.h (residuals in registers, two barriers per iteration); otherwise csrc/les_maxflow.h
+ * (residuals in LDS).  Same cut from both up to nodes on exact ties that float rounding moves; les_hip_batch_graph_solver_kind says
+ * which one a call would launch (0 = les_maxflow_cell.h, 1 / 2 = les_maxflow.h with 1024 / 512 threads, -1 = a cell above the limit);
+ * LES_HIP_MAXFLOW_CELL_KERNEL=0 in the environment forces les_maxflow.h.  d_masks: one byte per graph node (255 = the node takes the proposal), the input of les_hip_batch_apply_masks;
  * d_status: n ints (0 = solved, 1 = iteration limit reached: cut that cell with the host solver instead); d_flows: n doubles or
  * NULL (flow through the n-links; add flow0 of les_hip_batch_expansion_graph for the value of the cut).
  * les_hip_batch_max_cell_nodes: the largest w * h of the batch's target rects (callers check it against the limit). */
 #define LES_HIP_MAXFLOW_MAX_NODES 2304
 long long les_hip_batch_max_cell_nodes(const les_hip_batch* batch);
+int les_hip_batch_graph_solver_kind(const les_hip_batch* batch);
 int les_hip_batch_solve_graphs(les_hip_ctx* ctx, const les_hip_batch* batch, const float* d_payload, unsigned char* d_masks, int* d_status,
                                double* d_flows);
 /* The same with a running count: *d_unsolved_total (a device int the caller zeroed) += 1 for every cell that hits the iteration limit.  A caller

@@ -19,7 +19,7 @@ PLANE_DT = np.dtype([("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("v", "<f4")])
 SYMBOLS = [
     "les_hip_create", "les_hip_create_naive", "les_hip_destroy", "les_hip_last_error", "les_hip_set_stream", "les_hip_set_thread_stream", "les_hip_synchronize",
     "les_hip_unary_one", "les_hip_unary_one_scratch", "les_hip_scratch_create", "les_hip_scratch_destroy", "les_hip_unary_batch", "les_hip_batch_create", "les_hip_batch_destroy",
-    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_refresh_volume", "les_hip_batch_solve_graphs", "les_hip_batch_solve_graphs_counted", "les_hip_batch_solve_graphs_tiled", "les_hip_batch_solve_graphs_tiled_stats", "les_hip_batch_tiled_workspace_bytes", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
+    "les_hip_batch_num_jobs", "les_hip_batch_kernel_kind", "les_hip_batch_graph_nodes", "les_hip_batch_graph_offsets", "les_hip_batch_expansion_graph", "les_hip_batch_max_cell_nodes", "les_hip_batch_graph_solver_kind", "les_hip_refresh_volume", "les_hip_batch_solve_graphs", "les_hip_batch_solve_graphs_counted", "les_hip_batch_solve_graphs_tiled", "les_hip_batch_solve_graphs_tiled_stats", "les_hip_batch_tiled_workspace_bytes", "les_hip_batch_apply_masks", "les_hip_batch_run", "les_hip_batch_set_units", "les_hip_batch_propose", "les_hip_batch_wta",
     "les_hip_wta_update", "les_hip_malloc", "les_hip_free",
     "les_hip_memcpy_h2d", "les_hip_memcpy_d2h", "les_hip_memset", "les_hip_get_stats", "les_hip_strip_width", "les_hip_tiled_volume_bytes",
     "les_hip_calib_copy", "les_hip_calib_copy_wide", "les_hip_exchange_create", "les_hip_exchange_destroy", "les_hip_exchange_slot_floats",
@@ -84,6 +84,7 @@ def load(path=None):
         "les_hip_batch_expansion_graph": (ci, [vp, vp, ci, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
         "les_hip_batch_apply_masks": (ci, [vp, vp, vp, vp, vp, vp, vp]),
         "les_hip_batch_max_cell_nodes": (C.c_longlong, [vp]),
+        "les_hip_batch_graph_solver_kind": (ci, [vp]),
         "les_hip_refresh_volume": (ci, [vp, ci]),
         "les_hip_batch_solve_graphs": (ci, [vp, vp, vp, vp, vp, vp]),
         "les_hip_batch_solve_graphs_counted": (ci, [vp, vp, vp, vp, vp, vp, vp]),
@@ -307,6 +308,11 @@ class Batch:
     @property
     def max_cell_nodes(self):
         return int(self.e.L.les_hip_batch_max_cell_nodes(self.h))
+
+    @property
+    def graph_solver_kind(self):
+        """Which one-workgroup kernel solve_graphs would launch: 0 = les_maxflow_cell.h, 1 / 2 = les_maxflow.h, -1 = a cell above the limit."""
+        return int(self.e.L.les_hip_batch_graph_solver_kind(self.h))
 
     def solve_graphs(self, payload_dev, masks_dev, status_dev, flows_dev=None, unsolved_total_dev=None):
         """Max-flow + segment read-out of every cell's expansion graph on the device (LES/FastGCStereo.h:553-559); cells of at most

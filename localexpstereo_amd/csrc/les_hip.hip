@@ -12,6 +12,7 @@
 #include "les_pairwise.h"
 #include "les_maxflow.h"
 #include "les_maxflow_tiled.h"
+#include "les_maxflow_cell.h"
 
 #include "../host/ResidualCut.h"      // the host cores' finisher of the tiled max-flow (plain C++: search trees / push-relabel on a residual graph)
 

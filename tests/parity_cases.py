@@ -1025,7 +1025,7 @@ def case_device_cuts_vs_host_cuts(lib, device, gc_iters=2, units=(14, 43)):
     return worst, energies
 
 
-def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
+def case_device_maxflow_edge_cells(pr, seed=3, tiled=False, kind=None):
     """les_hip_batch_solve_graphs on hand-made graphs of awkward shapes -- single rows and columns, 1 x 1 and 2 x 2 cells, cells with no
     arcs, with only source or only sink terminals, with terminals of 1e6 next to capacities below 1, and one cell just under the
     node limit -- against the host solver on the same payload: identical masks, equal flows.  Also: a cell above the limit is refused."""
@@ -1033,13 +1033,17 @@ def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
     rng = np.random.default_rng(seed)
     H, W = pr.H, pr.W
     shapes = [(1, 1), (2, 2), (1, 17), (19, 1), (7, 5), (12, 12), (16, 9), (5, 23), (13, 13), (11, 8), (9, 9), (10, 6)]
-    if W >= 48 and H >= 48:
-        shapes.append((48, 48))                              # 2304 nodes: the largest cell the kernel takes (five nodes per thread)
+    if W >= 48 and H >= 48 and kind != 0:
+        shapes.append((48, 48))                              # 2304 nodes: the largest cell les_maxflow.h takes (five nodes per thread)
+    elif W >= 46 and H >= 68:
+        shapes += [(46, 44), (30, 68), (45, 45)]            # the largest cells les_maxflow_cell.h takes: (w + 2) (h + 2) <= 2304, w h <= 2048, h <= 70
     rects, x, y, rowh = [], 0, 0, 0
     for (w, h) in shapes:
         if x + w > W:
             x, y, rowh = 0, y + rowh, 0
-        assert y + h <= H
+        if y + h > H:                          # (the solvers only look at the payload: cells may overlap in the image)
+            x, y, rowh = 0, 0, 0
+        assert w <= W and h <= H
         rects.append((x, y, w, h))
         x += w
         rowh = max(rowh, h)
@@ -1052,14 +1056,14 @@ def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
         p = pay[off[i]: off[i] + n]
         p[:, 0] = rng.normal(0, 0.8, n)
         p[:, 1:] = rng.uniform(0, 0.6, (n, 4)) * (rng.uniform(0, 1, (n, 4)) < 0.8)
-        kind = i % 6
-        if kind == 1:
+        variant = i % 6
+        if variant == 1:
             p[:, 1:] = 0                                      # no arcs at all
-        elif kind == 2:
+        elif variant == 2:
             p[:, 0] = np.abs(p[:, 0])                         # only source terminals: everything takes the proposal
-        elif kind == 3:
+        elif variant == 3:
             p[:, 0] = -np.abs(p[:, 0])                        # only sink terminals: nothing changes
-        elif kind == 4:
+        elif variant == 4:
             big = rng.uniform(0, 1, n) < 0.3
             p[big, 0] = np.where(rng.uniform(0, 1, int(big.sum())) < 0.5, 1e6, -1e6)
         q = p.reshape(h, w, 5)                                # arcs E, S, SW, SE that would leave the cell carry no capacity
@@ -1072,6 +1076,7 @@ def case_device_maxflow_edge_cells(pr, seed=3, tiled=False):
         batch.solve_graphs_tiled(dp.ptr, dm.ptr, ds.ptr, ws.ptr, ws.nbytes, df.ptr)
         ws.free()
     else:
+        assert kind is None or batch.graph_solver_kind == kind, (batch.graph_solver_kind, kind)
         batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
     pr.e.synchronize()
     assert not ds.download((k,), np.int32).any()
@@ -1169,8 +1174,9 @@ def _random_cell_payloads(rng, shapes, dyadic):
     return pays
 
 
-def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=None):
-    """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel."""
+def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=None, kind=None):
+    """tiled: the region-parallel solver for cells of any size (les_hip_batch_solve_graphs_tiled) instead of the one-workgroup-per-cell kernel.
+    kind: which one-workgroup kernel the call must go to (0 = csrc/les_maxflow_cell.h, 1 / 2 = csrc/les_maxflow.h; None = not checked)."""
     H, W = pr.H, pr.W
     rects, x, y, rowh = [], 0, 0, 0
     for (w, h) in shapes:
@@ -1200,6 +1206,7 @@ def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=No
             stats.update(batch.tiled_stats)
         ws.free()
     else:
+        assert kind is None or batch.graph_solver_kind == kind, (batch.graph_solver_kind, kind)
         batch.solve_graphs(dp.ptr, dm.ptr, ds.ptr, df.ptr)
     pr.e.synchronize()
     status = ds.download((k,), np.int32)
@@ -1210,7 +1217,7 @@ def _solve_cells_on_device(pr, shapes, pays, tiled=False, poison=False, stats=No
     return off, status, masks, flows
 
 
-def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45, tiled=False):
+def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45, tiled=False, kind=None):
     """les_maxflow_kernel against an INDEPENDENT checker (networkx preflow-push + residual reachability), not against the host solver:
       * dyadic capacities (arithmetic exact in float and double): the device mask equals the canonical minimum cut node for node and the
         flow is equal;
@@ -1227,7 +1234,7 @@ def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45, tiled=Fa
         if side_hi >= 42:
             shapes[1] = (42, 42)
         pays = _random_cell_payloads(rng, shapes, dyadic)
-        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled)
+        off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled, kind=kind)
         assert not status.any(), "a cell hit the iteration limit"
         for i, ((w, h), p) in enumerate(zip(shapes, pays)):
             ref_flow, ref_src = _grid_graph_reference(p, w, h)
@@ -1245,14 +1252,14 @@ def case_device_maxflow_vs_networkx(pr, seed=5, ncells=50, max_side=45, tiled=Fa
     return ncells // 2 * 2, total_nodes, total_diff
 
 
-def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40, tiled=False):
+def case_device_maxflow_vs_brute_force(pr, seed=9, ncells=40, tiled=False, kind=None):
     """Cells of at most 4 x 4 nodes: every one of the 2^n labelings is enumerated; the device mask must be THE canonical minimum cut
     (the minimum-capacity labeling whose sink side is the intersection of all minimum sink sides).  Dyadic capacities: exact."""
     rng = np.random.default_rng(seed)
     shapes = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(ncells)]
     shapes[0] = (4, 4)
     pays = _random_cell_payloads(rng, shapes, dyadic=True)
-    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled)
+    off, status, masks, flows = _solve_cells_on_device(pr, shapes, pays, tiled=tiled, kind=kind)
     assert not status.any()
     for i, ((w, h), p) in enumerate(zip(shapes, pays)):
         n = w * h

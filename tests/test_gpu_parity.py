@@ -389,19 +389,26 @@ def test_gpu_device_cuts_vs_host_cuts(oracle_mod):
     print("device cuts vs host cuts: largest fraction of differing nodes per lock-step", worst, "energies after the iterations (host, device)", energies)
 
 
-def test_gpu_device_maxflow_edge_cells(cones, mid):
-    pc.case_device_maxflow_edge_cells(cones)
-    pc.case_device_maxflow_edge_cells(mid, seed=8)
+def test_gpu_device_maxflow_edge_cells(cones, mid, monkeypatch):
+    """Both one-workgroup solvers: csrc/les_maxflow_cell.h (every cell fits it) and csrc/les_maxflow.h (a 48 x 48 cell in the batch, or on request)."""
+    pc.case_device_maxflow_edge_cells(cones, kind=0)
+    pc.case_device_maxflow_edge_cells(mid, seed=8, kind=0)
+    pc.case_device_maxflow_edge_cells(cones, kind=2)
+    pc.case_device_maxflow_edge_cells(mid, seed=8, kind=2)
+    monkeypatch.setenv("LES_HIP_MAXFLOW_CELL_KERNEL", "0")
+    pc.case_device_maxflow_edge_cells(mid, seed=9, kind=2)
 
 
-def test_gpu_device_maxflow_against_independent_checkers(mid):
+def test_gpu_device_maxflow_against_independent_checkers(mid, monkeypatch):
     """les_maxflow_kernel is checked WITHOUT product code on the other side: networkx (preflow-push + residual reachability = the
     canonical cut of the reference's solver) on 50 layer-0-sized cells, and exhaustive enumeration on cells of at most 4 x 4 nodes."""
-    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(mid, seed=5, ncells=50, max_side=45)
-    print(f"device max-flow vs networkx: {cells} cells, {nodes} nodes; float-capacity cells: {diff} nodes on ties (zero energy difference, asserted)")
-    assert diff <= 2e-4 * nodes
-    n = pc.case_device_maxflow_vs_brute_force(mid, seed=9, ncells=40)
-    print(f"device max-flow vs brute force: {n} cells of at most 4 x 4 nodes, canonical cut reproduced exactly")
+    for kind in (0, 1):                                          # csrc/les_maxflow_cell.h (the product's choice for these cells), then csrc/les_maxflow.h
+        monkeypatch.setenv("LES_HIP_MAXFLOW_CELL_KERNEL", str(1 - kind))
+        cells, nodes, diff = pc.case_device_maxflow_vs_networkx(mid, seed=5, ncells=50, max_side=45, kind=kind)
+        print(f"device max-flow (kernel {kind}) vs networkx: {cells} cells, {nodes} nodes; float-capacity cells: {diff} nodes on ties (zero energy difference, asserted)")
+        assert diff <= 2e-4 * nodes
+        n = pc.case_device_maxflow_vs_brute_force(mid, seed=9, ncells=40, kind=kind)
+        print(f"device max-flow (kernel {kind}) vs brute force: {n} cells of at most 4 x 4 nodes, canonical cut reproduced exactly")
 
 
 @pytest.mark.parametrize("th_col", [0.5, 10.0])

@@ -216,11 +216,15 @@ def test_sim_expansion_graph_on_device(cones):
     pc.case_expansion_graph(cones)
 
 
-def test_sim_device_maxflow_edge_cells(cones):
-    """The device max-flow (csrc/les_maxflow.h) on hand-made graphs of awkward shapes against the host solver."""
+def test_sim_device_maxflow_edge_cells(cones, monkeypatch):
+    """The one-workgroup device max-flows (csrc/les_maxflow_cell.h, and csrc/les_maxflow.h for cells beyond it or on request) on hand-made graphs of
+    awkward shapes against the host solver."""
     from localexpstereo_amd import build
     build.build_host_lib()
-    pc.case_device_maxflow_edge_cells(cones)
+    pc.case_device_maxflow_edge_cells(cones, kind=0)
+    pc.case_device_maxflow_edge_cells(cones, kind=2)                       # (the 48 x 48 cell does not fit les_maxflow_cell.h)
+    monkeypatch.setenv("LES_HIP_MAXFLOW_CELL_KERNEL", "0")
+    pc.case_device_maxflow_edge_cells(cones, seed=4, kind=2)
 
 
 def test_sim_refresh_volume(sim_lib, oracle_mod):
@@ -256,9 +260,16 @@ def test_sim_tiled_maxflow_handover(sim_lib, oracle_mod, monkeypatch):
 
 def test_sim_device_maxflow_against_independent_checkers(cones):
     """The same kernel source against networkx and brute force (no product code as the checker); the full-size version runs on the GPU."""
-    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24)
+    cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24, kind=0)
     assert diff <= 1e-3 * nodes
-    pc.case_device_maxflow_vs_brute_force(cones, seed=9, ncells=12)
+    pc.case_device_maxflow_vs_brute_force(cones, seed=9, ncells=12, kind=0)
+    os.environ["LES_HIP_MAXFLOW_CELL_KERNEL"] = "0"                          # les_maxflow.h on the same cells
+    try:
+        cells, nodes, diff = pc.case_device_maxflow_vs_networkx(cones, seed=5, ncells=8, max_side=24, kind=1)
+        assert diff <= 1e-3 * nodes
+        pc.case_device_maxflow_vs_brute_force(cones, seed=9, ncells=12, kind=1)
+    finally:
+        del os.environ["LES_HIP_MAXFLOW_CELL_KERNEL"]
 
 
 def test_sim_exchange_pack_unpack(cones):
