@@ -24,8 +24,12 @@
 
 namespace les {
 
-constexpr int kMcThreads = 1024;
-constexpr int kMcNpt = 2;
+#if !defined(LES_MC_THREADS)
+#define LES_MC_THREADS 1024              // (lab builds: tools/build_variant.sh mcT -DLES_MC_THREADS=512 -DLES_MC_NPT=4; tools/lab/ab_cell_shape.sh)
+#define LES_MC_NPT 2
+#endif
+constexpr int kMcThreads = LES_MC_THREADS;
+constexpr int kMcNpt = LES_MC_NPT;
 constexpr int kMcMaxNodes = 2048;
 constexpr int kMcMaxHalo = 2304;
 constexpr int kMcMaxRows = 72;                              // h + 2
@@ -40,7 +44,7 @@ __host__ __device__ inline bool mc_fits(int w, int h)
 }
 
 // grid = cells; block = kMcThreads; dynamic LDS = kMcLdsBytes.  Every cell of the launch must satisfy mc_fits (or be empty).
-__global__ void __launch_bounds__(kMcThreads, 8)          // two 16-wave workgroups per CU -> at most 64 VGPRs
+__global__ void __launch_bounds__(kMcThreads, kMcThreads / 128)          // two workgroups per CU (1024 threads: 8 waves per SIMD -> at most 64 VGPRs)
 les_maxflow_cell_kernel(const GraphCellMf* __restrict__ cells, const long long* __restrict__ offsets, const float* __restrict__ payload,
                         int max_iter, int round_iters, uint8_t* __restrict__ masks, int* __restrict__ status, double* __restrict__ flows,
                         int* __restrict__ unsolved_total)
