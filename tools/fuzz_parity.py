@@ -160,6 +160,7 @@ def one_case(rng, lib, stats):
             if ndiff > max(2, 2e-5 * nn):
                 raise AssertionError(f"device cut differs from the host cut in {ndiff} of {nn} nodes ({W}x{H}, {k} cells, lambda {lam})")
             stats["cuts"] = stats.get("cuts", 0) + 1
+            stats["cuts_cell_kernel"] = stats.get("cuts_cell_kernel", 0) + (1 if batch.graph_solver_kind == 0 else 0)      # csrc/les_maxflow_cell.h (else les_maxflow.h)
             stats["cut_nodes"] = stats.get("cut_nodes", 0) + nn
             stats["cut_diff"] = stats.get("cut_diff", 0) + ndiff
             for b_ in (dm, ds, df):
@@ -226,7 +227,7 @@ def main():
             raise
         cases += 1
     print(f"fuzz OK: {cases} configurations, {stats['calls']} operator calls, {stats['post']} post-processing runs, "
-          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut; {stats.get('tiled_cuts', 0)} cut by the tiled solver, {stats.get('tiled_multi', 0)} of them with cells of several tiles: {stats.get('tiled_diff', 0)} of {stats.get('tiled_nodes', 0)} nodes differ), {stats.get('naive', 0)} image-based energies ({stats.get('naive_march', 0)} of them on the march kernel), {stats.get('march', 0)} configurations on the march kernel, "
+          f"{stats.get('graphs', 0)} expansion-graph lock-steps ({stats.get('cuts', 0)} of them also cut on the device, {stats.get('cuts_cell_kernel', 0)} by les_maxflow_cell.h and the rest by les_maxflow.h: {stats.get('cut_diff', 0)} of {stats.get('cut_nodes', 0)} nodes differ from the host cut; {stats.get('tiled_cuts', 0)} cut by the tiled solver, {stats.get('tiled_multi', 0)} of them with cells of several tiles: {stats.get('tiled_diff', 0)} of {stats.get('tiled_nodes', 0)} nodes differ), {stats.get('naive', 0)} image-based energies ({stats.get('naive_march', 0)} of them on the march kernel), {stats.get('march', 0)} configurations on the march kernel, "
           f"max abs err / max(1, th_col) = {stats['max_err']:.2e}, {time.time() - t0:.0f} s")
 
 
