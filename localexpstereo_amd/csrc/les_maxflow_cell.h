@@ -84,7 +84,7 @@ les_maxflow_cell_kernel(const GraphCellMf* __restrict__ cells, const long long* 
         const int v = tid + j * kMcThreads;
         has[j] = v < N;
         const int vv = has[j] ? v : 0;
-        const int ly = (int)(((float)vv + 0.5f) * inv_w), lx = vv - ly * W;      // (vv < 2048: the quotient is exact, les_maxflow_tiled.h)
+        const int ly = (int)(((float)vv + 0.5f) * inv_w), lx = vv - ly * W;      // (vv < 2048, W <= 766: the same argument as for yrow below; les_maxflow_tiled.h)
         hi[j] = (ly + 1) * hp + lx + 1;
         edge[j] = (lx == W - 1 ? kMtDirsE : 0u) | (lx == 0 ? kMtDirsW : 0u) | (ly == H - 1 ? kMtDirsS : 0u) | (ly == 0 ? kMtDirsN : 0u);
         e[j] = 0.0f; hv[j] = BIG;
@@ -121,7 +121,7 @@ les_maxflow_cell_kernel(const GraphCellMf* __restrict__ cells, const long long* 
     // Residual distances to the sink over the live values of hgA, one barrier per sweep (les_maxflow_tiled.h: relax)
     const float inv_hp = 1.0f / (float)hp;
     auto relax = [&](const unsigned (&rm)[kMcNpt]) {
-        int yrow[kMcNpt];                                                    // halo-pitched row of the own nodes (hi < 2304, hp <= 66: the quotient is exact)
+        int yrow[kMcNpt];                                                    // halo-pitched row of the own nodes (hi < 2304, hp <= 768: (hi + 0.5) / hp keeps 0.5 / hp >= 6.5e-4 from every integer, the rounding stays below 2e-5)
 #pragma unroll
         for (int j = 0; j < kMcNpt; j++) yrow[j] = (int)(((float)hi[j] + 0.5f) * inv_hp);
         for (int s = 0;; s++) {

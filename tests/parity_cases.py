@@ -1037,6 +1037,8 @@ def case_device_maxflow_edge_cells(pr, seed=3, tiled=False, kind=None):
         shapes.append((48, 48))                              # 2304 nodes: the largest cell les_maxflow.h takes (five nodes per thread)
     elif W >= 46 and H >= 68:
         shapes += [(46, 44), (30, 68), (45, 45)]            # the largest cells les_maxflow_cell.h takes: (w + 2) (h + 2) <= 2304, w h <= 2048, h <= 70
+        if W >= 440:
+            shapes += [(250, 7), (440, 3), (3, 70)]          # ... and its widest / tallest: the row of a node comes from one reciprocal (exactness argued in the header)
     rects, x, y, rowh = [], 0, 0, 0
     for (w, h) in shapes:
         if x + w > W:

@@ -216,6 +216,17 @@ def test_sim_expansion_graph_on_device(cones):
     pc.case_expansion_graph(cones)
 
 
+def test_sim_device_maxflow_widest_cells(sim_lib, oracle_mod):
+    """csrc/les_maxflow_cell.h on its widest and tallest cells (250 x 7, 440 x 3, 3 x 70 next to the usual awkward shapes) against the host solver."""
+    from localexpstereo_amd import build
+    build.build_host_lib()
+    pr = pc.synth_pair(sim_lib, 96, 450, 4)
+    try:
+        pc.case_device_maxflow_edge_cells(pr, seed=5, kind=0)
+    finally:
+        pr.close()
+
+
 def test_sim_device_maxflow_edge_cells(cones, monkeypatch):
     """The one-workgroup device max-flows (csrc/les_maxflow_cell.h, and csrc/les_maxflow.h for cells beyond it or on request) on hand-made graphs of
     awkward shapes against the host solver."""
