@@ -133,7 +133,7 @@ int les_hip_batch_create(les_hip_ctx* ctx, int n, const les_hip_rect* filterRect
 void les_hip_batch_destroy(les_hip_batch* b);
 int les_hip_batch_num_jobs(const les_hip_batch* b);     /* workgroups one run launches                   */
 /* Diagnostic: which kernel les_hip_batch_run launches for this batch and view: 1 = the fixed-point march kernel
- * (csrc/les_march.h; needs a finite volume with th_col - min <= 8 th_col, a guided-filter radius of 4 .. 10 and every target at least 2 x radius away from
+ * (csrc/les_march.h; needs a finite volume with th_col - min <= 8 th_col, a guided-filter radius of 2 .. 10 and every target at least 2 x radius away from
  * filterRect borders that are not image borders -- the geometry of every LayerManager cell), 0 = the fp64 strip kernel
  * (csrc/les_kernels.h; any input), -1 = bad argument.  Both implement LES/CostVolumeEnergy.h:55-183. */
 int les_hip_batch_kernel_kind(const les_hip_ctx* ctx, const les_hip_batch* b, int mode);

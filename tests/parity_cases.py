@@ -100,7 +100,7 @@ def case_naive(lib, windR=20, pm=True):
         # which kernel served the lock-step: the march kernel (raw-cost patches + role A's one-tap path) where the radius has an
         # instantiation and LES_HIP_KERNEL does not force the strip kernel; both must meet the same bound
         bt = api.Batch(pr.e, layer.filter[cells], layer.shared[cells])
-        want = 1 if (4 <= windR // 2 <= 10 and os.environ.get("LES_HIP_KERNEL", "") != "strip") else 0
+        want = 1 if (2 <= windR // 2 <= 10 and os.environ.get("LES_HIP_KERNEL", "") != "strip") else 0
         assert bt.kernel_kind(mode) == want, (windR, bt.kernel_kind(mode))
         bt.destroy()
     pr.close()

@@ -87,7 +87,7 @@ def test_gpu_wta(mid):
 
 
 def test_gpu_other_radii(oracle_mod):
-    # guided-filter radius = windR / 2: the strip kernel is instantiated for radii 1 .. 10, 12, 15 (csrc/les_hip.hip: kStrip), the march kernel for 4 .. 10
+    # guided-filter radius = windR / 2: the strip kernel is instantiated for radii 1 .. 10, 12, 15 (csrc/les_hip.hip: kStrip), the march kernel for 2 .. 10
     # (kMarch); every radius below runs on whichever serves it and is compared with the oracle
     for windR, eps, th in ((2, 1e-2, 0.5), (4, 1e-3, 0.8), (6, 1e-4, 0.5), (8, 1e-4, 0.5), (10, 1e-4, 0.5), (12, 1e-4, 0.3),
                            (14, 1e-4, 0.5), (15, 1e-4, 0.5), (16, 1e-5, 1.5), (18, 1e-4, 0.5), (20, 1e-4, 0.5), (24, 1e-4, 0.5), (30, 1e-3, 0.5)):
@@ -95,7 +95,7 @@ def test_gpu_other_radii(oracle_mod):
         try:
             layer = pc.om.Layer(pr.W, pr.H, windR, 11)
             b = pc.api.Batch(pr.e, layer.filter[layer.sets[0]], layer.shared[layer.sets[0]])
-            assert b.kernel_kind(0) == (1 if 4 <= windR // 2 <= 10 else 0), windR       # radii 4 .. 10 are served by the march kernel
+            assert b.kernel_kind(0) == (1 if 2 <= windR // 2 <= 10 else 0), windR       # radii 2 .. 10 are served by the march kernel
             b.destroy()
             for s in (0, 6):
                 cells = layer.sets[s]
