@@ -405,18 +405,27 @@ __global__ void les_ransac_walk_kernel(const Rect4* __restrict__ units, uint64_t
     const Rect4 u = units[cell];
     const int len = u.w * u.h;
     const size_t base = (size_t)cell * MAX_SAM;
+    // (one thread walks one cell: a chain of dependent loads unless the inlier counts of the next eight candidates are fetched together)
     while (c.no_sam < c.max_sam && c.no_sam < j1) {                    // :193
-        const int j = c.no_sam;
-        c.no_sam++;
-        const int no_i = sc.noi[base + j];
-        if (c.max_i < no_i) {                                          // :208
-            const int no = sc.no[base + j];
-            if (no > c.no_i_c) {                                       // :229-236
-                c.result[0] = sc.refit[(base + j) * 3]; c.result[1] = sc.refit[(base + j) * 3 + 1]; c.result[2] = sc.refit[(base + j) * 3 + 2];
-                c.no_i_c = no;
-                c.max_i = no_i;
-                const int cnt = ransac_sample_count(no, len, 3, conf);
-                c.max_sam = c.max_sam < cnt ? c.max_sam : cnt;
+        const int jb = c.no_sam;
+        int noi8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) noi8[q] = jb + q < j1 ? sc.noi[base + jb + q] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (!(c.no_sam < c.max_sam && c.no_sam < j1)) break;
+            const int j = c.no_sam;
+            c.no_sam++;
+            const int no_i = noi8[q];
+            if (c.max_i < no_i) {                                      // :208
+                const int no = sc.no[base + j];
+                if (no > c.no_i_c) {                                   // :229-236
+                    c.result[0] = sc.refit[(base + j) * 3]; c.result[1] = sc.refit[(base + j) * 3 + 1]; c.result[2] = sc.refit[(base + j) * 3 + 2];
+                    c.no_i_c = no;
+                    c.max_i = no_i;
+                    const int cnt = ransac_sample_count(no, len, 3, conf);
+                    c.max_sam = c.max_sam < cnt ? c.max_sam : cnt;
+                }
             }
         }
     }
