@@ -263,8 +263,8 @@ __device__ inline void ransac_draw(const Rect4& u, RansacScratch& sc, int cell, 
     uint64_t* st = sc.state + (size_t)cell * (MAX_SAM + 1);
     Rng r{st[j0]};
     const uint64_t M = len > 0 ? ~0ull / (uint32_t)len + 1 : 0;          // uniform(0, len) = next() % len (cv::RNG), as fastmod_u32
-    for (int j = j0; j < j1; j++) {
-        // three distinct uniformly random indices: the first three entries of randperm (:163-174,196-201)
+    // one sample the exact way: three distinct uniformly random indices, the first three entries of randperm (:163-174,196-201)
+    auto draw_one = [&](int j) {
         int idx[3];
         for (int i = 0; i < 3; i++) {
             bool again;
@@ -276,7 +276,34 @@ __device__ inline void ransac_draw(const Rect4& u, RansacScratch& sc, int cell, 
         }
         idxp[j * 3 + 0] = idx[0]; idxp[j * 3 + 1] = idx[1]; idxp[j * 3 + 2] = idx[2];
         st[j + 1] = r.state;
+    };
+    int j = j0;
+    // Four samples at a time on the assumption that no draw repeats an index of its sample (a repeat has probability ~3 / len per sample): the twelve
+    // generator steps are one short chain and the twelve reductions mod len independent of each other, instead of one dependent stream of
+    // step -> reduce -> compare -> branch per draw.  A batch with a repeat is drawn again the exact way, from the state it started with.
+    for (; len > 2 && j + 4 <= j1; j += 4) {
+        Rng t{r.state};
+        uint64_t s[12];
+        int id[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) { id[q] = (int)t.next(); s[q] = t.state; }
+#pragma unroll
+        for (int q = 0; q < 12; q++) id[q] = (int)fastmod_u32((uint32_t)id[q], M, (uint32_t)len);
+        bool distinct = true;
+#pragma unroll
+        for (int q = 0; q < 12; q += 3) distinct = distinct && id[q] != id[q + 1] && id[q] != id[q + 2] && id[q + 1] != id[q + 2];
+        if (distinct) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                idxp[(j + q) * 3 + 0] = id[3 * q]; idxp[(j + q) * 3 + 1] = id[3 * q + 1]; idxp[(j + q) * 3 + 2] = id[3 * q + 2];
+                st[j + q + 1] = s[3 * q + 2];
+            }
+            r.state = s[11];
+        } else {
+            for (int q = 0; q < 4; q++) draw_one(j + q);
+        }
     }
+    for (; j < j1; j++) draw_one(j);
 }
 
 __global__ void les_ransac_begin_kernel(const Rect4* __restrict__ units, const uint64_t* __restrict__ rng, RansacScratch sc, int n, int MAX_SAM, int first)
